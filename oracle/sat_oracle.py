@@ -1,0 +1,400 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement of the Show-Attend-and-Tell
+train-step hot path.
+
+This file restates, in plain fp32 PyTorch-CPU ops over a *state dict*, what the
+reference computes.  Every function cites the reference lines it follows
+(paths are under /root/reference).  It is the checker for the HIP path and the
+"port" CPU baseline of bench.py; it is never imported by the product package.
+
+Pinning: ``tests/golden/*.npz`` were produced by importing the reference's own
+``model.py`` in the build container (``tests/golden/make_golden.py``) and
+``tests/test_oracle_golden.py`` checks this restatement against them
+(decoder rows a2-a10: pinned).  The torchvision ResNet arithmetic (row a1) is
+third party and absent from the reference tree: **encoder parity is unpinned
+at the reference level**; it is pinned only structurally (parameter counts /
+feature dims from dev/encoder_summaries.txt:2-18 and the 256px -> 8x8 map).
+
+Dropout is not restated: parity runs use dropout = embedding_dropout = 0
+(train.py:140-143 defaults), where ``nn.Dropout`` is the identity.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+# --------------------------------------------------------------------------
+# a1. Encoder: torchvision-style ResNet trunk (third-party arithmetic; the
+#     reference only slices it: model.py:19-29).  Key names follow torchvision
+#     so real weights could be loaded from a local file.
+# --------------------------------------------------------------------------
+
+#: arch -> (block kind, blocks per stage, width per group)
+RESNET_TABLE = {
+    "resnet18": ("basic", (2, 2, 2, 2), 64),
+    "resnet34": ("basic", (3, 4, 6, 3), 64),
+    "resnet50": ("bottleneck", (3, 4, 6, 3), 64),
+    "resnet101": ("bottleneck", (3, 4, 23, 3), 64),
+    "resnet152": ("bottleneck", (3, 8, 36, 3), 64),
+    "wide_resnet50_2": ("bottleneck", (3, 4, 6, 3), 128),
+    "wide_resnet101_2": ("bottleneck", (3, 4, 23, 3), 128),
+}
+
+
+class _Residual(nn.Module):
+    """One residual unit.  ``kind`` selects 3x3-3x3 or 1x1-3x3-1x1 (stride on
+    the 3x3, i.e. the "v1.5" layout torchvision uses)."""
+
+    def __init__(self, kind, cin, planes, stride, width_per_group):
+        super().__init__()
+        self.kind = kind
+        if kind == "basic":
+            cout = planes
+            self.conv1 = nn.Conv2d(cin, planes, 3, stride, 1, bias=False)
+            self.bn1 = nn.BatchNorm2d(planes)
+            self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+            self.bn2 = nn.BatchNorm2d(planes)
+        else:
+            cout = planes * 4
+            mid = int(planes * (width_per_group / 64.0))
+            self.conv1 = nn.Conv2d(cin, mid, 1, 1, 0, bias=False)
+            self.bn1 = nn.BatchNorm2d(mid)
+            self.conv2 = nn.Conv2d(mid, mid, 3, stride, 1, bias=False)
+            self.bn2 = nn.BatchNorm2d(mid)
+            self.conv3 = nn.Conv2d(mid, cout, 1, 1, 0, bias=False)
+            self.bn3 = nn.BatchNorm2d(cout)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(
+                nn.Conv2d(cin, cout, 1, stride, 0, bias=False), nn.BatchNorm2d(cout))
+        self.cout = cout
+
+    def forward(self, x):
+        skip = x if self.downsample is None else self.downsample(x)
+        y = self.relu(self.bn1(self.conv1(x)))
+        if self.kind == "basic":
+            y = self.bn2(self.conv2(y))
+        else:
+            y = self.relu(self.bn2(self.conv2(y)))
+            y = self.bn3(self.conv3(y))
+        y += skip
+        return self.relu(y)
+
+
+class ResNetOracle(nn.Module):
+    """Child order conv1,bn1,relu,maxpool,layer1..4,avgpool,fc so that the
+    reference's ``list(m.children())[:-2]`` (model.py:29) keeps the trunk."""
+
+    def __init__(self, arch, num_classes=1000):
+        super().__init__()
+        kind, depths, wpg = RESNET_TABLE[arch]
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        cin = 64
+        for si, (planes, nblk) in enumerate(zip((64, 128, 256, 512), depths)):
+            blocks = []
+            for bi in range(nblk):
+                blk = _Residual(kind, cin, planes, (2 if si > 0 and bi == 0 else 1), wpg)
+                cin = blk.cout
+                blocks.append(blk)
+            setattr(self, "layer%d" % (si + 1), nn.Sequential(*blocks))
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(cin, num_classes)
+        self.feature_dim = cin
+        for mod in self.modules():
+            if isinstance(mod, nn.Conv2d):
+                nn.init.kaiming_normal_(mod.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(mod, nn.BatchNorm2d):
+                nn.init.ones_(mod.weight)
+                nn.init.zeros_(mod.bias)
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        return self.fc(torch.flatten(self.avgpool(x), 1))
+
+
+class NormalizeInplace(nn.Module):
+    """torchvision.transforms.Normalize(mean, std, inplace=True) on a batch:
+    ``x.sub_(mean).div_(std)`` (used at model.py:59; mutates its input, F9)."""
+
+    def __init__(self, mean, std, inplace=True):
+        super().__init__()
+        self.mean, self.std, self.inplace = list(mean), list(std), inplace
+
+    def forward(self, x):
+        if not self.inplace:
+            x = x.clone()
+        m = torch.as_tensor(self.mean, dtype=x.dtype, device=x.device).view(-1, 1, 1)
+        s = torch.as_tensor(self.std, dtype=x.dtype, device=x.device).view(-1, 1, 1)
+        return x.sub_(m).div_(s)
+
+
+def resnet_factory(arch):
+    """Callable with torchvision's ``models.<arch>(pretrained=...)`` signature."""
+
+    def make(pretrained=False, **_):
+        if pretrained:
+            raise RuntimeError("no pretrained weights offline (SURVEY 8c)")
+        return ResNetOracle(arch)
+
+    make.__name__ = arch
+    return make
+
+
+def build_encoder(hp):
+    """Restates get_encoder (model.py:16-63) for the resnet family, plus the
+    ``encoder_size`` resize the README documents (readme.md:118-121, F2).
+
+    Returns nn.Sequential whose state-dict keys equal the reference's
+    (``1.weight`` conv1, ``2.*`` bn1, ``5..8`` layer1..4, ``9.*`` 1x1 proj)."""
+    if hp.encoder_arch not in RESNET_TABLE:
+        raise ValueError("Encoder not supported : {}".format(hp.encoder_arch))
+    net = ResNetOracle(hp.encoder_arch)
+    trunk = [net.conv1, net.bn1, net.relu, net.maxpool, net.layer1, net.layer2, net.layer3, net.layer4]
+    # model.py:46-48: a zero image is pushed through the (train-mode) trunk to read the
+    # feature dim; as a side effect every BatchNorm's running stats see one batch.
+    probe = nn.Sequential(*trunk)(torch.zeros(1, 3, hp.input_size, hp.input_size))
+    final_dim, final_size = probe.shape[1], probe.shape[-1]
+    if getattr(hp, "encoder_dim", None) is not None and hp.encoder_dim != final_dim:
+        trunk.append(nn.Conv2d(final_dim, hp.encoder_dim, kernel_size=1, stride=1, bias=True))
+    else:
+        hp.encoder_dim = final_dim
+    es = getattr(hp, "encoder_size", None)
+    if es is not None:
+        if es < final_size:
+            trunk.append(nn.AdaptiveAvgPool2d((es, es)))
+        elif es > final_size:
+            trunk.append(nn.Upsample((es, es), mode="bilinear", align_corners=False))
+    return nn.Sequential(NormalizeInplace(hp.mean, hp.std, inplace=True), *trunk)
+
+
+def trunk_param_count(arch):
+    """Parameters of the trunk without fc (dev/encoder_summaries.txt:2-18)."""
+    net = ResNetOracle(arch)
+    return sum(p.numel() for n, p in net.named_parameters() if not n.startswith("fc.")), net.feature_dim
+
+
+# --------------------------------------------------------------------------
+# a2-a7. Decoder pieces over a state dict ``sd`` (reference key names,
+#        SURVEY 8b).  All tensors fp32 CPU.
+# --------------------------------------------------------------------------
+
+def init_state(sd, ann, layers, n):
+    """InitLSTM.forward (model.py:76-81).  ann (N,D,h,w) -> h0,c0 (layers,N,n).
+    The ``reshape`` is a raw reinterpretation of the (N, 2*layers*n) buffer --
+    no permute -- so rows mix across the batch."""
+    mean = ann.mean((2, 3))
+    v = F.linear(F.linear(mean, sd["init_lstm.factorize.weight"], sd["init_lstm.factorize.bias"]),
+                 sd["init_lstm.init.weight"], sd["init_lstm.init.bias"])
+    flat = v.reshape(2 * layers, mean.shape[0], n)
+    return flat[:layers], flat[layers:]
+
+
+def soft_attention(sd, ann, h):
+    """SoftAttention.forward (model.py:94-109).  ann (N,D,h,w), h (N,n) ->
+    z (N,D), alpha (N,h,w).  Scores are scaled by L**-0.5 (F8)."""
+    N, D, H, W = ann.shape
+    a = ann.reshape(N, D, H * W).permute(0, 2, 1)                      # (N,L,D)
+    u = F.linear(a, sd["attention.encoder_att.weight"])                # (N,L,A)  F4: loop invariant
+    q = F.linear(h, sd["attention.decoder_att.weight"]).unsqueeze(1)   # (N,1,A)
+    s = F.linear(torch.tanh(u + q), sd["attention.f_att.weight"]) * a.shape[1] ** -0.5
+    alpha = F.softmax(s, dim=1)                                        # (N,L,1)
+    z = (a * alpha).sum(dim=1)
+    return z, alpha.permute(0, 2, 1).reshape(N, H, W)
+
+
+def beta_gate(sd, h):
+    """self.beta = Sigmoid(Linear(n->D)) (model.py:187-192, used at 538)."""
+    return torch.sigmoid(F.linear(h, sd["beta.0.weight"], sd["beta.0.bias"]))
+
+
+def embed(sd, idx, max_norm=None, padding_idx=0):
+    """self.embedding (model.py:158-163).  ``max_norm`` renormalises the
+    looked-up rows of the weight in place, as nn.Embedding does."""
+    return F.embedding(idx, sd["embedding.weight"], padding_idx=padding_idx, max_norm=max_norm)
+
+
+def lstm_weights(sd, layers):
+    out = []
+    for k in range(layers):
+        out += [sd["lstm.weight_ih_l%d" % k], sd["lstm.weight_hh_l%d" % k],
+                sd["lstm.bias_ih_l%d" % k], sd["lstm.bias_hh_l%d" % k]]
+    return out
+
+
+def lstm_step(sd, x, h, c, layers):
+    """One time step of nn.LSTM (model.py:175-180, calls at 326/544) through the
+    same ATen entry point nn.LSTM.forward uses.  x (1,N,m+D); h,c (layers,N,n)."""
+    _, hn, cn = torch._VF.lstm(x, (h, c), lstm_weights(sd, layers), True, layers, 0.0, False, False, False)
+    return hn, cn
+
+
+def lstm_step_math(sd, x, h, c, layers):
+    """The same step written out (gate order i,f,g,o; two biases; F1):
+    g = x W_ih^T + b_ih + h W_hh^T + b_hh; c' = s(f) c + s(i) tanh(g); h' = s(o) tanh(c')."""
+    hs, cs = [], []
+    inp = x[0]
+    for k in range(layers):
+        g = (F.linear(inp, sd["lstm.weight_ih_l%d" % k], sd["lstm.bias_ih_l%d" % k])
+             + F.linear(h[k], sd["lstm.weight_hh_l%d" % k], sd["lstm.bias_hh_l%d" % k]))
+        i, f, gg, o = g.chunk(4, dim=1)
+        cn = torch.sigmoid(f) * c[k] + torch.sigmoid(i) * torch.tanh(gg)
+        hn = torch.sigmoid(o) * torch.tanh(cn)
+        hs.append(hn)
+        cs.append(cn)
+        inp = hn
+    return torch.stack(hs), torch.stack(cs)
+
+
+def deep_output(sd, y, h, z, deep=True):
+    """DeepOutput.forward (model.py:125-131): un-gated context z and the *new*
+    hidden state (F8).  Tied weights simply alias output.output.weight."""
+    if deep:
+        x = torch.tanh(y + F.linear(h, sd["output.hidden.weight"]) + F.linear(z, sd["output.context.weight"]))
+    else:
+        x = F.linear(h, sd["output.hidden.weight"])
+    return F.linear(x, sd["output.output.weight"], sd.get("output.output.bias"))
+
+
+# --------------------------------------------------------------------------
+# a8. train_batch (model.py:474-557)
+# --------------------------------------------------------------------------
+
+def decode_train(sd, hp, ann_img, caps, lengths, epsilon=0, draw=None, lstm_fn=lstm_step):
+    """Decoder half of train_batch: everything after ``self.encoder(img)``.
+
+    ann_img (B,D,h,w); caps (B,R,T) int64; lengths (B,R) int64.
+    Returns dict(logits (N,T-1,V), alphas (N,T-1,L), targets (N,T-1), lengths (N,)).
+    ``draw()`` supplies the per-step uniform sample of model.py:518 (default:
+    the global CPU generator, consumed exactly as the reference does, F7)."""
+    if draw is None:
+        draw = lambda: float(torch.rand(1))
+    layers, n, V = hp.decoder_layers, hp.decoder_dim, hp.vocab_size
+    R = lengths.size(1)
+    ann = ann_img.repeat_interleave(R, dim=0)                 # model.py:487 (F5)
+    _, _, Hh, Ww = ann.shape
+    caps = caps.reshape(-1, caps.size(2))
+    lens = lengths.reshape(-1)
+    h, c = init_state(sd, ann, layers, n)                     # model.py:498
+    h, c = h.clone(), c.clone()
+    N, T = caps.shape
+    logits = torch.zeros(N, T - 1, V)
+    alphas = torch.zeros(N, T - 1, Hh * Ww)
+    for step in range(T - 1):
+        live = lens > step                                    # model.py:512 (F6)
+        if not bool(live.any()):
+            break
+        if step <= 2 or draw() <= epsilon:                    # model.py:518 (F7)
+            tok = caps[live, step]
+        else:
+            tok = torch.argmax(logits[live, step - 1, :], dim=1)
+        y = embed(sd, tok, getattr(hp, "embed_norm", None))
+        z, alpha = soft_attention(sd, ann[live], h[-1, live])
+        alphas[live, step, :] = alpha.reshape(int(live.sum()), Hh * Ww)
+        gate = beta_gate(sd, h[-1, live])
+        x = torch.cat([y, gate * z], dim=1).unsqueeze(0)
+        hn, cn = lstm_fn(sd, x, h[:, live], c[:, live], layers)
+        h = h.clone(); c = c.clone()
+        h[:, live] = hn
+        c[:, live] = cn
+        logits[live, step, :] = deep_output(sd, y, h[-1, live], z, hp.deep_output).float()
+    return dict(logits=logits, alphas=alphas, targets=caps[:, 1:], lengths=lens)
+
+
+def pack_time_major(x, lens):
+    """``pack_padded_sequence(x, lens, batch_first=True, enforce_sorted=False)``
+    (model.py:553-554): returns (.data, .batch_sizes as list).  Rows are ordered
+    time-major over the batch sorted by length descending; ties follow
+    ``torch.sort`` (not stable), so the library call itself is used."""
+    packed = torch.nn.utils.rnn.pack_padded_sequence(x, lens.tolist(), batch_first=True, enforce_sorted=False)
+    return packed.data, packed.batch_sizes.tolist()
+
+
+# --------------------------------------------------------------------------
+# a9/a10. Losses (util.py:105-112, model.py:592-597)
+# --------------------------------------------------------------------------
+
+def label_smoothing_ce(x, target, smoothing=0.0):
+    """LabelSmoothing.forward (util.py:105-112)."""
+    logp = F.log_softmax(x, dim=-1)
+    nll = -logp.gather(dim=-1, index=target.unsqueeze(1)).squeeze(1)
+    smooth = -logp.mean(dim=-1)
+    return ((1.0 - smoothing) * nll + smoothing * smooth).mean()
+
+
+def doubly_stochastic(alphas, gamma):
+    """model.py:594: gamma * ((1 - sum_t alpha)^2).mean() over (N, L)."""
+    return gamma * ((1 - alphas.sum(dim=1)) ** 2).mean()
+
+
+def training_loss(sd, hp, ann_img, caps, lengths, epsilon=0, draw=None):
+    """model.py:589-597 without the logging: returns (loss, parts)."""
+    out = decode_train(sd, hp, ann_img, caps, lengths, epsilon, draw)
+    lp, bs = pack_time_major(out["logits"], out["lengths"])
+    tp, _ = pack_time_major(out["targets"], out["lengths"])
+    ce = label_smoothing_ce(lp, tp, hp.label_smoothing)
+    ds = doubly_stochastic(out["alphas"], hp.att_gamma)
+    loss = ce + ds
+    pred = torch.argmax(lp, dim=1)
+    acc = torch.sum(pred == tp) / pred.shape[0]
+    out.update(logits_packed=lp, targets_packed=tp, batch_sizes=bs, ce=ce, ds=ds, loss=loss, acc=acc)
+    return loss, out
+
+
+# --------------------------------------------------------------------------
+# Convenience: default hyper-parameters (train.py:16-165 defaults for the
+# hot-path keys listed in SURVEY section 5) and random state dicts.
+# --------------------------------------------------------------------------
+
+def default_hparams(**over):
+    V = over.get("vocab_size", 64)
+    stoi = {"<PAD>": 0, "<UNK>": V - 3, "<START>": V - 2, "<END>": V - 1}
+    hp = dict(encoder_arch="resnet18", pretrained=False, input_size=256, encoder_dim=256, encoder_size=None,
+              mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225], embed_dim=256, embed_norm=None,
+              attention_dim=128, decoder_dim=512, decoder_layers=1, dropout=0.0, embedding_dropout=0.0,
+              label_smoothing=0.0, weight_tying=False, deep_output=True, att_gamma=1.0, vocab_size=V,
+              vocab_stoi=stoi, vocab_itos={v: k for k, v in stoi.items()}, pretrained_embedding=None,
+              decoder_tf="always", decoder_tf_min=0.5, epochs=10, encoder_finetune_after=-1)
+    hp.update(over)
+    return SimpleNamespace(**hp)
+
+
+def random_decoder_state(hp, seed=0):
+    """Decoder state dict with the reference's shapes and torch's
+    default initialisers' scale; used when no reference module is at hand."""
+    g = torch.Generator().manual_seed(seed)
+    D, m, A, n, V, K = hp.encoder_dim, hp.embed_dim, hp.attention_dim, hp.decoder_dim, hp.vocab_size, hp.decoder_layers
+
+    def U(shape, fan_in):
+        b = 1.0 / math.sqrt(fan_in)
+        return (torch.rand(shape, generator=g) * 2 - 1) * b
+
+    sd = {"embedding.weight": torch.randn(V, m, generator=g)}
+    sd["embedding.weight"][0].zero_()
+    sd["init_lstm.factorize.weight"] = U((m, D), D); sd["init_lstm.factorize.bias"] = U((m,), D)
+    sd["init_lstm.init.weight"] = U((2 * n * K, m), m); sd["init_lstm.init.bias"] = U((2 * n * K,), m)
+    for k in range(K):
+        cin = m + D if k == 0 else n
+        sd["lstm.weight_ih_l%d" % k] = U((4 * n, cin), n); sd["lstm.weight_hh_l%d" % k] = U((4 * n, n), n)
+        sd["lstm.bias_ih_l%d" % k] = U((4 * n,), n); sd["lstm.bias_hh_l%d" % k] = U((4 * n,), n)
+    sd["attention.encoder_att.weight"] = U((A, D), D)
+    sd["attention.decoder_att.weight"] = U((A, n), n)
+    sd["attention.f_att.weight"] = U((1, A), A)
+    sd["beta.0.weight"] = U((D, n), n); sd["beta.0.bias"] = torch.full((D,), 1.0 / n)
+    sd["output.hidden.weight"] = U((m, n), n)
+    if hp.deep_output:
+        sd["output.context.weight"] = U((m, D), D)
+    if hp.weight_tying and hp.deep_output:
+        sd["output.output.weight"] = sd["embedding.weight"]
+    else:
+        sd["output.output.weight"] = U((V, m), m)
+    if not hp.weight_tying:
+        sd["output.output.bias"] = U((V,), m)
+    return sd

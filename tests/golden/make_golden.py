@@ -1,0 +1,222 @@
+"""Generate tests/golden/*.npz by running the REFERENCE (imported unmodified
+from /root/reference through ref_shim) on seeded inputs.  Build container only.
+
+    python tests/golden/make_golden.py
+
+Fixtures hold numbers only (inputs, weights, expected outputs).  SURVEY 8c list:
+G1 SoftAttention fwd+grads, G2 InitLSTM (F3), G3 one decode step, G4 train_batch
+(+losses, DS bit pattern), G5 gradients for G4, G6 LabelSmoothing, G8 config-size
+spot checks (C1 decoder shapes; weights regenerated from oracle/prng.py).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+from torch import nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_shim  # noqa: E402
+
+from oracle import prng, sat_oracle as O  # noqa: E402
+
+torch.set_num_threads(1)   # fixed reduction order while generating
+ref = ref_shim.load_reference()
+
+
+class _PassThrough(nn.Module):
+    """Stands where ``self.encoder`` is so that a fixture can feed annotations."""
+
+    def forward(self, x):
+        return x
+
+
+def build(hp, seed):
+    model = ref_shim.make_sat(ref, hp)
+    model.encoder = _PassThrough()
+    sd_np = prng.decoder_state(hp, seed)
+    missing = model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()}, strict=False)
+    assert not missing.unexpected_keys, missing
+    assert all(k.startswith("encoder") for k in missing.missing_keys), missing
+    model.train()
+    return model, sd_np
+
+
+def f32bits(x):
+    return np.asarray(np.float32(x)).view(np.uint32)
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
+    print("%-28s %7.1f KB" % (name, os.path.getsize(path) / 1024))
+
+
+def small_hp(**over):
+    base = dict(vocab_size=23, encoder_dim=12, embed_dim=10, attention_dim=7, decoder_dim=9, input_size=64)
+    base.update(over)
+    return O.default_hparams(**base)
+
+
+# ---------------------------------------------------------------- G1
+def g1():
+    hp = small_hp()
+    model, sd = build(hp, 11)
+    N, H, W = 5, 2, 3
+    ann = torch.from_numpy(prng.uniform((N, hp.encoder_dim, H, W), 101)).requires_grad_()
+    hid = torch.from_numpy(prng.uniform((N, hp.decoder_dim), 102)).requires_grad_()
+    gz = torch.from_numpy(prng.uniform((N, hp.encoder_dim), 103))
+    ga = torch.from_numpy(prng.uniform((N, H, W), 104))
+    z, alpha = model.attention(ann, hid)
+    ((z * gz).sum() + (alpha * ga).sum()).backward()
+    att = model.attention
+    save("g1_attention", ann=ann.detach(), hid=hid.detach(), gz=gz, ga=ga,
+         We=sd["attention.encoder_att.weight"], Wd=sd["attention.decoder_att.weight"], wf=sd["attention.f_att.weight"],
+         z=z.detach(), alpha=alpha.detach(), d_ann=ann.grad, d_hid=hid.grad,
+         d_We=att.encoder_att.weight.grad, d_Wd=att.decoder_att.weight.grad, d_wf=att.f_att.weight.grad)
+
+
+# ---------------------------------------------------------------- G2
+def g2():
+    out = {}
+    for layers in (1, 2):
+        for N in (4, 5):
+            hp = small_hp(decoder_layers=layers)
+            model, sd = build(hp, 20 + layers)
+            ann = torch.from_numpy(prng.uniform((N, hp.encoder_dim, 3, 2), 200 + N))
+            h0, c0 = model.init_lstm(ann)
+            tag = "L%d_N%d_" % (layers, N)
+            out.update({tag + "ann": ann, tag + "h0": h0.detach(), tag + "c0": c0.detach()})
+            for k in ("init_lstm.factorize.weight", "init_lstm.factorize.bias", "init_lstm.init.weight", "init_lstm.init.bias"):
+                out["L%d_%s" % (layers, k)] = sd[k]
+    save("g2_initlstm", **out)
+
+
+# ---------------------------------------------------------------- G3
+def g3():
+    for tag, over in (("deep", {}), ("shallow", dict(deep_output=False)),
+                      ("tied", dict(weight_tying=True)), ("layers2", dict(decoder_layers=2))):
+        hp = small_hp(**over)
+        model, sd = build(hp, 30)
+        N, H, W = 4, 3, 2
+        ann = torch.from_numpy(prng.uniform((N, hp.encoder_dim, H, W), 301))
+        h = torch.from_numpy(prng.uniform((hp.decoder_layers, N, hp.decoder_dim), 302))
+        c = torch.from_numpy(prng.uniform((hp.decoder_layers, N, hp.decoder_dim), 303))
+        tok = torch.from_numpy(prng.integers((N,), 304, 0, hp.vocab_size))
+        with torch.no_grad():                                   # model.py:526-547, one iteration
+            y = model.embedding_dropout(model.embedding(tok))
+            z, alpha = model.attention(ann, h[-1])
+            beta = model.beta(h[-1])
+            h_in = torch.cat([y, beta * z], dim=1).unsqueeze(0)
+            _, (hn, cn) = model.lstm(h_in, (h, c))
+            logit = model.output(y, hn[-1], z)
+        arrs = {"sd." + k: v for k, v in sd.items()}
+        save("g3_step_" + tag, ann=ann, h=h, c=c, tok=tok, z=z, alpha=alpha, beta=beta, hn=hn, cn=cn, logit=logit, **arrs)
+
+
+# ---------------------------------------------------------------- G4 + G5
+def g4(tag, eps, seed, B=3, R=2, T=8, H=2, W=3, **over):
+    hp = small_hp(**over)
+    model, sd = build(hp, seed)
+    ann = torch.from_numpy(prng.uniform((B, hp.encoder_dim, H, W), seed + 1)).requires_grad_()
+    caps_np, len_np = prng.captions(B, R, T, hp.vocab_size, seed + 2)
+    caps, lengths = torch.from_numpy(caps_np), torch.from_numpy(len_np)
+    # The reference draws torch.rand(1) once per step > 2 (model.py:518).  Record the draws.
+    n_draws = max(0, min(T - 1, int(len_np.max())) - 3)
+    torch.manual_seed(seed)
+    draws = np.array([float(torch.rand(1)) for _ in range(n_draws)], np.float64)
+    torch.manual_seed(seed)
+    lp, tp, alphas = model.train_batch((ann, caps, lengths), epsilon=eps)
+    ce = model.criterion(lp.data, tp.data)
+    ds = hp.att_gamma * ((1 - alphas.sum(dim=1)) ** 2).mean()
+    loss = ce + ds                                                     # model.py:592-594
+    pred = torch.argmax(lp.data, dim=1)
+    acc = torch.sum(pred == tp.data) / pred.shape[0]
+    loss.backward()
+    grads = {"g." + k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    arrs = {"sd." + k: v for k, v in sd.items() if not (k == "output.output.weight" and hp.weight_tying and hp.deep_output)}
+    save("g4_train_" + tag, ann=ann.detach(), caps=caps, lengths=lengths, epsilon=np.float64(eps), draws=draws,
+         logits_packed=lp.data.detach(), targets_packed=tp.data, batch_sizes=lp.batch_sizes,
+         sorted_indices=lp.sorted_indices, alphas=alphas.detach(),
+         ce=ce.detach(), ds=ds.detach(), loss=loss.detach(), acc=acc,
+         ce_bits=f32bits(ce.item()), ds_bits=f32bits(ds.item()), loss_bits=f32bits(loss.item()),
+         d_ann=ann.grad, hp_label_smoothing=hp.label_smoothing, hp_att_gamma=hp.att_gamma,
+         hp_deep_output=int(hp.deep_output), hp_weight_tying=int(hp.weight_tying), hp_layers=hp.decoder_layers,
+         hp_embed_norm=(-1.0 if hp.embed_norm is None else hp.embed_norm), **arrs, **grads)
+
+
+# ---------------------------------------------------------------- G6
+def g6():
+    util = sys.modules["util"]
+    x = torch.from_numpy(prng.uniform((20, 10), 601, -3, 3)).requires_grad_()
+    t = torch.from_numpy(prng.integers((20,), 602, 0, 10))
+    out = dict(x=x.detach(), t=t, ce_torch=torch.nn.functional.cross_entropy(x, t).detach())
+    for s in (0.0, 0.15, 0.3):
+        x.grad = None
+        loss = util.LabelSmoothing(s)(x, t)
+        loss.backward()
+        out["loss_%g" % s] = loss.detach()
+        out["grad_%g" % s] = x.grad.clone()
+    save("g6_label_smoothing", **out)
+
+
+# ---------------------------------------------------------------- G8 (C1 decoder shapes)
+def g8():
+    hp = O.default_hparams(vocab_size=6400, encoder_dim=256, embed_dim=256, attention_dim=128, decoder_dim=512, input_size=64)
+    model, _ = build(hp, 80)
+    B, R, T = 8, 5, 22
+    ann = torch.from_numpy(prng.uniform((B, 256, 7, 7), 801, 0.0, 2.0)).requires_grad_()
+    caps_np, len_np = prng.captions(B, R, T, 6400, 802, min_len=8)
+    torch.set_num_threads(8)
+    lp, tp, alphas = model.train_batch((ann, torch.from_numpy(caps_np), torch.from_numpy(len_np)), epsilon=1)
+    ce = model.criterion(lp.data, tp.data)
+    ds = ((1 - alphas.sum(dim=1)) ** 2).mean()
+    (ce + ds).backward()
+    g = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    sums = {"gsum." + k: v.double().sum() for k, v in g.items()}
+    asums = {"gabs." + k: v.double().abs().sum() for k, v in g.items()}
+    save("g8_c1_decoder", logits_head=lp.data[:64, :32].detach(), logits_sum=lp.data.double().sum().detach(),
+         logits_abs=lp.data.double().abs().sum().detach(), alphas_head=alphas[:4].detach(), alphas_sum=alphas.double().sum().detach(),
+         ce=ce.detach(), ds=ds.detach(), ds_bits=f32bits(ds.item()), d_ann_head=ann.grad[:2, :16], d_ann_sum=ann.grad.double().sum(),
+         d_ann_abs=ann.grad.double().abs().sum(), n_tokens=np.int64(lp.data.shape[0]), **sums, **asums)
+    torch.set_num_threads(1)
+
+
+# ---------------------------------------------------------------- encoder (structural + reference get_encoder logic)
+def g_encoder():
+    hp = O.default_hparams(encoder_arch="resnet18", encoder_dim=32, input_size=64)
+    torch.manual_seed(7)
+    enc_ref = ref.get_encoder(hp)                 # reference slicing / 1x1 conv / Normalize over the repo's ResNet
+    hp2 = O.default_hparams(encoder_arch="resnet18", encoder_dim=32, input_size=64)
+    torch.manual_seed(7)
+    enc_own = O.build_encoder(hp2)
+    k1, k2 = list(enc_ref.state_dict().keys()), list(enc_own.state_dict().keys())
+    assert k1 == k2, "state-dict keys differ"
+    for k in k1:
+        assert torch.equal(enc_ref.state_dict()[k], enc_own.state_dict()[k]), k
+    img = torch.from_numpy(prng.uniform((2, 3, 64, 64), 901, 0.0, 1.0))
+    y1 = enc_ref(img.clone())
+    y2 = enc_own(img.clone())
+    assert torch.equal(y1, y2), "oracle build_encoder != reference get_encoder on the same trunk"
+    counts = {}
+    for arch in ("resnet18", "resnet50", "resnet101", "wide_resnet101_2"):
+        n, f = O.trunk_param_count(arch)
+        counts["params." + arch] = np.int64(n)
+        counts["features." + arch] = np.int64(f)
+    save("g_encoder", keys=np.array(k1), out_shape=np.array(y1.shape), out_head=y1[0, :8].detach(),
+         out_sum=y1.double().sum().detach(), seed=np.int64(7), **counts)
+
+
+if __name__ == "__main__":
+    g1(); g2(); g3()
+    g4("tf1", 1.0, 40)
+    g4("tf0", 0.0, 41)
+    g4("tf05", 0.5, 42, T=10)
+    g4("smooth", 1.0, 43, label_smoothing=0.15)
+    g4("shallow", 1.0, 44, deep_output=False)
+    g4("tied", 1.0, 45, weight_tying=True)
+    g4("layers2", 1.0, 46, decoder_layers=2)
+    g4("embnorm", 1.0, 47, embed_norm=0.3)
+    g4("gamma", 0.0, 48, att_gamma=0.5, B=4, R=3, T=9, H=3, W=3)
+    g6(); g8(); g_encoder()

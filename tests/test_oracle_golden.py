@@ -1,0 +1,196 @@
+"""CPU: the oracle (oracle/sat_oracle.py) against the fixtures captured from the
+reference itself (tests/golden/make_golden.py).  Tolerance: the oracle runs the
+same ATen ops in the same order, so on the generating host it is bit-equal;
+another host's BLAS may round differently, hence 2e-6 relative-to-scale."""
+import glob
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import prng, sat_oracle as O
+
+TOL = 2e-6
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"), allow_pickle=False)
+
+
+def close(a, b, tol=TOL):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    scale = max(1.0, float(np.abs(b).max()) if b.size else 1.0)
+    err = float(np.abs(a - b).max()) if b.size else 0.0
+    assert err <= tol * scale, "max|d|=%g scale=%g" % (err, scale)
+
+
+def sd_from(g, grad=False):
+    sd = {k[3:]: torch.from_numpy(g[k].copy()) for k in g.files if k.startswith("sd.")}
+    if "output.output.weight" not in sd:               # tied
+        sd["output.output.weight"] = sd["embedding.weight"]
+    if grad:
+        for k, v in sd.items():
+            v.requires_grad_()
+    return sd
+
+
+def test_g1_attention(golden_dir):
+    g = load(golden_dir, "g1_attention")
+    sd = {"attention.encoder_att.weight": torch.tensor(g["We"], requires_grad=True),
+          "attention.decoder_att.weight": torch.tensor(g["Wd"], requires_grad=True),
+          "attention.f_att.weight": torch.tensor(g["wf"], requires_grad=True)}
+    ann = torch.tensor(g["ann"], requires_grad=True); hid = torch.tensor(g["hid"], requires_grad=True)
+    z, alpha = O.soft_attention(sd, ann, hid)
+    close(z.detach(), g["z"]); close(alpha.detach(), g["alpha"])
+    ((z * torch.tensor(g["gz"])).sum() + (alpha * torch.tensor(g["ga"])).sum()).backward()
+    close(ann.grad, g["d_ann"]); close(hid.grad, g["d_hid"])
+    close(sd["attention.encoder_att.weight"].grad, g["d_We"])
+    close(sd["attention.decoder_att.weight"].grad, g["d_Wd"])
+    close(sd["attention.f_att.weight"].grad, g["d_wf"])
+    np.testing.assert_allclose(alpha.detach().sum((1, 2)).numpy(), 1.0, atol=1e-6)
+
+
+@pytest.mark.parametrize("layers", [1, 2])
+@pytest.mark.parametrize("N", [4, 5])
+def test_g2_initlstm_batch_mixing(golden_dir, layers, N):
+    g = load(golden_dir, "g2_initlstm")
+    sd = {k: torch.tensor(g["L%d_%s" % (layers, k)]) for k in
+          ("init_lstm.factorize.weight", "init_lstm.factorize.bias", "init_lstm.init.weight", "init_lstm.init.bias")}
+    tag = "L%d_N%d_" % (layers, N)
+    h0, c0 = O.init_state(sd, torch.tensor(g[tag + "ann"]), layers, 9)
+    close(h0, g[tag + "h0"]); close(c0, g[tag + "c0"])
+    # F3: h0[0, i] is chunk i of the flat (N, 2*layers*n) buffer, i.e. comes from row i // (2*layers)
+    flat = torch.cat([h0, c0]).reshape(N, 2 * layers * 9)
+    assert torch.equal(flat[1, :9], h0.reshape(-1, 9)[2 * layers])
+
+
+@pytest.mark.parametrize("tag", ["deep", "shallow", "tied", "layers2"])
+def test_g3_decode_step(golden_dir, tag):
+    g = load(golden_dir, "g3_step_" + tag)
+    sd = sd_from(g)
+    layers = g["h"].shape[0]
+    deep = "output.context.weight" in sd
+    ann, h, c, tok = (torch.tensor(g[k]) for k in ("ann", "h", "c", "tok"))
+    y = O.embed(sd, tok)
+    z, alpha = O.soft_attention(sd, ann, h[-1])
+    beta = O.beta_gate(sd, h[-1])
+    x = torch.cat([y, beta * z], 1).unsqueeze(0)
+    hn, cn = O.lstm_step(sd, x, h, c, layers)
+    hm, cm = O.lstm_step_math(sd, x, h, c, layers)
+    logit = O.deep_output(sd, y, hn[-1], z, deep)
+    for got, key in ((z, "z"), (alpha, "alpha"), (beta, "beta"), (hn, "hn"), (cn, "cn"), (logit, "logit")):
+        close(got, g[key])
+    close(hm, g["hn"], 1e-5); close(cm, g["cn"], 1e-5)      # written-out cell vs ATen's
+
+
+G4 = ["tf1", "tf0", "tf05", "smooth", "shallow", "tied", "layers2", "embnorm", "gamma"]
+
+
+def g4_hp(g, sd):
+    V, m = sd["embedding.weight"].shape
+    n = sd["lstm.weight_hh_l0"].shape[1]
+    return SimpleNamespace(decoder_layers=int(g["hp_layers"]), decoder_dim=n, vocab_size=V, embed_dim=m,
+                           deep_output=bool(g["hp_deep_output"]), weight_tying=bool(g["hp_weight_tying"]),
+                           label_smoothing=float(g["hp_label_smoothing"]), att_gamma=float(g["hp_att_gamma"]),
+                           embed_norm=(None if g["hp_embed_norm"] < 0 else float(g["hp_embed_norm"])))
+
+
+@pytest.mark.parametrize("tag", G4)
+def test_g4_g5_train_batch_and_grads(golden_dir, tag, record_property):
+    g = load(golden_dir, "g4_train_" + tag)
+    sd = sd_from(g, grad=True)
+    hp = g4_hp(g, sd)
+    ann = torch.tensor(g["ann"], requires_grad=True)
+    draws = iter(g["draws"].tolist())
+    loss, out = O.training_loss(sd, hp, ann, torch.tensor(g["caps"]), torch.tensor(g["lengths"]),
+                                float(g["epsilon"]), draw=lambda: next(draws))
+    assert next(draws, None) is None, "the oracle must consume exactly the reference's RNG draws (F7)"
+    assert out["batch_sizes"] == g["batch_sizes"].tolist()
+    assert np.array_equal(out["targets_packed"].numpy(), g["targets_packed"])
+    close(out["logits_packed"].detach(), g["logits_packed"])
+    close(out["alphas"].detach(), g["alphas"])
+    close(out["ce"].detach(), g["ce"]); close(out["ds"].detach(), g["ds"]); close(loss.detach(), g["loss"])
+    close(out["acc"], g["acc"])
+    ds_bits = np.float32(out["ds"].item()).view(np.uint32)
+    ulps = abs(int(ds_bits) - int(g["ds_bits"]))
+    record_property("ds_ulps", ulps)
+    assert ulps <= 4, "doubly-stochastic loss differs by %d ulps" % ulps
+    loss.backward()
+    close(ann.grad, g["d_ann"], 1e-5)
+    for k in g.files:
+        if k.startswith("g."):
+            name = k[2:]
+            assert sd[name].grad is not None, name
+            got = sd[name].grad
+            if name == "embedding.weight" and hp.weight_tying and hp.deep_output:
+                pass                                     # one shared tensor: grad already summed
+            close(got, g[k], 1e-5)
+
+
+def test_g6_label_smoothing(golden_dir):
+    g = load(golden_dir, "g6_label_smoothing")
+    t = torch.tensor(g["t"])
+    for s in (0.0, 0.15, 0.3):
+        x = torch.tensor(g["x"], requires_grad=True)
+        loss = O.label_smoothing_ce(x, t, s)
+        loss.backward()
+        close(loss.detach(), g["loss_%g" % s]); close(x.grad, g["grad_%g" % s])
+    # dev/dev_label_smoothing.py:18-27: smoothing 0 is plain cross entropy
+    close(g["loss_0"], g["ce_torch"], 1e-6)
+
+
+def test_g8_c1_decoder_shapes(golden_dir):
+    """C1 decoder shapes (N=40, L=49, D=256, V=6400, T=22); weights regenerated from oracle/prng."""
+    g = load(golden_dir, "g8_c1_decoder")
+    hp = O.default_hparams(vocab_size=6400, encoder_dim=256, embed_dim=256, attention_dim=128, decoder_dim=512)
+    sd = {k: torch.from_numpy(v).requires_grad_() for k, v in prng.decoder_state(hp, 80).items()}
+    ann = torch.from_numpy(prng.uniform((8, 256, 7, 7), 801, 0.0, 2.0)).requires_grad_()
+    caps, lengths = prng.captions(8, 5, 22, 6400, 802, min_len=8)
+    loss, out = O.training_loss(sd, hp, ann, torch.from_numpy(caps), torch.from_numpy(lengths), 1.0)
+    lp = out["logits_packed"].detach()
+    assert lp.shape[0] == int(g["n_tokens"])
+    close(lp[:64, :32], g["logits_head"], 1e-5)
+    assert abs(lp.double().sum().item() - float(g["logits_sum"])) <= 1e-5 * float(g["logits_abs"])
+    close(out["alphas"][:4].detach(), g["alphas_head"], 1e-5)
+    close(out["ce"].detach(), g["ce"], 1e-5); close(out["ds"].detach(), g["ds"], 1e-5)
+    loss.backward()
+    close(ann.grad[:2, :16], g["d_ann_head"], 1e-4)
+    for k in g.files:
+        if k.startswith("gsum."):
+            name = k[5:]
+            got = sd[name].grad.double().sum().item()
+            assert abs(got - float(g[k])) <= 1e-4 * max(1e-3, float(g["gabs." + name])), name
+
+
+def test_encoder_structure(golden_dir):
+    """dev/encoder_summaries.txt:2-18 parameter counts / feature dims, 256px -> 8x8 (F2),
+    state-dict key layout and the F2 resize semantics (readme.md:118-121)."""
+    g = load(golden_dir, "g_encoder")
+    expect = {"resnet18": (11.18, 512), "resnet50": (23.51, 2048), "resnet101": (42.50, 2048), "wide_resnet101_2": (124.84, 2048)}
+    for arch, (mparams, feat) in expect.items():
+        assert round(int(g["params." + arch]) / 1e6, 2) == mparams
+        assert int(g["features." + arch]) == feat
+    n, f = O.trunk_param_count("resnet18")
+    assert (n, f) == (int(g["params.resnet18"]), 512)
+    hp = O.default_hparams(encoder_arch="resnet18", encoder_dim=32, input_size=64)
+    torch.manual_seed(int(g["seed"]))
+    enc = O.build_encoder(hp)
+    assert list(enc.state_dict().keys()) == g["keys"].tolist()
+    assert "1.weight" in enc.state_dict() and "9.bias" in enc.state_dict() and "5.0.conv1.weight" in enc.state_dict()
+    img = torch.from_numpy(prng.uniform((2, 3, 64, 64), 901, 0.0, 1.0))
+    y = enc(img.clone())
+    assert list(y.shape) == g["out_shape"].tolist()
+    close(y[0, :8].detach(), g["out_head"], 1e-4)       # same torch build => same initialiser stream
+    for es, L in ((7, 7), (14, 14), (None, 8)):
+        hp = O.default_hparams(encoder_arch="resnet18", encoder_dim=16, input_size=256, encoder_size=es)
+        e = O.build_encoder(hp).eval()
+        with torch.no_grad():
+            assert e(torch.rand(1, 3, 256, 256)).shape == (1, 16, L, L)
+
+
+def test_fixtures_are_small(golden_dir):
+    total = sum(os.path.getsize(p) for p in glob.glob(os.path.join(golden_dir, "*.npz")))
+    assert total < 4 << 20
