@@ -1,0 +1,136 @@
+/* sat_hip.h -- C ABI of libsat_hip.so, the MI355X (gfx950) implementation of the
+ * Show-Attend-and-Tell train-step hot path.
+ *
+ * The reference (Lukeasargen/Show-Attend-and-Tell-Pytorch-Lightning) is pure Python and
+ * has no FFI: the boundary it offers is the Python surface of `class SAT`
+ * (model.py:134) and its sub-modules.  Each entry point below replaces the stock
+ * PyTorch ops behind one of those call sites (cited per function).  INTEGRATION.md
+ * shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in `_host`;
+ *   - fp32 tensors, int32 indices, row-major; Linear weights keep torch's (out,in)
+ *     layout, conv weights are KRSC (torch channels_last memory), activations NHWC;
+ *   - no allocation, no synchronisation, no ownership transfer: the caller provides
+ *     outputs and a workspace (size from the *_workspace_bytes query) and a hipStream_t
+ *     (passed as void*); calls are capture-safe and re-entrant per stream;
+ *   - return 0 on success, non-zero otherwise with text in sat_last_error()
+ *     (thread-local).  Nothing throws, nothing exits.
+ */
+#ifndef SAT_HIP_H
+#define SAT_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAT_HIP_ABI_VERSION 1
+
+int sat_abi_version(void);
+const char* sat_last_error(void);
+
+/* ------------------------------------------------------------------ GEMM family
+ * C[MxN] = op(A)[MxK] * op(B)[KxN] on v_mfma_f32_32x32x2_f32.  Replaces nn.Linear
+ * (model.py:72-73, 90-92, 119-123, 188) and its autograd.  amode/bmode/epi: enum values
+ * of csrc/gemm.h (0 = row-major k-contiguous, 1 = k-major). */
+typedef struct sat_gemm_desc {
+    const float* A; int64_t lda; const int32_t* a_rows; /* optional row gather, -1 = zero row */
+    const float* B; int64_t ldb;
+    float* C; int64_t ldc;       const int32_t* c_rows; /* optional row scatter, -1 = skip */
+    int32_t M, N, K;
+    int32_t amode, bmode;
+    int32_t accumulate;          /* C += */
+    int32_t epi;                 /* 0 none, 1 +bias, 2 +bias & sigmoid on cols [c0,c1), 3 tanh(v+e0), 4 v*(1-e0^2), 5 relu(v+bias) */
+    const float* bias; const float* e0; int64_t lde0; int32_t c0, c1;
+    float* slab; int64_t slab_elems;   /* optional split-K scratch */
+} sat_gemm_desc;
+int sat_gemm_f32(const sat_gemm_desc* d, void* stream);
+
+/* ------------------------------------------------------------------ decoder (train_batch, model.py:474-557) */
+typedef struct sat_decoder_dims {
+    int32_t B;            /* images in the batch                                   */
+    int32_t R;            /* captions per image (lengths.size(1), model.py:487)    */
+    int32_t T;            /* caption tensor width; T-1 decode steps                */
+    int32_t L;            /* locations h*w                                         */
+    int32_t D;            /* encoder_dim                                           */
+    int32_t A;            /* attention_dim                                         */
+    int32_t m;            /* embed_dim                                             */
+    int32_t n;            /* decoder_dim                                           */
+    int32_t V;            /* vocab_size                                            */
+    int32_t P;            /* packed tokens = sum(lengths)                          */
+    int32_t deep_output;  /* DeepOutput.deep (model.py:116)                        */
+    int32_t padding_idx;  /* <PAD> id (model.py:162)                               */
+} sat_decoder_dims;
+
+/* state-dict tensors of the decoder; used for weights and, with the same
+ * field meaning, for gradient outputs. */
+typedef struct sat_decoder_params {
+    float* embedding;                 /* embedding.weight            (V, m)      */
+    float* init_f_w; float* init_f_b; /* init_lstm.factorize         (m, D), (m) */
+    float* init_i_w; float* init_i_b; /* init_lstm.init              (2n, m), (2n) */
+    float* w_ih; float* w_hh;         /* lstm.weight_ih_l0 (4n, m+D), lstm.weight_hh_l0 (4n, n) */
+    float* b_ih; float* b_hh;         /* lstm.bias_ih_l0, lstm.bias_hh_l0 (4n)   */
+    float* att_enc;                   /* attention.encoder_att.weight (A, D)     */
+    float* att_dec;                   /* attention.decoder_att.weight (A, n)     */
+    float* att_f;                     /* attention.f_att.weight       (1, A)     */
+    float* beta_w; float* beta_b;     /* beta.0                       (D, n), (D) */
+    float* out_hidden;                /* output.hidden.weight         (m, n)     */
+    float* out_context;               /* output.context.weight        (m, D), NULL when shallow */
+    float* out_w; float* out_b;       /* output.output (V, m), (V); out_b NULL under weight tying */
+} sat_decoder_params;
+
+typedef struct sat_decoder_batch {
+    const float* ann;            /* (B, L, D) annotations = encoder output, NHWC flattened          */
+    const int32_t* caps;         /* (B*R, T) encoded captions                                        */
+    const int32_t* lengths;      /* (B*R)                                                            */
+    const int32_t* prow;         /* (T-1, B*R) packed row of (step, caption) or -1 when finished    */
+    const int32_t* src_row;      /* (P) step*N + caption of packed row p                             */
+    const int32_t* step_offsets_host; /* HOST (T) : first packed row of each step, [T-1] = P         */
+    const int32_t* teacher_host;      /* HOST (T-1): 1 = feed the caption token, 0 = argmax of the
+                                         previous step's logits (scheduled sampling, model.py:518-523) */
+} sat_decoder_batch;
+
+size_t sat_decoder_workspace_bytes(const sat_decoder_dims* d);
+
+/* train_batch decoder forward (model.py:487-548): writes logits in packed order
+ * (pack_padded_sequence(...).data order, model.py:553) and alphas (N, T-1, L). */
+int sat_decoder_train_fwd(const sat_decoder_dims* d, const sat_decoder_params* w, const sat_decoder_batch* b,
+                          float* logits_packed, float* alphas, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Backward of the above through time (what autograd does for loss.backward()).
+ * dlogits_packed (P, V); dalphas (N, T-1, L) or NULL.  Overwrites every field of `g`
+ * and dann (B, L, D).  Must follow a forward on the same workspace. */
+int sat_decoder_train_bwd(const sat_decoder_dims* d, const sat_decoder_params* w, const sat_decoder_batch* b,
+                          const float* dlogits_packed, const float* alphas /* forward output */, const float* dalphas,
+                          const sat_decoder_params* g, float* dann, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------ losses
+ * LabelSmoothing.forward (util.py:105-112) over packed rows.  out[0] = loss, out[1] = accuracy
+ * (model.py:596-597).  scratch: P floats lse + P floats loss + P ints. */
+int sat_ce_label_smooth_fwd(const float* logits, const int32_t* targets, int32_t P, int32_t V, float smoothing,
+                            float* lse_rows, float* loss_rows, int32_t* correct_rows, float* out, void* stream);
+/* dlogits = gscale[0] * d loss / d logits  (gscale device pointer or NULL = 1) */
+int sat_ce_label_smooth_bwd(const float* logits, const int32_t* targets, const float* lse_rows, int32_t P, int32_t V,
+                            float smoothing, const float* gscale, float* dlogits, void* stream);
+/* model.py:594: out[0] = gamma * mean((1 - sum_t alphas)^2); asum (N, L) kept for backward;
+ * part: ceil(N*L/256) floats scratch. */
+int sat_doubly_stochastic_fwd(const float* alphas, int32_t N, int32_t T1, int32_t L, float gamma,
+                              float* asum, float* part, float* out, void* stream);
+int sat_doubly_stochastic_bwd(const float* asum, const float* gscale, int32_t N, int32_t T1, int32_t L, float gamma,
+                              float* dalphas, void* stream);
+
+/* ------------------------------------------------------------------ sub-module entry points
+ * (drop-in for attention / init_lstm called on their own, e.g. from caption(), model.py:269,299) */
+/* att_enc = ann * W_e^T (model.py:100), hoisted */
+int sat_attention_precompute(const float* ann, const float* att_enc_w, float* U, int32_t B, int32_t L, int32_t D, int32_t A, void* stream);
+/* one SoftAttention.forward + beta gate for N = B*R rows: hc (N, hc_ld) holds [q | beta | ...] */
+int sat_attention_step_fwd(const float* ann, const float* U, const float* hc, int32_t hc_ld, const float* att_f,
+                           const int32_t* lengths, int32_t step, float* alphas, int32_t T1, float* Z, float* XZ,
+                           int32_t B, int32_t R, int32_t L, int32_t D, int32_t A, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAT_HIP_H */

@@ -1,0 +1,111 @@
+"""ctypes binding of libsat_hip.so (include/sat_hip.h).  Fails loudly: no fallback."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsat_hip.so")
+_lib = None
+
+f32p = C.POINTER(C.c_float)
+i32p = C.POINTER(C.c_int32)
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int64), ("a_rows", C.c_void_p),
+                ("B", C.c_void_p), ("ldb", C.c_int64),
+                ("C", C.c_void_p), ("ldc", C.c_int64), ("c_rows", C.c_void_p),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("amode", C.c_int32), ("bmode", C.c_int32), ("accumulate", C.c_int32), ("epi", C.c_int32),
+                ("bias", C.c_void_p), ("e0", C.c_void_p), ("lde0", C.c_int64), ("c0", C.c_int32), ("c1", C.c_int32),
+                ("slab", C.c_void_p), ("slab_elems", C.c_int64)]
+
+
+class DecoderDims(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("B", "R", "T", "L", "D", "A", "m", "n", "V", "P", "deep_output", "padding_idx")]
+
+
+PARAM_FIELDS = ("embedding", "init_f_w", "init_f_b", "init_i_w", "init_i_b", "w_ih", "w_hh", "b_ih", "b_hh",
+                "att_enc", "att_dec", "att_f", "beta_w", "beta_b", "out_hidden", "out_context", "out_w", "out_b")
+#: C field -> reference state-dict key
+PARAM_KEYS = dict(embedding="embedding.weight", init_f_w="init_lstm.factorize.weight", init_f_b="init_lstm.factorize.bias",
+                  init_i_w="init_lstm.init.weight", init_i_b="init_lstm.init.bias", w_ih="lstm.weight_ih_l0",
+                  w_hh="lstm.weight_hh_l0", b_ih="lstm.bias_ih_l0", b_hh="lstm.bias_hh_l0",
+                  att_enc="attention.encoder_att.weight", att_dec="attention.decoder_att.weight", att_f="attention.f_att.weight",
+                  beta_w="beta.0.weight", beta_b="beta.0.bias", out_hidden="output.hidden.weight",
+                  out_context="output.context.weight", out_w="output.output.weight", out_b="output.output.bias")
+
+
+class DecoderParams(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in PARAM_FIELDS]
+
+
+class DecoderBatch(C.Structure):
+    _fields_ = [("ann", C.c_void_p), ("caps", C.c_void_p), ("lengths", C.c_void_p), ("prow", C.c_void_p), ("src_row", C.c_void_p),
+                ("step_offsets_host", C.c_void_p), ("teacher_host", C.c_void_p)]
+
+
+#: every symbol include/sat_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "sat_abi_version": (C.c_int, []),
+    "sat_last_error": (C.c_char_p, []),
+    "sat_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
+    "sat_decoder_workspace_bytes": (C.c_size_t, [C.POINTER(DecoderDims)]),
+    "sat_decoder_train_fwd": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), C.POINTER(DecoderBatch),
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "sat_decoder_train_bwd": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), C.POINTER(DecoderBatch),
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DecoderParams), C.c_void_p,
+                                        C.c_void_p, C.c_size_t, C.c_void_p]),
+    "sat_ce_label_smooth_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sat_ce_label_smooth_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]),
+    "sat_doubly_stochastic_fwd": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p]),
+    "sat_doubly_stochastic_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
+    "sat_attention_precompute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "sat_attention_step_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                         C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                         C.c_int32, C.c_int32, C.c_void_p]),
+}
+
+
+class SatHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises if it was not built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SatHipError("libsat_hip.so is missing at %s: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950).  There is no CPU/PyTorch fallback." % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(handle, name)          # AttributeError if the export is missing
+            fn.restype, fn.argtypes = res, args
+        if handle.sat_abi_version() != 1:
+            raise SatHipError("libsat_hip.so ABI version %d != 1" % handle.sat_abi_version())
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise SatHipError("%s failed (%d): %s" % (what, rc, lib().sat_last_error().decode(errors="replace")))
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise SatHipError("sat_amd computes on the GPU only: got a %s tensor (no CPU fallback)" % t.device)
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

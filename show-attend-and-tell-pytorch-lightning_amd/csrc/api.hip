@@ -1,0 +1,100 @@
+// extern "C" surface of libsat_hip.so (declared in include/sat_hip.h).
+#include <stdarg.h>
+
+#include "../../include/sat_hip.h"
+#include "decoder.h"
+#include "gemm.h"
+
+namespace sat {
+static thread_local char g_err[512] = {0};
+char* last_error_buf() { return g_err; }
+int fail(int code, const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+    return code;
+}
+}  // namespace sat
+
+using namespace sat;
+
+extern "C" {
+
+int sat_abi_version(void) { return SAT_HIP_ABI_VERSION; }
+const char* sat_last_error(void) { return last_error_buf(); }
+
+int sat_gemm_f32(const sat_gemm_desc* d, void* stream) {
+    if (!d) return fail(SAT_EINVAL, "sat_gemm_f32: null descriptor");
+    if (d->amode != A_ROW && d->amode != A_KMAJOR) return fail(SAT_EINVAL, "sat_gemm_f32: amode %d (dense modes only)", d->amode);
+    if (d->bmode != B_ROW && d->bmode != B_KMAJOR) return fail(SAT_EINVAL, "sat_gemm_f32: bmode %d (dense modes only)", d->bmode);
+    GemmArgs g;
+    g.A = d->A; g.lda = d->lda; g.a_rows = d->a_rows; g.B = d->B; g.ldb = d->ldb; g.C = d->C; g.ldc = d->ldc; g.c_rows = d->c_rows;
+    g.M = d->M; g.N = d->N; g.K = d->K; g.amode = d->amode; g.bmode = d->bmode; g.accumulate = d->accumulate; g.epi = d->epi;
+    g.bias = d->bias; g.e0 = d->e0; g.lde0 = d->lde0; g.c0 = d->c0; g.c1 = d->c1; g.slab = d->slab; g.slab_elems = d->slab_elems;
+    return launch_gemm(g, (hipStream_t)stream);
+}
+
+size_t sat_decoder_workspace_bytes(const sat_decoder_dims* d) {
+    if (check_dims(d) != SAT_OK) return 0;
+    return decoder_workspace_bytes(*d);
+}
+
+static int check_params(const sat_decoder_dims* d, const sat_decoder_params* w, const char* what) {
+    if (!w) return fail(SAT_EINVAL, "%s: null parameter struct", what);
+    if (!w->embedding || !w->init_f_w || !w->init_f_b || !w->init_i_w || !w->init_i_b || !w->w_ih || !w->w_hh || !w->b_ih || !w->b_hh ||
+        !w->att_enc || !w->att_dec || !w->att_f || !w->beta_w || !w->beta_b || !w->out_hidden || !w->out_w)
+        return fail(SAT_EINVAL, "%s: null tensor in parameter struct", what);
+    if (d->deep_output && !w->out_context) return fail(SAT_EINVAL, "%s: deep output needs output.context.weight", what);
+    return SAT_OK;
+}
+static int check_batch(const sat_decoder_batch* b) {
+    if (!b || !b->ann || !b->caps || !b->lengths || !b->prow || !b->src_row || !b->step_offsets_host || !b->teacher_host)
+        return fail(SAT_EINVAL, "decoder: null field in batch struct");
+    return SAT_OK;
+}
+
+int sat_decoder_train_fwd(const sat_decoder_dims* d, const sat_decoder_params* w, const sat_decoder_batch* b, float* logits_packed,
+                          float* alphas, void* workspace, size_t workspace_bytes, void* stream) {
+    SAT_TRY(check_dims(d)); SAT_TRY(check_params(d, w, "decoder_train_fwd")); SAT_TRY(check_batch(b));
+    if (!alphas || !workspace || (d->P > 0 && !logits_packed)) return fail(SAT_EINVAL, "decoder_train_fwd: null output/workspace");
+    return decoder_fwd(*d, *w, *b, logits_packed, alphas, (char*)workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int sat_decoder_train_bwd(const sat_decoder_dims* d, const sat_decoder_params* w, const sat_decoder_batch* b, const float* dlogits_packed,
+                          const float* alphas, const float* dalphas, const sat_decoder_params* g, float* dann, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+    SAT_TRY(check_dims(d)); SAT_TRY(check_params(d, w, "decoder_train_bwd")); SAT_TRY(check_params(d, g, "decoder_train_bwd(grads)")); SAT_TRY(check_batch(b));
+    if (!alphas || !dann || !workspace || (d->P > 0 && !dlogits_packed)) return fail(SAT_EINVAL, "decoder_train_bwd: null input/output/workspace");
+    return decoder_bwd(*d, *w, *b, dlogits_packed, alphas, dalphas, *g, dann, (char*)workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int sat_ce_label_smooth_fwd(const float* logits, const int32_t* targets, int32_t P, int32_t V, float smoothing, float* lse_rows,
+                            float* loss_rows, int32_t* correct_rows, float* out, void* stream) {
+    if (!logits || !targets || !lse_rows || !loss_rows || !correct_rows || !out) return fail(SAT_EINVAL, "ce_label_smooth_fwd: null pointer");
+    return ce_fwd(logits, targets, P, V, smoothing, lse_rows, loss_rows, correct_rows, out, (hipStream_t)stream);
+}
+int sat_ce_label_smooth_bwd(const float* logits, const int32_t* targets, const float* lse_rows, int32_t P, int32_t V, float smoothing,
+                            const float* gscale, float* dlogits, void* stream) {
+    if (!logits || !targets || !lse_rows || !dlogits) return fail(SAT_EINVAL, "ce_label_smooth_bwd: null pointer");
+    return ce_bwd(logits, targets, lse_rows, P, V, smoothing, gscale, dlogits, (hipStream_t)stream);
+}
+int sat_doubly_stochastic_fwd(const float* alphas, int32_t N, int32_t T1, int32_t L, float gamma, float* asum, float* part, float* out, void* stream) {
+    if (!alphas || !asum || !part || !out) return fail(SAT_EINVAL, "doubly_stochastic_fwd: null pointer");
+    return ds_fwd(alphas, N, T1, L, gamma, asum, part, out, (hipStream_t)stream);
+}
+int sat_doubly_stochastic_bwd(const float* asum, const float* gscale, int32_t N, int32_t T1, int32_t L, float gamma, float* dalphas, void* stream) {
+    if (!asum || !dalphas) return fail(SAT_EINVAL, "doubly_stochastic_bwd: null pointer");
+    return ds_bwd(asum, gscale, N, T1, L, gamma, dalphas, (hipStream_t)stream);
+}
+
+int sat_attention_precompute(const float* ann, const float* att_enc_w, float* U, int32_t B, int32_t L, int32_t D, int32_t A, void* stream) {
+    if (!ann || !att_enc_w || !U) return fail(SAT_EINVAL, "attention_precompute: null pointer");
+    GemmArgs g; g.A = ann; g.lda = D; g.B = att_enc_w; g.ldb = D; g.C = U; g.ldc = A; g.M = B * L; g.N = A; g.K = D;
+    return launch_gemm(g, (hipStream_t)stream);
+}
+int sat_attention_step_fwd(const float* ann, const float* U, const float* hc, int32_t hc_ld, const float* att_f, const int32_t* lengths,
+                           int32_t step, float* alphas, int32_t T1, float* Z, float* XZ, int32_t B, int32_t R, int32_t L, int32_t D, int32_t A, void* stream) {
+    if (!ann || !U || !hc || !att_f || !lengths || !alphas || !Z || !XZ) return fail(SAT_EINVAL, "attention_step_fwd: null pointer");
+    if (hc_ld < A + D) return fail(SAT_EINVAL, "attention_step_fwd: hc_ld %d < A+D", hc_ld);
+    return launch_attention_fwd((hipStream_t)stream, ann, U, hc, hc_ld, att_f, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A);
+}
+
+}  // extern "C"

@@ -1,0 +1,20 @@
+// Internal C++ entry points of the decoder (wrapped by the C ABI in api.hip).
+#pragma once
+#include "../../include/sat_hip.h"
+#include "common.h"
+
+namespace sat {
+struct Ws;
+int check_dims(const sat_decoder_dims* d);
+size_t decoder_workspace_bytes(const sat_decoder_dims& d);
+int decoder_fwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sat_decoder_batch& b, float* logits, float* alphas,
+                char* ws, size_t ws_bytes, hipStream_t st);
+int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sat_decoder_batch& b, const float* dlogits,
+                const float* alphas, const float* dalphas, const sat_decoder_params& g, float* dann, char* ws, size_t ws_bytes, hipStream_t st);
+int launch_attention_fwd(hipStream_t st, const float* ann, const float* U, const float* hc, int hc_ld, const float* wf,
+                         const int* lengths, int step, float* alphas, int T1, float* Z, float* XZ, int B, int R, int L, int D, int A);
+int ce_fwd(const float* logits, const int* targets, int P, int V, float smoothing, float* lse_rows, float* loss_rows, int* correct_rows, float* out, hipStream_t st);
+int ce_bwd(const float* logits, const int* targets, const float* lse_rows, int P, int V, float smoothing, const float* gscale, float* dlogits, hipStream_t st);
+int ds_fwd(const float* alphas, int N, int T1, int L, float gamma, float* asum, float* part, float* out, hipStream_t st);
+int ds_bwd(const float* asum, const float* gscale, int N, int T1, int L, float gamma, float* dalphas, hipStream_t st);
+}  // namespace sat

@@ -1,0 +1,344 @@
+// Host-side orchestration of the SAT decoder on one HIP stream: the whole train_batch time loop
+// (model.py:487-548) and its backward through time, as a fixed sequence of kernel launches.
+// No allocation, no synchronisation: everything lives in the caller's workspace.
+#include "../../include/sat_hip.h"
+#include "decoder.h"
+#include "decoder_kernels.h"
+#include "gemm.h"
+
+namespace sat {
+
+// ------------------------------------------------------------------ workspace layout
+struct Ws {
+    size_t total = 0;
+    // saved by forward
+    float *U, *mean, *f, *init_img, *H_all, *C_all, *HC, *Z, *XZ, *Y, *GY, *Uact, *Wcat, *bcat;
+    int* Tok;
+    // backward scratch
+    float *dA, *dHout, *dZout, *DZ, *DHC, *dXZ, *dHc, *dCc, *dU, *dwf_part, *dY, *colpart, *dinit_img, *df, *dmean, *slab;
+    long slab_elems;
+};
+
+Ws layout(const sat_decoder_dims& d, char* base) {
+    Ws w; size_t off = 0;
+    const long N = (long)d.B * d.R, T1 = d.T - 1, HCW = d.A + d.D + 4L * d.n;
+    auto take = [&](size_t elems, size_t esz = 4) { size_t o = off; off += (elems * esz + 255) & ~(size_t)255; return base ? base + o : (char*)nullptr; };
+    w.U = (float*)take((size_t)d.B * d.L * d.A);
+    w.mean = (float*)take((size_t)d.B * d.D);
+    w.f = (float*)take((size_t)d.B * d.m);
+    w.init_img = (float*)take((size_t)d.B * 2 * d.n);
+    w.H_all = (float*)take((size_t)(T1 + 1) * N * d.n);
+    w.C_all = (float*)take((size_t)(T1 + 1) * N * d.n);
+    w.HC = (float*)take((size_t)T1 * N * HCW);
+    w.Z = (float*)take((size_t)T1 * N * d.D);
+    w.XZ = (float*)take((size_t)T1 * N * d.D);
+    w.Y = (float*)take((size_t)T1 * N * d.m);
+    w.GY = (float*)take((size_t)T1 * N * 4 * d.n);
+    w.Uact = (float*)take((size_t)(d.P > 0 ? d.P : 1) * d.m);
+    w.Wcat = (float*)take((size_t)HCW * d.n);
+    w.bcat = (float*)take((size_t)HCW);
+    w.Tok = (int*)take((size_t)T1 * N);
+    w.dA = (float*)take((size_t)(d.P > 0 ? d.P : 1) * d.m);
+    w.dHout = (float*)take((size_t)T1 * N * d.n);
+    w.dZout = (float*)take((size_t)T1 * N * d.D);
+    w.DZ = (float*)take((size_t)T1 * N * d.D);
+    w.DHC = (float*)take((size_t)T1 * N * HCW);
+    w.dXZ = (float*)take((size_t)N * d.D);
+    w.dHc = (float*)take((size_t)N * d.n);
+    w.dCc = (float*)take((size_t)N * d.n);
+    w.dU = (float*)take((size_t)d.B * d.L * d.A);
+    w.dwf_part = (float*)take((size_t)d.B * d.A);
+    w.dY = (float*)take((size_t)T1 * N * d.m);
+    long maxrows = d.P > T1 * N ? d.P : T1 * N; if (maxrows < d.B * (long)d.L) maxrows = d.B * (long)d.L;
+    long maxcols = d.V > HCW ? d.V : HCW;
+    w.colpart = (float*)take((size_t)cdiv(maxrows, 256) * maxcols);
+    w.dinit_img = (float*)take((size_t)d.B * 2 * d.n);
+    w.df = (float*)take((size_t)d.B * d.m);
+    w.dmean = (float*)take((size_t)d.B * d.D);
+    w.slab_elems = 8L << 20;   // 32 MiB of split-K partials
+    w.slab = (float*)take((size_t)w.slab_elems);
+    w.total = off;
+    return w;
+}
+
+int check_dims(const sat_decoder_dims* d) {
+    SAT_REQUIRE(d, "decoder: null dims");
+    SAT_REQUIRE(d->B > 0 && d->R > 0 && d->T >= 2 && d->L > 0 && d->D > 0 && d->A > 0 && d->m > 0 && d->n > 0 && d->V > 0,
+                "decoder: non-positive dimension (B=%d R=%d T=%d L=%d D=%d A=%d m=%d n=%d V=%d)", d->B, d->R, d->T, d->L, d->D, d->A, d->m, d->n, d->V);
+    SAT_REQUIRE(d->P >= 0 && (long)d->P <= (long)d->B * d->R * (d->T - 1), "decoder: packed token count %d out of range", d->P);
+    return SAT_OK;
+}
+
+// ------------------------------------------------------------------ small launch helpers
+static int gemm(hipStream_t st, int amode, int bmode, const float* A, long lda, const float* B, long ldb, float* C, long ldc,
+                int M, int N, int K, int acc = 0, int epi = EPI_NONE, const float* bias = nullptr, const int* a_rows = nullptr,
+                const int* c_rows = nullptr, const float* e0 = nullptr, long lde0 = 0, int c0 = 0, int c1 = 0, float* slab = nullptr, long slab_elems = 0) {
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.amode = amode; g.bmode = bmode; g.accumulate = acc; g.epi = epi; g.bias = bias; g.a_rows = a_rows; g.c_rows = c_rows;
+    g.e0 = e0; g.lde0 = lde0; g.c0 = c0; g.c1 = c1; g.slab = slab; g.slab_elems = slab_elems;
+    return launch_gemm(g, st);
+}
+
+static int colsum(hipStream_t st, const Ws& w, const float* x, long ld, int rows, int cols, float* out, int accumulate = 0, float scale = 1.f) {
+    if (cols <= 0) return SAT_OK;
+    if (rows <= 0) { if (!accumulate) SAT_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)cols * 4, st)); return SAT_OK; }
+    int nparts = cdiv(rows, 256);
+    hipLaunchKernelGGL(colsum_part_kernel, dim3(cdiv(cols, 256), nparts), dim3(256), 0, st, x, ld, rows, cols, 256, w.colpart);
+    SAT_TRY(launch_ok("colsum_part"));
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, st, w.colpart, nparts, cols, out, accumulate, scale);
+    return launch_ok("colsum_finish");
+}
+
+static int live_steps(const sat_decoder_dims& d, const sat_decoder_batch& b) {
+    const int T1 = d.T - 1; int ts = 0;
+    for (int t = 0; t < T1; ++t) if (b.step_offsets_host[t + 1] > b.step_offsets_host[t]) ts = t + 1;
+    return ts;
+}
+
+static size_t att_fwd_lds(int L, int A, int vw) { return (size_t)(ATT_RMAX * L + ATT_RMAX * A + A + ATT_RMAX * ATT_THREADS * vw) * 4; }
+static size_t att_bwd_lds(int L, int A, int D) { return (size_t)(2 * ATT_RMAX * L + ATT_RMAX * A + A + ATT_RMAX * D + 4 * ATT_RMAX * A + 4 * A) * 4; }
+
+int launch_attention_fwd(hipStream_t st, const float* ann, const float* U, const float* hc, int hc_ld, const float* wf,
+                                const int* lengths, int step, float* alphas, int T1, float* Z, float* XZ, int B, int R, int L, int D, int A) {
+    const bool vec = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(ann) & 15) == 0);
+    const int vw = vec ? 4 : 1;
+    int dchunk = vec ? 256 : 64;
+    if (dchunk > D) dchunk = D;
+    size_t lds = att_fwd_lds(L, A, vw);
+    SAT_REQUIRE(lds <= 160 * 1024, "attention_fwd: L=%d A=%d need %zu B of LDS (> 160 KiB)", L, A, lds);
+    dim3 grid(B, cdiv(D, dchunk));
+    if (vec) {
+        SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_fwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(attention_fwd_kernel<4>, grid, dim3(ATT_THREADS), lds, st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, R, L, D, A, dchunk);
+    } else {
+        SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_fwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(attention_fwd_kernel<1>, grid, dim3(ATT_THREADS), lds, st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, R, L, D, A, dchunk);
+    }
+    return launch_ok("attention_fwd");
+}
+
+// ------------------------------------------------------------------ output stage for packed rows [p0, p1)
+static int flush_outputs(hipStream_t st, const sat_decoder_dims& d, const sat_decoder_params& p, const sat_decoder_batch& b,
+                         const Ws& w, float* logits, int p0, int p1) {
+    const int rows = p1 - p0;
+    if (rows <= 0) return SAT_OK;
+    const long N = (long)d.B * d.R;
+    const float* H1 = w.H_all + N * d.n;                 // hidden state AFTER each step (F8: the new h)
+    float* u = w.Uact + (long)p0 * d.m;
+    const int* rows_map = b.src_row + p0;
+    if (d.deep_output) {
+        SAT_TRY(gemm(st, A_ROW, B_ROW, H1, d.n, p.out_hidden, d.n, u, d.m, rows, d.m, d.n, 0, EPI_NONE, nullptr, rows_map));
+        SAT_TRY(gemm(st, A_ROW, B_ROW, w.Z, d.D, p.out_context, d.D, u, d.m, rows, d.m, d.D, 1, EPI_ADD_TANH, nullptr, rows_map, nullptr, w.Y, d.m));
+    } else {
+        SAT_TRY(gemm(st, A_ROW, B_ROW, H1, d.n, p.out_hidden, d.n, u, d.m, rows, d.m, d.n, 0, EPI_NONE, nullptr, rows_map));
+    }
+    return gemm(st, A_ROW, B_ROW, u, d.m, p.out_w, d.m, logits + (long)p0 * d.V, d.V, rows, d.V, d.m, 0,
+                p.out_b ? EPI_BIAS : EPI_NONE, p.out_b);
+}
+
+int decoder_fwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sat_decoder_batch& b, float* logits, float* alphas,
+                       char* ws, size_t ws_bytes, hipStream_t st) {
+    Ws w = layout(d, ws);
+    SAT_REQUIRE(ws_bytes >= w.total, "decoder_fwd: workspace %zu < %zu bytes", ws_bytes, w.total);
+    SAT_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, "decoder: workspace must be 256-byte aligned");
+    const int N = d.B * d.R, T1 = d.T - 1, HCW = d.A + d.D + 4 * d.n, n = d.n, A = d.A, D = d.D, m = d.m;
+    const int ts = live_steps(d, b);
+    SAT_REQUIRE(b.step_offsets_host[T1] == d.P, "decoder: step_offsets[T-1]=%d != P=%d", b.step_offsets_host[T1], d.P);
+    for (int t = 0; t < ts; ++t) SAT_REQUIRE(b.teacher_host[t] || t > 0, "decoder: step 0 must be teacher forced");
+
+    // packed parameters: Wcat = [W_d ; W_beta ; W_hh] (HCW, n), bcat = [0 ; b_beta ; b_ih + b_hh]
+    SAT_CHECK_HIP(hipMemcpyAsync(w.Wcat, p.att_dec, (size_t)A * n * 4, hipMemcpyDeviceToDevice, st));
+    SAT_CHECK_HIP(hipMemcpyAsync(w.Wcat + (long)A * n, p.beta_w, (size_t)D * n * 4, hipMemcpyDeviceToDevice, st));
+    SAT_CHECK_HIP(hipMemcpyAsync(w.Wcat + (long)(A + D) * n, p.w_hh, (size_t)4 * n * n * 4, hipMemcpyDeviceToDevice, st));
+    SAT_CHECK_HIP(hipMemsetAsync(w.bcat, 0, (size_t)A * 4, st));
+    SAT_CHECK_HIP(hipMemcpyAsync(w.bcat + A, p.beta_b, (size_t)D * 4, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(add_kernel, dim3(cdiv(4 * n, 256)), dim3(256), 0, st, w.bcat + A + D, p.b_ih, p.b_hh, (long)4 * n);
+    SAT_TRY(launch_ok("bias add"));
+
+    // att_enc, hoisted (model.py:100): U = ann * W_e^T once per image
+    SAT_TRY(gemm(st, A_ROW, B_ROW, b.ann, D, p.att_enc, D, w.U, A, d.B * d.L, A, D));
+    // InitLSTM (model.py:76-81) on the B images, then the raw reshape over the repeated rows (F3)
+    hipLaunchKernelGGL(ann_mean_kernel, dim3(d.B), dim3(256), 0, st, b.ann, w.mean, d.L, D);
+    SAT_TRY(launch_ok("ann_mean"));
+    SAT_TRY(gemm(st, A_ROW, B_ROW, w.mean, D, p.init_f_w, D, w.f, m, d.B, m, D, 0, EPI_BIAS, p.init_f_b));
+    SAT_TRY(gemm(st, A_ROW, B_ROW, w.f, m, p.init_i_w, m, w.init_img, 2 * n, d.B, 2 * n, m, 0, EPI_BIAS, p.init_i_b));
+    hipLaunchKernelGGL(init_expand_kernel, dim3(cdiv(2L * N * n, 256)), dim3(256), 0, st, w.init_img, w.H_all, w.C_all, N, d.R, n);
+    SAT_TRY(launch_ok("init_expand"));
+
+    // alphas of steps that never run stay zero (model.py:506)
+    if (ts < T1) SAT_CHECK_HIP(hipMemsetAsync(alphas, 0, (size_t)N * T1 * d.L * 4, st));
+
+    // tokens + embeddings + the embedding half of the LSTM input GEMM for every teacher-forced step, in one batch
+    SAT_CHECK_HIP(hipMemsetAsync(w.Tok, 0xFF, (size_t)T1 * N * 4, st));       // -1: no token
+    for (int t = 0; t < ts; ++t)
+        if (b.teacher_host[t]) {
+            hipLaunchKernelGGL(teacher_tokens_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, b.caps, b.lengths, w.Tok + (long)t * N, N, d.T, t);
+            SAT_TRY(launch_ok("teacher_tokens"));
+        }
+    if (ts > 0) {
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(ts * N), dim3(64), 0, st, p.embedding, w.Tok, w.Y, ts * N, m);
+        SAT_TRY(launch_ok("embedding gather"));
+        SAT_TRY(gemm(st, A_ROW, B_ROW, w.Y, m, p.w_ih, m + D, w.GY, 4 * n, ts * N, 4 * n, m));
+    }
+
+    int pending = 0;
+    for (int t = 0; t < ts; ++t) {
+        float* hc = w.HC + (long)t * N * HCW;
+        if (!b.teacher_host[t]) {
+            // scheduled sampling (model.py:521-523): feed argmax of the previous step's logits
+            SAT_TRY(flush_outputs(st, d, p, b, w, logits, b.step_offsets_host[pending], b.step_offsets_host[t]));
+            pending = t;
+            hipLaunchKernelGGL(argmax_tokens_kernel, dim3(N), dim3(256), 0, st, logits, b.prow + (long)(t - 1) * N, b.lengths, w.Tok + (long)t * N, d.V, t);
+            SAT_TRY(launch_ok("argmax_tokens"));
+            hipLaunchKernelGGL(gather_rows_kernel, dim3(N), dim3(64), 0, st, p.embedding, w.Tok + (long)t * N, w.Y + (long)t * N * m, N, m);
+            SAT_TRY(launch_ok("embedding gather"));
+            SAT_TRY(gemm(st, A_ROW, B_ROW, w.Y + (long)t * N * m, m, p.w_ih, m + D, w.GY + (long)t * N * 4 * n, 4 * n, N, 4 * n, m));
+        }
+        // [q | beta | gates_h] = h_{t-1} * Wcat^T + bcat, sigmoid on the beta columns
+        SAT_TRY(gemm(st, A_ROW, B_ROW, w.H_all + (long)t * N * n, n, w.Wcat, n, hc, HCW, N, HCW, n, 0, EPI_BIAS_SIGMOID_RANGE, w.bcat,
+                     nullptr, nullptr, nullptr, 0, A, A + D));
+        SAT_TRY(launch_attention_fwd(st, b.ann, w.U, hc, HCW, p.att_f, b.lengths, t, alphas, T1, w.Z + (long)t * N * D, w.XZ + (long)t * N * D,
+                                     d.B, d.R, d.L, D, A));
+        // gates += (beta*z) * W_ih[:, m:]^T
+        SAT_TRY(gemm(st, A_ROW, B_ROW, w.XZ + (long)t * N * D, D, p.w_ih + m, m + D, hc + A + D, HCW, N, 4 * n, D, 1));
+        hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(cdiv((long)N * n, 256)), dim3(256), 0, st, hc + A + D, HCW, w.GY + (long)t * N * 4 * n,
+                           w.C_all + (long)t * N * n, w.H_all + (long)t * N * n, w.C_all + (long)(t + 1) * N * n, w.H_all + (long)(t + 1) * N * n,
+                           b.lengths, t, N, n);
+        SAT_TRY(launch_ok("lstm_cell_fwd"));
+    }
+    return flush_outputs(st, d, p, b, w, logits, b.step_offsets_host[pending], b.step_offsets_host[ts]);
+}
+
+int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sat_decoder_batch& b, const float* dlogits,
+                       const float* alphas, const float* dalphas, const sat_decoder_params& g, float* dann, char* ws, size_t ws_bytes, hipStream_t st) {
+    Ws w = layout(d, ws);
+    SAT_REQUIRE(ws_bytes >= w.total, "decoder_bwd: workspace %zu < %zu bytes", ws_bytes, w.total);
+    const int N = d.B * d.R, T1 = d.T - 1, HCW = d.A + d.D + 4 * d.n, n = d.n, A = d.A, D = d.D, m = d.m, V = d.V, P = d.P;
+    const int ts = live_steps(d, b);
+    const int KR = ts * N;                              // rows of the time-major padded buffers that were touched
+    float* const slab = w.slab; const long se = w.slab_elems;
+
+    SAT_CHECK_HIP(hipMemsetAsync(w.dU, 0, (size_t)d.B * d.L * A * 4, st));
+    SAT_CHECK_HIP(hipMemsetAsync(w.dwf_part, 0, (size_t)d.B * A * 4, st));
+    SAT_CHECK_HIP(hipMemsetAsync(w.dHc, 0, (size_t)N * n * 4, st));
+    SAT_CHECK_HIP(hipMemsetAsync(w.dCc, 0, (size_t)N * n * 4, st));
+    SAT_CHECK_HIP(hipMemsetAsync(w.dHout, 0, (size_t)T1 * N * n * 4, st));
+    SAT_CHECK_HIP(hipMemsetAsync(w.dZout, 0, (size_t)T1 * N * D * 4, st));
+    SAT_CHECK_HIP(hipMemsetAsync(g.embedding, 0, (size_t)V * m * 4, st));
+
+    // ---- output layer, all packed rows at once (DeepOutput backward)
+    if (P > 0) {
+        SAT_TRY(gemm(st, A_ROW, B_KMAJOR, dlogits, V, p.out_w, m, w.dA, m, P, m, V, 0, d.deep_output ? EPI_MUL_DTANH : EPI_NONE, nullptr,
+                     nullptr, nullptr, w.Uact, m));
+        SAT_TRY(gemm(st, A_KMAJOR, B_KMAJOR, dlogits, V, w.Uact, m, g.out_w, m, V, m, P, 0, EPI_NONE, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, slab, se));
+        if (g.out_b) SAT_TRY(colsum(st, w, dlogits, V, P, V, g.out_b));
+        SAT_TRY(gemm(st, A_ROW, B_KMAJOR, w.dA, m, p.out_hidden, n, w.dHout, n, P, n, m, 0, EPI_NONE, nullptr, nullptr, b.src_row));
+        if (d.deep_output)
+            SAT_TRY(gemm(st, A_ROW, B_KMAJOR, w.dA, m, p.out_context, D, w.dZout, D, P, D, m, 0, EPI_NONE, nullptr, nullptr, b.src_row));
+    } else {
+        SAT_CHECK_HIP(hipMemsetAsync(g.out_w, 0, (size_t)V * m * 4, st));
+        if (g.out_b) SAT_CHECK_HIP(hipMemsetAsync(g.out_b, 0, (size_t)V * 4, st));
+    }
+    // dA in time-major padded rows (zeros for finished captions): operand of the weight-grad GEMMs and of dY
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(T1 * N), dim3(64), 0, st, w.dA, b.prow, w.dY, T1 * N, m);
+    SAT_TRY(launch_ok("scatter dA"));
+    const float* H1 = w.H_all + (long)N * n;
+    SAT_TRY(gemm(st, A_KMAJOR, B_KMAJOR, w.dY, m, H1, n, g.out_hidden, n, m, n, KR, 0, EPI_NONE, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, slab, se));
+    if (d.deep_output)
+        SAT_TRY(gemm(st, A_KMAJOR, B_KMAJOR, w.dY, m, w.Z, D, g.out_context, D, m, D, KR, 0, EPI_NONE, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, slab, se));
+    else
+        SAT_CHECK_HIP(hipMemsetAsync(w.dY, 0, (size_t)T1 * N * m * 4, st));     // shallow output does not see the embedding
+
+    // ---- back through time
+    const size_t lds_b = att_bwd_lds(d.L, A, D);
+    SAT_REQUIRE(lds_b <= 160 * 1024, "attention_bwd: L=%d A=%d D=%d need %zu B of LDS (> 160 KiB)", d.L, A, D, lds_b);
+    SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+    for (int t = ts - 1; t >= 0; --t) {
+        const float* hc = w.HC + (long)t * N * HCW;
+        float* dhc = w.DHC + (long)t * N * HCW;
+        hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(cdiv((long)N * n, 256)), dim3(256), 0, st, hc + A + D, HCW, w.C_all + (long)t * N * n,
+                           w.C_all + (long)(t + 1) * N * n, w.dHout + (long)t * N * n, w.dHc, w.dCc, dhc + A + D, HCW, b.lengths, t, N, n);
+        SAT_TRY(launch_ok("lstm_cell_bwd"));
+        // d(beta*z) = dG * W_ih[:, m:]
+        SAT_TRY(gemm(st, A_ROW, B_KMAJOR, dhc + A + D, HCW, p.w_ih + m, m + D, w.dXZ, D, N, D, 4 * n));
+        hipLaunchKernelGGL(attention_bwd_kernel, dim3(d.B), dim3(ATT_THREADS), lds_b, st, b.ann, w.U, hc, HCW, p.att_f, b.lengths, t, alphas,
+                           dalphas, T1, w.Z + (long)t * N * D, w.dZout + (long)t * N * D, w.dXZ, w.DZ + (long)t * N * D, dhc, HCW, w.dU, w.dwf_part,
+                           d.R, d.L, D, A);
+        SAT_TRY(launch_ok("attention_bwd"));
+        // dh_{t-1} += [dq | dbeta_pre | dG] * Wcat
+        SAT_TRY(gemm(st, A_ROW, B_KMAJOR, dhc, HCW, w.Wcat, n, w.dHc, n, N, n, HCW, 1));
+    }
+    // now dHc = dL/dh0 and dCc = dL/dc0
+
+    // ---- weight gradients, batched over every executed step (reduction length KR = ts*N)
+    auto wgrad = [&](const float* dy, long ldy, const float* x, long ldx, float* out, long ldo, int M, int Nn) {
+        return gemm(st, A_KMAJOR, B_KMAJOR, dy, ldy, x, ldx, out, ldo, M, Nn, KR, 0, EPI_NONE, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, slab, se);
+    };
+    const float* dG = w.DHC + A + D;
+    SAT_TRY(wgrad(w.DHC, HCW, w.H_all, n, g.att_dec, n, A, n));
+    SAT_TRY(wgrad(w.DHC + A, HCW, w.H_all, n, g.beta_w, n, D, n));
+    SAT_TRY(wgrad(dG, HCW, w.H_all, n, g.w_hh, n, 4 * n, n));
+    SAT_TRY(colsum(st, w, w.DHC + A, HCW, KR, D, g.beta_b));
+    SAT_TRY(colsum(st, w, dG, HCW, KR, 4 * n, g.b_ih));
+    SAT_CHECK_HIP(hipMemcpyAsync(g.b_hh, g.b_ih, (size_t)4 * n * 4, hipMemcpyDeviceToDevice, st));
+    SAT_TRY(wgrad(dG, HCW, w.Y, m, g.w_ih, m + D, 4 * n, m));
+    SAT_TRY(wgrad(dG, HCW, w.XZ, D, g.w_ih + m, m + D, 4 * n, D));
+    // embedding: dY = dA (deep output) + dG * W_ih[:, :m], scattered into the table (padding row skipped)
+    SAT_TRY(gemm(st, A_ROW, B_KMAJOR, dG, HCW, p.w_ih, m + D, w.dY, m, KR, m, 4 * n, 1));
+    if (KR > 0) {
+        hipLaunchKernelGGL(embedding_bwd_kernel, dim3(KR), dim3(64), 0, st, w.dY, w.Tok, g.embedding, KR, m, d.padding_idx);
+        SAT_TRY(launch_ok("embedding_bwd"));
+    }
+    // attention parameters and the annotation gradient
+    SAT_TRY(colsum(st, w, w.dwf_part, A, d.B, A, g.att_f));
+    SAT_TRY(gemm(st, A_KMAJOR, B_KMAJOR, w.dU, A, b.ann, D, g.att_enc, D, A, D, d.B * d.L, 0, EPI_NONE, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, slab, se));
+    SAT_TRY(gemm(st, A_ROW, B_KMAJOR, w.dU, A, p.att_enc, D, dann, D, d.B * d.L, D, A));
+    hipLaunchKernelGGL(dann_from_context_kernel, dim3(d.B, cdiv(D, 256)), dim3(256), 16 * sizeof(float), st, alphas, w.DZ, b.lengths, dann, 1,
+                       d.R, N, T1, d.L, D);
+    SAT_TRY(launch_ok("dann_from_context"));
+    // InitLSTM backward (the raw reshape is a reinterpretation: gradients of the repeated rows add up per image)
+    hipLaunchKernelGGL(init_expand_bwd_kernel, dim3(cdiv((long)d.B * 2 * n, 256)), dim3(256), 0, st, w.dHc, w.dCc, w.dinit_img, d.B, d.R, n);
+    SAT_TRY(launch_ok("init_expand_bwd"));
+    SAT_TRY(gemm(st, A_KMAJOR, B_KMAJOR, w.dinit_img, 2 * n, w.f, m, g.init_i_w, m, 2 * n, m, d.B));
+    SAT_TRY(colsum(st, w, w.dinit_img, 2 * n, d.B, 2 * n, g.init_i_b));
+    SAT_TRY(gemm(st, A_ROW, B_KMAJOR, w.dinit_img, 2 * n, p.init_i_w, m, w.df, m, d.B, m, 2 * n));
+    SAT_TRY(gemm(st, A_KMAJOR, B_KMAJOR, w.df, m, w.mean, D, g.init_f_w, D, m, D, d.B));
+    SAT_TRY(colsum(st, w, w.df, m, d.B, m, g.init_f_b));
+    SAT_TRY(gemm(st, A_ROW, B_KMAJOR, w.df, m, p.init_f_w, D, w.dmean, D, d.B, D, m));
+    const long tot = (long)d.B * d.L * D;
+    hipLaunchKernelGGL(dann_add_mean_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, st, dann, w.dmean, d.L, D, tot);
+    return launch_ok("dann_add_mean");
+}
+
+
+size_t decoder_workspace_bytes(const sat_decoder_dims& d) { return layout(d, nullptr).total; }
+
+// ------------------------------------------------------------------ losses
+int ce_fwd(const float* logits, const int* targets, int P, int V, float smoothing, float* lse_rows, float* loss_rows, int* correct_rows, float* out, hipStream_t st) {
+    SAT_REQUIRE(P > 0 && V > 0, "ce_fwd: empty input (P=%d V=%d)", P, V);
+    SAT_REQUIRE(smoothing >= 0.f && smoothing < 1.f, "ce_fwd: smoothing %g out of range", smoothing);
+    hipLaunchKernelGGL(ce_rows_kernel, dim3(P), dim3(256), 0, st, logits, targets, V, smoothing, lse_rows, loss_rows, correct_rows);
+    SAT_TRY(launch_ok("ce_rows"));
+    hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(256), 0, st, loss_rows, correct_rows, P, out);
+    return launch_ok("ce_finish");
+}
+int ce_bwd(const float* logits, const int* targets, const float* lse_rows, int P, int V, float smoothing, const float* gscale, float* dlogits, hipStream_t st) {
+    SAT_REQUIRE(P > 0 && V > 0, "ce_bwd: empty input");
+    hipLaunchKernelGGL(ce_grad_kernel, dim3(P), dim3(256), 0, st, logits, targets, lse_rows, V, smoothing, 1.0f / (float)P, gscale, dlogits);
+    return launch_ok("ce_grad");
+}
+int ds_fwd(const float* alphas, int N, int T1, int L, float gamma, float* asum, float* part, float* out, hipStream_t st) {
+    SAT_REQUIRE(N > 0 && T1 > 0 && L > 0, "ds_fwd: empty input");
+    const int nb = cdiv((long)N * L, 256);
+    hipLaunchKernelGGL(ds_rows_kernel, dim3(nb), dim3(256), 0, st, alphas, asum, part, N, T1, L);
+    SAT_TRY(launch_ok("ds_rows"));
+    hipLaunchKernelGGL(ds_finish_kernel, dim3(1), dim3(256), 0, st, part, nb, gamma, (long)N * L, out);
+    return launch_ok("ds_finish");
+}
+int ds_bwd(const float* asum, const float* gscale, int N, int T1, int L, float gamma, float* dalphas, hipStream_t st) {
+    hipLaunchKernelGGL(ds_grad_kernel, dim3(cdiv((long)N * T1 * L, 256)), dim3(256), 0, st, asum, gscale, gamma, dalphas, N, T1, L);
+    return launch_ok("ds_grad");
+}
+
+}  // namespace sat

@@ -1,0 +1,579 @@
+// Device kernels of the SAT attention-LSTM decoder (forward and backward).
+// Reference semantics: model.py:76-81 (InitLSTM), 94-109 (SoftAttention),
+// 125-131 (DeepOutput), 187-192 (beta), 510-548 (train_batch loop),
+// util.py:105-112 (LabelSmoothing), model.py:594 (doubly stochastic term).
+//
+// Layout (all fp32, row-major):
+//   ann    (B, L, D)   annotations, one row per location -- NHWC encoder output viewed flat.
+//                      The R captions of an image share it (repeat_interleave is never materialised:
+//                      caption row i belongs to image i / R).
+//   U      (B, L, A)   att_enc = ann * W_e^T, hoisted out of the time loop.
+//   HC[t]  (N, A+D+4n) per step: [ q = h W_d^T | beta = sigmoid(h W_b^T + b) | LSTM gates ]
+//   time-major padded buffers (T1, N, .) for everything saved for backward.
+#pragma once
+#include "common.h"
+
+namespace sat {
+
+constexpr int ATT_RMAX = 8;      // caption rows of one image handled per pass
+constexpr int ATT_THREADS = 256;
+
+// ------------------------------------------------------------------ small utilities
+__global__ void fill_kernel(float* p, long n, float v) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// dst[r, :] = src[idx(r), :]  (embedding gather; tok < 0 -> zeros)
+__global__ void gather_rows_kernel(const float* __restrict__ table, const int* __restrict__ tok, float* __restrict__ out, int rows, int width) {
+    int r = blockIdx.x;
+    if (r >= rows) return;
+    int t = tok[r];
+    for (int c = threadIdx.x; c < width; c += blockDim.x) out[(long)r * width + c] = (t >= 0) ? table[(long)t * width + c] : 0.f;
+}
+
+// token ids of step `step` for every caption row (teacher forcing): tok[i] = caps[i*T + step]
+__global__ void teacher_tokens_kernel(const int* __restrict__ caps, const int* __restrict__ lengths, int* __restrict__ tok, int N, int T, int step) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) tok[i] = (lengths[i] > step) ? caps[(long)i * T + step] : -1;     // finished captions feed nothing
+}
+
+// argmax feedback (model.py:523): tok[i] = argmax_v logits_packed[prow_prev[i], v] (first maximum), -1 for dead rows
+__global__ void argmax_tokens_kernel(const float* __restrict__ logits, const int* __restrict__ prow_prev, const int* __restrict__ lengths,
+                                     int* __restrict__ tok, int V, int step) {
+    int i = blockIdx.x;
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    if (lengths[i] <= step) { if (threadIdx.x == 0) tok[i] = -1; return; }
+    const float* row = logits + (long)prow_prev[i] * V;
+    float best = -INFINITY; int bi = 0x7fffffff;
+    for (int v = threadIdx.x; v < V; v += blockDim.x) {
+        float x = row[v];
+        if (x > best || (x == best && v < bi)) { best = x; bi = v; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        float ob = __shfl_xor(best, o, 64); int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sv[w] = best; si[w] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < (int)(blockDim.x >> 6); ++k)
+            if (sv[k] > best || (sv[k] == best && si[k] < bi)) { best = sv[k]; bi = si[k]; }
+        tok[i] = bi;
+    }
+}
+
+// mean over L of the annotations: mean[b, d]  (model.py:78)
+__global__ void ann_mean_kernel(const float* __restrict__ ann, float* __restrict__ mean, int L, int D) {
+    int b = blockIdx.x;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        float s = 0.f;
+        for (int l = 0; l < L; ++l) s += ann[((long)b * L + l) * D + d];
+        mean[(long)b * D + d] = s / (float)L;
+    }
+}
+
+// InitLSTM raw reshape (model.py:79-80): the (N, 2n) buffer whose row j is init[j / R]
+// is reinterpreted as (2, N, n): hc0[0] = h0, hc0[1] = c0.  flat element e of the buffer -> row e / (2n).
+__global__ void init_expand_kernel(const float* __restrict__ init_img, float* __restrict__ h0, float* __restrict__ c0, int N, int R, int n) {
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long half = (long)N * n;
+    if (e >= 2 * half) return;
+    long row = e / (2 * n), col = e % (2 * n);
+    float v = init_img[(row / R) * (2 * n) + col];
+    if (e < half) h0[e] = v; else c0[e - half] = v;
+}
+// backward of the above: dinit_img[b, col] = sum_r dflat[(b*R + r), col]
+__global__ void init_expand_bwd_kernel(const float* __restrict__ dh0, const float* __restrict__ dc0, float* __restrict__ dinit_img, int B, int R, int n) {
+    long o = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    int N = B * R; long half = (long)N * n;
+    if (o >= (long)B * 2 * n) return;
+    long b = o / (2 * n), col = o % (2 * n);
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) {
+        long e = (b * R + r) * (2 * n) + col;
+        s += (e < half) ? dh0[e] : dc0[e - half];
+    }
+    dinit_img[o] = s;
+}
+
+// ------------------------------------------------------------------ attention forward (one decode step)
+// grid = (B, D-chunks); block = 256.  Every block recomputes the (cheap) scores + softmax of its image's
+// R caption rows, then accumulates its D-chunk of the context while reading the annotation tile ONCE
+// for all R rows.  dyn LDS: [RMAX*L scores/alpha][RMAX*A q][A w][part: 4*RMAX*chunk]
+template <int VW>
+__global__ __launch_bounds__(ATT_THREADS) void attention_fwd_kernel(
+    const float* __restrict__ ann, const float* __restrict__ U, const float* __restrict__ hc, int hc_ld,
+    const float* __restrict__ wf, const int* __restrict__ lengths, int step,
+    float* __restrict__ alphas, int T1, float* __restrict__ Z, float* __restrict__ XZ,
+    int R, int L, int D, int A, int dchunk) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* s_sc = sm;                        // [RMAX][L]
+    float* s_q = s_sc + ATT_RMAX * L;        // [RMAX][A]
+    float* s_w = s_q + ATT_RMAX * A;         // [A]
+    float* s_part = s_w + A;                 // [4 groups][RMAX][dchunk]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int d0 = blockIdx.y * dchunk, dn = min(dchunk, D - d0);
+    const float scale = 1.0f / sqrtf((float)L);
+    for (int k = tid; k < A; k += ATT_THREADS) s_w[k] = wf[k];
+
+    for (int r0 = 0; r0 < R; r0 += ATT_RMAX) {
+        const int rn = min(ATT_RMAX, R - r0);
+        const int i0 = b * R + r0;
+        unsigned lmask = 0;
+        for (int r = 0; r < rn; ++r) if (lengths[i0 + r] > step) lmask |= 1u << r;
+        const bool any = lmask != 0;
+        __syncthreads();
+        if (any) {
+            for (int e = tid; e < rn * A; e += ATT_THREADS) { int r = e / A, k = e - r * A; s_q[r * A + k] = hc[(long)(i0 + r) * hc_ld + k]; }
+            __syncthreads();
+            // ---- scores: wave per location, lanes over the attention dim
+            for (int l = wave; l < L; l += 4) {
+                float part[ATT_RMAX];
+#pragma unroll
+                for (int r = 0; r < ATT_RMAX; ++r) part[r] = 0.f;
+                const float* u = U + ((long)b * L + l) * A;
+                for (int k = lane; k < A; k += 64) {
+                    float uv = u[k], w = s_w[k];
+#pragma unroll
+                    for (int r = 0; r < ATT_RMAX; ++r) if (((lmask >> r) & 1u)) part[r] += w * fast_tanh(uv + s_q[r * A + k]);
+                }
+#pragma unroll
+                for (int r = 0; r < ATT_RMAX; ++r) if (((lmask >> r) & 1u)) { float s = wave_sum(part[r]); if (lane == 0) s_sc[r * L + l] = s * scale; }
+            }
+            __syncthreads();
+            // ---- softmax over L: wave per row
+            for (int r = wave; r < rn; r += 4) {
+                if (!((lmask >> r) & 1u)) continue;       // wave-uniform
+                float mx = -INFINITY;
+                for (int l = lane; l < L; l += 64) mx = fmaxf(mx, s_sc[r * L + l]);
+                mx = wave_max(mx);
+                float sum = 0.f;
+                for (int l = lane; l < L; l += 64) { float e = __expf(s_sc[r * L + l] - mx); s_sc[r * L + l] = e; sum += e; }
+                sum = wave_sum(sum);
+                float inv = 1.0f / sum;
+                for (int l = lane; l < L; l += 64) s_sc[r * L + l] *= inv;
+            }
+            __syncthreads();
+        }
+        // ---- alphas out (only the first D-chunk block writes); dead rows are written as zeros
+        if (blockIdx.y == 0) {
+            for (int e = tid; e < rn * L; e += ATT_THREADS) {
+                int r = e / L, l = e - r * L;
+                alphas[((long)(i0 + r) * T1 + step) * L + l] = ((lmask >> r) & 1u) ? s_sc[r * L + l] : 0.f;
+            }
+        }
+        // ---- context: z[r][d] = sum_l alpha[r][l] * ann[b,l,d] for d in this chunk
+        const int nv = dn / VW;                         // vectors in the chunk
+        const int groups = max(1, min(4, ATT_THREADS / max(nv, 1)));
+        const int gsz = ATT_THREADS / groups;           // threads per group
+        const int g = tid / gsz, tv = tid - g * gsz;
+        float acc[ATT_RMAX][VW];
+        if (any) {
+            for (int v0 = 0; v0 < nv; v0 += gsz) {
+                const int v = v0 + tv;
+#pragma unroll
+                for (int r = 0; r < ATT_RMAX; ++r)
+#pragma unroll
+                    for (int c = 0; c < VW; ++c) acc[r][c] = 0.f;
+                if (v < nv && g < groups) {
+                    const float* base = ann + (long)b * L * D + d0 + v * VW;
+                    for (int l = g; l < L; l += groups) {
+                        float x[VW];
+                        if (VW == 4) { float4 t4 = *reinterpret_cast<const float4*>(base + (long)l * D); x[0] = t4.x; x[1 % VW] = t4.y; x[2 % VW] = t4.z; x[3 % VW] = t4.w; }
+                        else x[0] = base[(long)l * D];
+#pragma unroll
+                        for (int r = 0; r < ATT_RMAX; ++r) if (((lmask >> r) & 1u)) { float al = s_sc[r * L + l];
+#pragma unroll
+                            for (int c = 0; c < VW; ++c) acc[r][c] += al * x[c]; }
+                    }
+                }
+                // combine the l-groups through LDS in a fixed order
+                __syncthreads();
+                if (v < nv && g < groups)
+#pragma unroll
+                    for (int r = 0; r < ATT_RMAX; ++r)
+#pragma unroll
+                        for (int c = 0; c < VW; ++c) s_part[((g * ATT_RMAX + r) * gsz + tv) * VW + c] = acc[r][c];
+                __syncthreads();
+                if (g == 0 && v < nv) {
+#pragma unroll
+                    for (int r = 0; r < ATT_RMAX; ++r) {
+                        if (r >= rn) continue;
+                        const long orow = (long)(i0 + r);
+#pragma unroll
+                        for (int c = 0; c < VW; ++c) {
+                            float z = 0.f;
+                            if (((lmask >> r) & 1u)) for (int gg = 0; gg < groups; ++gg) z += s_part[((gg * ATT_RMAX + r) * gsz + tv) * VW + c];
+                            const int d = d0 + v * VW + c;
+                            const float beta = ((lmask >> r) & 1u) ? hc[orow * hc_ld + A + d] : 0.f;
+                            Z[orow * D + d] = z;
+                            XZ[orow * D + d] = beta * z;
+                        }
+                    }
+                }
+            }
+        } else {
+            for (int e = tid; e < rn * dn; e += ATT_THREADS) { int r = e / dn, d = d0 + e - r * dn; Z[(long)(i0 + r) * D + d] = 0.f; XZ[(long)(i0 + r) * D + d] = 0.f; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ LSTM cell (pointwise part)
+// gates (N,4n) pre-activation = h W_hh^T + xz W_ih_z^T + biases (already in HC) + GY (embedding part).
+// Gate order i,f,g,o.  Activated gates are written back in place for backward.
+__global__ void lstm_cell_fwd_kernel(float* __restrict__ gates, int g_ld, const float* __restrict__ gy,
+                                     const float* __restrict__ c_prev, const float* __restrict__ h_prev,
+                                     float* __restrict__ c_new, float* __restrict__ h_new,
+                                     const int* __restrict__ lengths, int step, int N, int n) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)N * n) return;
+    int i = (int)(idx / n), j = (int)(idx - (long)i * n);
+    if (lengths[i] <= step) {       // finished caption: state is carried unchanged (model.py:544 updates live rows only)
+        c_new[idx] = c_prev[idx]; h_new[idx] = h_prev[idx];
+        float* g = gates + (long)i * g_ld;
+        g[j] = 0.f; g[n + j] = 0.f; g[2 * n + j] = 0.f; g[3 * n + j] = 0.f;
+        return;
+    }
+    float* g = gates + (long)i * g_ld;
+    const float* y = gy + (long)i * 4 * n;
+    float gi = fast_sigmoid(g[j] + y[j]);
+    float gf = fast_sigmoid(g[n + j] + y[n + j]);
+    float gg = fast_tanh(g[2 * n + j] + y[2 * n + j]);
+    float go = fast_sigmoid(g[3 * n + j] + y[3 * n + j]);
+    float c = gf * c_prev[idx] + gi * gg;
+    c_new[idx] = c;
+    h_new[idx] = go * fast_tanh(c);
+    g[j] = gi; g[n + j] = gf; g[2 * n + j] = gg; g[3 * n + j] = go;
+}
+
+// backward of the cell.  dh_carry/dc_carry are the running gradients w.r.t. h_t / c_t from later steps;
+// dh_out is the gradient arriving from the output layer of this step.  Writes dG (pre-activation gate
+// grads) and leaves dh_carry = 0 for live rows (the h_{t-1} gradient is accumulated by the GEMM after).
+__global__ void lstm_cell_bwd_kernel(const float* __restrict__ gates, int g_ld, const float* __restrict__ c_prev,
+                                     const float* __restrict__ c_new, const float* __restrict__ dh_out,
+                                     float* __restrict__ dh_carry, float* __restrict__ dc_carry,
+                                     float* __restrict__ dgates, int dg_ld,
+                                     const int* __restrict__ lengths, int step, int N, int n) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)N * n) return;
+    int i = (int)(idx / n), j = (int)(idx - (long)i * n);
+    float* dg = dgates + (long)i * dg_ld;
+    if (lengths[i] <= step) { dg[j] = 0.f; dg[n + j] = 0.f; dg[2 * n + j] = 0.f; dg[3 * n + j] = 0.f; return; }
+    const float* g = gates + (long)i * g_ld;
+    float gi = g[j], gf = g[n + j], gg = g[2 * n + j], go = g[3 * n + j];
+    float dh = dh_carry[idx] + dh_out[idx];
+    float tc = fast_tanh(c_new[idx]);
+    float dc = dc_carry[idx] + dh * go * (1.f - tc * tc);
+    dg[j] = dc * gg * gi * (1.f - gi);
+    dg[n + j] = dc * c_prev[idx] * gf * (1.f - gf);
+    dg[2 * n + j] = dc * gi * (1.f - gg * gg);
+    dg[3 * n + j] = dh * tc * go * (1.f - go);
+    dc_carry[idx] = dc * gf;
+    dh_carry[idx] = 0.f;
+}
+
+// ------------------------------------------------------------------ attention backward (one decode step)
+// grid = B; block = 256.  Per live caption row i of image b:
+//   dz = dZ_out + dXZ*beta ; dbeta_pre = dXZ * z * beta(1-beta)
+//   dalpha_l = dz . ann[b,l,:] + dalpha_ext ; ds = alpha (dalpha - sum alpha dalpha)
+//   dpre_lk = ds_l L^-1/2 w_k (1 - tanh^2(U_lk + q_k)) ; dq_k = sum_l dpre ; dU += sum_r dpre ; dw_k += sum ds L^-1/2 tanh
+// dyn LDS: [RMAX*L alpha][RMAX*L dalpha/ds][RMAX*A q][A w][RMAX*D dz][4*RMAX*A dq partial][4*A dw partial]
+__global__ __launch_bounds__(ATT_THREADS) void attention_bwd_kernel(
+    const float* __restrict__ ann, const float* __restrict__ U, const float* __restrict__ hc, int hc_ld,
+    const float* __restrict__ wf, const int* __restrict__ lengths, int step,
+    const float* __restrict__ alphas, const float* __restrict__ dalphas_ext, int T1,
+    const float* __restrict__ Zs, const float* __restrict__ dZ_out, const float* __restrict__ dXZ,
+    float* __restrict__ DZ, float* __restrict__ dhc, int dhc_ld, float* __restrict__ dU, float* __restrict__ dwf_part,
+    int R, int L, int D, int A) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* s_al = sm;                         // [RMAX][L]
+    float* s_da = s_al + ATT_RMAX * L;        // [RMAX][L]
+    float* s_q = s_da + ATT_RMAX * L;         // [RMAX][A]
+    float* s_w = s_q + ATT_RMAX * A;          // [A]
+    float* s_dz = s_w + A;                    // [RMAX][D]
+    float* s_dq = s_dz + ATT_RMAX * D;        // [4][RMAX][A]
+    float* s_dw = s_dq + 4 * ATT_RMAX * A;    // [4][A]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float scale = 1.0f / sqrtf((float)L);
+    for (int k = tid; k < A; k += ATT_THREADS) s_w[k] = wf[k];
+    for (int e = tid; e < 4 * A; e += ATT_THREADS) s_dw[e] = 0.f;
+
+    for (int r0 = 0; r0 < R; r0 += ATT_RMAX) {
+        const int rn = min(ATT_RMAX, R - r0);
+        const int i0 = b * R + r0;
+        unsigned lmask = 0;
+        for (int r = 0; r < rn; ++r) if (lengths[i0 + r] > step) lmask |= 1u << r;
+        const bool any = lmask != 0;
+        __syncthreads();
+        // gate backward + dz for every row of the chunk (dead rows: zeros)
+        for (int e = tid; e < rn * D; e += ATT_THREADS) {
+            int r = e / D, d = e - r * D; long row = i0 + r;
+            float dz = 0.f, dbp = 0.f;
+            if (((lmask >> r) & 1u)) {
+                float beta = hc[row * hc_ld + A + d], z = Zs[row * D + d], dx = dXZ[row * D + d];
+                dz = dZ_out[row * D + d] + dx * beta;
+                dbp = dx * z * beta * (1.f - beta);
+            }
+            s_dz[r * D + d] = dz;
+            DZ[row * D + d] = dz;
+            dhc[row * dhc_ld + A + d] = dbp;
+        }
+        if (!any) {
+            for (int e = tid; e < rn * A; e += ATT_THREADS) { int r = e / A, k = e - r * A; dhc[(long)(i0 + r) * dhc_ld + k] = 0.f; }
+            continue;
+        }
+        for (int e = tid; e < rn * A; e += ATT_THREADS) { int r = e / A, k = e - r * A; s_q[r * A + k] = hc[(long)(i0 + r) * hc_ld + k]; }
+        for (int e = tid; e < rn * L; e += ATT_THREADS) { int r = e / L, l = e - r * L; s_al[r * L + l] = ((lmask >> r) & 1u) ? alphas[((long)(i0 + r) * T1 + step) * L + l] : 0.f; }
+        __syncthreads();
+        // ---- dalpha[r][l] = dz[r] . ann[b,l,:]  (wave per location)
+        for (int l = wave; l < L; l += 4) {
+            float part[ATT_RMAX];
+#pragma unroll
+            for (int r = 0; r < ATT_RMAX; ++r) part[r] = 0.f;
+            const float* a = ann + ((long)b * L + l) * D;
+            for (int d = lane; d < D; d += 64) {
+                float av = a[d];
+#pragma unroll
+                for (int r = 0; r < ATT_RMAX; ++r) if (((lmask >> r) & 1u)) part[r] += av * s_dz[r * D + d];
+            }
+#pragma unroll
+            for (int r = 0; r < ATT_RMAX; ++r) if (((lmask >> r) & 1u)) {
+                float s = wave_sum(part[r]);
+                if (lane == 0) s_da[r * L + l] = s + (dalphas_ext ? dalphas_ext[((long)(i0 + r) * T1 + step) * L + l] : 0.f);
+            }
+        }
+        __syncthreads();
+        // ---- softmax backward, wave per row: ds = alpha * (dalpha - sum alpha*dalpha)
+        for (int r = wave; r < rn; r += 4) {
+            if (!((lmask >> r) & 1u)) continue;
+            float dot = 0.f;
+            for (int l = lane; l < L; l += 64) dot += s_al[r * L + l] * s_da[r * L + l];
+            dot = wave_sum(dot);
+            for (int l = lane; l < L; l += 64) s_da[r * L + l] = s_al[r * L + l] * (s_da[r * L + l] - dot) * scale;
+        }
+        __syncthreads();
+        // ---- through tanh: wave per location, lanes over the attention dim (2 per lane at A=128)
+        for (int k0 = 0; k0 < A; k0 += 64) {
+            const int k = k0 + lane;
+            float dq[ATT_RMAX]; float dw = 0.f;
+#pragma unroll
+            for (int r = 0; r < ATT_RMAX; ++r) dq[r] = 0.f;
+            if (k < A) {
+                const float w = s_w[k];
+                for (int l = wave; l < L; l += 4) {
+                    const long uo = ((long)b * L + l) * A + k;
+                    const float uv = U[uo];
+                    float du = 0.f;
+#pragma unroll
+                    for (int r = 0; r < ATT_RMAX; ++r) if (((lmask >> r) & 1u)) {
+                        float th = fast_tanh(uv + s_q[r * A + k]);
+                        float ds = s_da[r * L + l];
+                        float dp = ds * w * (1.f - th * th);
+                        dq[r] += dp; du += dp; dw += ds * th;
+                    }
+                    dU[uo] += du;                   // this block owns image b: plain read-modify-write, fixed order
+                }
+#pragma unroll
+                for (int r = 0; r < ATT_RMAX; ++r) s_dq[(wave * ATT_RMAX + r) * A + k] = dq[r];
+                s_dw[wave * A + k] += dw;
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < rn * A; e += ATT_THREADS) {
+            int r = e / A, k = e - r * A;
+            float s = 0.f;
+            if (((lmask >> r) & 1u)) for (int w = 0; w < 4; ++w) s += s_dq[(w * ATT_RMAX + r) * A + k];
+            dhc[(long)(i0 + r) * dhc_ld + k] = s;
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < A; k += ATT_THREADS) dwf_part[(long)b * A + k] += s_dw[k] + s_dw[A + k] + s_dw[2 * A + k] + s_dw[3 * A + k];
+}
+
+// dann[b,l,d] (+)= sum over this image's caption rows r and steps t of alpha[i,t,l] * DZ[t][i][d]
+// grid = (B, ceil(D/256)); the (t,r) loop runs in a fixed order: deterministic.
+__global__ void dann_from_context_kernel(const float* __restrict__ alphas, const float* __restrict__ DZ, const int* __restrict__ lengths,
+                                         float* __restrict__ dann, int accumulate, int R, int N, int T1, int L, int D) {
+    extern __shared__ float s_a[];   // [L] alphas of the current (t, r)
+    const int b = blockIdx.x, d = blockIdx.y * blockDim.x + threadIdx.x;
+    float acc[16];                   // L is processed in slabs of 16 locations
+    for (int l0 = 0; l0 < L; l0 += 16) {
+        const int ln = min(16, L - l0);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+        for (int r = 0; r < R; ++r) {
+            const int i = b * R + r; const int len = min(lengths[i], T1);
+            for (int t = 0; t < len; ++t) {
+                __syncthreads();
+                if ((int)threadIdx.x < ln) s_a[threadIdx.x] = alphas[((long)i * T1 + t) * L + l0 + threadIdx.x];
+                __syncthreads();
+                if (d < D) {
+                    const float dz = DZ[((long)t * N + i) * D + d];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) if (j < ln) acc[j] += s_a[j] * dz;
+                }
+            }
+        }
+        if (d < D)
+            for (int j = 0; j < ln; ++j) {
+                float* p = dann + ((long)b * L + l0 + j) * D + d;
+                *p = accumulate ? (*p + acc[j]) : acc[j];
+            }
+    }
+}
+
+// dann[b,l,d] += dmean[b,d] / L  (backward of the spatial mean in InitLSTM)
+__global__ void dann_add_mean_kernel(float* __restrict__ dann, const float* __restrict__ dmean, int L, int D, long total) {
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    long b = e / ((long)L * D); int d = (int)(e % D);
+    dann[e] += dmean[b * D + d] / (float)L;
+}
+
+// ------------------------------------------------------------------ losses
+// Label-smoothed cross entropy over packed rows (util.py:105-112).  One block per packed token row:
+// online log-sum-exp, row argmax (accuracy, model.py:596-597) and the row loss; ce_finish_kernel reduces
+// loss_rows in a fixed order.  The gradient is a second kernel so that autograd's grad_output scales it.
+__global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ logits, const int* __restrict__ target, int V,
+                                                      float smoothing, float* __restrict__ lse_rows,
+                                                      float* __restrict__ loss_rows, int* __restrict__ correct_rows) {
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const float* x = logits + (long)p * V;
+    __shared__ float s_m[4], s_s[4], s_t[4], s_b[4]; __shared__ int s_i[4];
+    float mx = -INFINITY, sum = 0.f, tot = 0.f; int bi = 0x7fffffff; float bv = -INFINITY;
+    for (int v = tid; v < V; v += 256) {
+        float xv = x[v];
+        tot += xv;
+        if (xv > bv || (xv == bv && v < bi)) { bv = xv; bi = v; }
+        if (xv > mx) { sum = sum * __expf(mx - xv) + 1.f; mx = xv; } else sum += __expf(xv - mx);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        float om = __shfl_xor(mx, o, 64), os = __shfl_xor(sum, o, 64);
+        float nm = fmaxf(mx, om);
+        float fa = (mx == nm) ? 1.f : __expf(mx - nm), fb = (om == nm) ? 1.f : __expf(om - nm);   // (-inf) - (-inf) guard
+        sum = sum * fa + os * fb; mx = nm;
+        tot += __shfl_xor(tot, o, 64);
+        float ob = __shfl_xor(bv, o, 64); int oi = __shfl_xor(bi, o, 64);
+        if (ob > bv || (ob == bv && oi < bi)) { bv = ob; bi = oi; }
+    }
+    const int w = tid >> 6;
+    if ((tid & 63) == 0) { s_m[w] = mx; s_s[w] = sum; s_t[w] = tot; s_b[w] = bv; s_i[w] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        float M = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+        float S = 0.f, Tt = 0.f, Bv = -INFINITY; int Bi = 0x7fffffff;
+        for (int k = 0; k < 4; ++k) {
+            S += (s_m[k] == M) ? s_s[k] : s_s[k] * __expf(s_m[k] - M); Tt += s_t[k];
+            if (s_b[k] > Bv || (s_b[k] == Bv && s_i[k] < Bi)) { Bv = s_b[k]; Bi = s_i[k]; }
+        }
+        const float lse = M + __logf(S);
+        const int t = target[p];
+        float nll = lse - x[t];
+        float smooth = lse - Tt / (float)V;
+        lse_rows[p] = lse;
+        loss_rows[p] = (1.f - smoothing) * nll + smoothing * smooth;
+        correct_rows[p] = (Bi == t) ? 1 : 0;
+    }
+}
+// dlogits[p, v] = g/P * (softmax - smoothing/V - (1-smoothing)[v == target])
+__global__ void ce_grad_kernel(const float* __restrict__ logits, const int* __restrict__ target, const float* __restrict__ lse_rows,
+                               int V, float smoothing, float inv_rows, const float* __restrict__ gscale, float* __restrict__ dlogits) {
+    const int p = blockIdx.x;
+    const float* x = logits + (long)p * V; float* g = dlogits + (long)p * V;
+    const float lse = lse_rows[p], sv = smoothing / (float)V, conf = 1.f - smoothing;
+    const float sc = inv_rows * (gscale ? gscale[0] : 1.f);
+    const int t = target[p];
+    for (int v = threadIdx.x; v < V; v += blockDim.x) g[v] = (__expf(x[v] - lse) - sv - ((v == t) ? conf : 0.f)) * sc;
+}
+
+// out[0] = mean(loss_rows), out[1] = #correct / P   (single block, fixed-order tree)
+__global__ void ce_finish_kernel(const float* __restrict__ loss_rows, const int* __restrict__ correct_rows, int P, float* __restrict__ out) {
+    __shared__ double s_l[256]; __shared__ int s_c[256];
+    double s = 0.0; int c = 0;
+    for (int p = threadIdx.x; p < P; p += 256) { s += (double)loss_rows[p]; c += correct_rows[p]; }
+    s_l[threadIdx.x] = s; s_c[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) { s_l[threadIdx.x] += s_l[threadIdx.x + o]; s_c[threadIdx.x] += s_c[threadIdx.x + o]; } __syncthreads(); }
+    if (threadIdx.x == 0) { out[0] = (float)(s_l[0] / (double)P); out[1] = (float)s_c[0] / (float)P; }
+}
+
+// Doubly-stochastic term (model.py:594).  asum[i,l] = sum_t alphas[i,t,l]; part[block] = sum (1-asum)^2
+__global__ void ds_rows_kernel(const float* __restrict__ alphas, float* __restrict__ asum, float* __restrict__ part, int N, int T1, int L) {
+    __shared__ float s_p[256];
+    long e = (long)blockIdx.x * 256 + threadIdx.x;
+    float v = 0.f;
+    if (e < (long)N * L) {
+        long i = e / L; int l = (int)(e % L);
+        float s = 0.f;
+        for (int t = 0; t < T1; ++t) s += alphas[(i * T1 + t) * L + l];
+        asum[e] = s;
+        v = (1.f - s) * (1.f - s);
+    }
+    s_p[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) s_p[threadIdx.x] += s_p[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) part[blockIdx.x] = s_p[0];
+}
+__global__ void ds_finish_kernel(const float* __restrict__ part, int nparts, float gamma, long count, float* __restrict__ out) {
+    __shared__ double s_p[256];
+    double s = 0.0;
+    for (int p = threadIdx.x; p < nparts; p += 256) s += (double)part[p];
+    s_p[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) s_p[threadIdx.x] += s_p[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) out[0] = gamma * (float)(s_p[0] / (double)count);
+}
+// dalphas[i,t,l] = gscale[0] * gamma * 2 (asum[i,l] - 1) / (N L)   for every t
+__global__ void ds_grad_kernel(const float* __restrict__ asum, const float* __restrict__ gscale, float gamma, float* __restrict__ dalphas, int N, int T1, int L) {
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)N * T1 * L) return;
+    long i = e / ((long)T1 * L); int l = (int)(e % L);
+    float g = gscale ? gscale[0] : 1.f;
+    dalphas[e] = g * gamma * 2.f * (asum[i * L + l] - 1.f) / (float)((long)N * L);
+}
+
+// ------------------------------------------------------------------ reductions for bias grads
+// out[c] (+)= sum_r x[r*ld + c], rows split over grid.y into fixed chunks, partials reduced in order.
+__global__ void colsum_part_kernel(const float* __restrict__ x, long ld, int rows, int cols, int rows_per, float* __restrict__ part) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += x[(long)r * ld + c];
+    part[(long)blockIdx.y * cols + c] = s;
+}
+__global__ void colsum_finish_kernel(const float* __restrict__ part, int nparts, int cols, float* __restrict__ out, int accumulate, float scale) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += part[(long)p * cols + c];
+    s *= scale;
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+// embedding gradient: dE[tok[r], :] += dY[r, :]  (padding row and dead rows skipped).  Float atomics.
+__global__ void embedding_bwd_kernel(const float* __restrict__ dY, const int* __restrict__ tok, float* __restrict__ dE, int rows, int width, int padding_idx) {
+    int r = blockIdx.x;
+    if (r >= rows) return;
+    int t = tok[r];
+    if (t < 0 || t == padding_idx) return;
+    for (int c = threadIdx.x; c < width; c += blockDim.x) atomicAdd(dE + (long)t * width + c, dY[(long)r * width + c]);
+}
+
+// out[i] = a[i] + b[i]
+__global__ void add_kernel(float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ b, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i];
+}
+// y[r, :] (+)= x[map[r], :]   (map < 0 -> zero contribution)
+__global__ void scatter_rows_kernel(const float* __restrict__ src, const int* __restrict__ prow, float* __restrict__ dst, int rows, int width) {
+    int r = blockIdx.x;
+    if (r >= rows) return;
+    int p = prow[r];
+    for (int c = threadIdx.x; c < width; c += blockDim.x) dst[(long)r * width + c] = (p >= 0) ? src[(long)p * width + c] : 0.f;
+}
+
+}  // namespace sat

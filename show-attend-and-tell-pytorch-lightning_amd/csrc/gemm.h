@@ -1,0 +1,59 @@
+// MFMA GEMM / implicit-GEMM family used by every contraction on the SAT hot
+// path: decoder Linears (model.py:72-73,90-92,119-123,175-180,188), the 1x1
+// projection conv (model.py:53) and the ResNet conv stack fwd/dgrad/wgrad.
+#pragma once
+#include "common.h"
+
+namespace sat {
+
+// How the A operand (M x K) is laid out / gathered.
+enum AMode : int {
+    A_ROW = 0,         // A[m][k], k contiguous (activations x Linear)        optional a_rows gather
+    A_KMAJOR = 1,      // A stored [k][m], m contiguous (dY for weight grads)
+    A_CONV_FWD = 2,    // im2col over NHWC input : m=(n,p,q)  k=(r,s,c)
+    A_CONV_DGRAD = 3   // im2col over NHWC dY    : m=(n,h,w)  k=(r,s,ko) with stride predicate
+};
+// How the B operand (K x N) is laid out / gathered.
+enum BMode : int {
+    B_ROW = 0,           // B stored [n][k], k contiguous (Linear weight (out,in), conv weight KRSC)
+    B_KMAJOR = 1,        // B stored [k][n], n contiguous
+    B_CONV_WGRAD = 2,    // k=(n,p,q) pixel, n=(r,s,c): gathered NHWC input
+    B_CONV_DGRAD_W = 3   // k=(r,s,ko), n=c : KRSC weight read as [(r,s,ko)][c]
+};
+enum Epi : int {
+    EPI_NONE = 0,
+    EPI_BIAS = 1,               // + bias[col]
+    EPI_BIAS_SIGMOID_RANGE = 2, // + bias[col] (if bias), sigmoid on cols [c0,c1)
+    EPI_ADD_TANH = 3,           // tanh(v + e0[arow][col])   (arow = a_rows[row] if gather)
+    EPI_MUL_DTANH = 4,          // v * (1 - e0[row][col]^2)
+    EPI_BIAS_RELU = 5           // max(0, v + bias[col])
+};
+
+struct ConvGeom {
+    int N, H, W, C;      // input  NHWC
+    int K, R, S;         // filters KRSC
+    int P, Q;            // output NPQK
+    int stride, pad;
+};
+
+struct GemmArgs {
+    const float* A = nullptr; long lda = 0; const int* a_rows = nullptr;
+    const float* B = nullptr; long ldb = 0;
+    float* C = nullptr;       long ldc = 0; const int* c_rows = nullptr;
+    int M = 0, N = 0, K = 0;
+    int amode = A_ROW, bmode = B_ROW;
+    int accumulate = 0;                       // C += result (applied before the epilogue function)
+    int epi = EPI_NONE;
+    const float* bias = nullptr;
+    const float* e0 = nullptr; long lde0 = 0;
+    int c0 = 0, c1 = 0;
+    ConvGeom g = {};
+    float* slab = nullptr; long slab_elems = 0;   // split-K scratch (optional)
+};
+
+// Launches on `stream`; returns SAT_OK or sets last_error.
+int launch_gemm(const GemmArgs& a, hipStream_t stream);
+// Bytes of split-K scratch that lets launch_gemm fill the chip for this shape (0 = none needed).
+size_t gemm_slab_bytes(int M, int N, int K);
+
+}  // namespace sat

@@ -1,0 +1,87 @@
+"""CPU: the C-ABI library builds, loads, and exports every symbol include/sat_hip.h declares
+(no compute calls - there is no GPU here).  Also: the product never imports the oracle."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "show-attend-and-tell-pytorch-lightning_amd")
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    path = os.path.join(PKG, "libsat_hip.so")
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-C", os.path.join(PKG, "csrc"), "-j4"])
+    return path
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "sat_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sat_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported(libpath):
+    lib = ctypes.CDLL(libpath)
+    names = declared_symbols()
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(lib, n), "libsat_hip.so does not export %s" % n
+    lib.sat_abi_version.restype = ctypes.c_int
+    assert lib.sat_abi_version() == 1
+
+
+def test_binding_covers_header(libpath):
+    import sat_amd  # noqa: F401
+    from sat_amd import _lib
+    assert sorted(_lib.SYMBOLS) == declared_symbols()
+    _lib.lib()
+
+
+def test_argument_validation_without_gpu(libpath):
+    """Error path returns a status + message; nothing throws or exits."""
+    import sat_amd  # noqa: F401
+    from sat_amd import _lib
+    lib = _lib.lib()
+    assert lib.sat_gemm_f32(None, None) != 0
+    assert b"null" in lib.sat_last_error()
+    d = _lib.DecoderDims(B=0, R=1, T=4, L=1, D=1, A=1, m=1, n=1, V=1, P=0, deep_output=1, padding_idx=0)
+    assert lib.sat_decoder_workspace_bytes(ctypes.byref(d)) == 0
+    d = _lib.DecoderDims(B=2, R=5, T=22, L=49, D=256, A=128, m=256, n=512, V=6400, P=210, deep_output=1, padding_idx=0)
+    assert lib.sat_decoder_workspace_bytes(ctypes.byref(d)) > 1 << 20
+
+
+def test_product_fails_loudly_on_cpu():
+    import torch
+    import sat_amd  # noqa: F401
+    from sat_amd import _lib, decoder
+    with pytest.raises(_lib.SatHipError):
+        decoder.gemm(torch.zeros(4, 4), torch.zeros(4, 4))
+
+
+def test_product_does_not_import_oracle():
+    for dirpath, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("no oracle", ""), "%s mentions the oracle" % f
+
+
+def test_pack_plan_matches_pack_padded_sequence():
+    import torch
+    import sat_amd  # noqa: F401
+    from sat_amd.decoder import PackPlan
+    g = torch.Generator().manual_seed(3)
+    for N, T in ((7, 6), (40, 22), (1, 3)):
+        lens = torch.randint(1, T, (N,), generator=g)
+        x = torch.randn(N, T - 1, 5, generator=g)
+        plan = PackPlan(lens, T, "cpu")
+        ref = torch.nn.utils.rnn.pack_padded_sequence(x, lens.tolist(), batch_first=True, enforce_sorted=False)
+        assert torch.equal(plan.pack(x), ref.data)
+        assert torch.equal(plan.batch_sizes, ref.batch_sizes)
+        assert plan.P == int(lens.sum())

@@ -1,0 +1,141 @@
+"""GPU parity: the HIP decoder (C ABI: sat_decoder_train_fwd/bwd + losses) against
+ (1) the fixtures captured from the reference (tests/golden, G4/G5),
+ (2) the CPU oracle at C1 decoder shapes (G8),
+ (3) size-independent properties at the C2 benchmark shapes.
+Tolerance (north_star): fp32 logits / attention weights within 1e-4."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def close(a, b, tol=TOL, what=""):
+    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, np.float64)
+    b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(1.0, float(np.abs(b).max())) if b.size else 1.0
+    err = float(np.abs(a - b).max()) if b.size else 0.0
+    assert err <= tol * scale, "%s: max|d|=%.3e (scale %.3g, tol %.1e)" % (what, err, scale, tol)
+    return err
+
+
+@pytest.fixture(scope="module")
+def M():
+    import sat_amd  # noqa: F401
+    from sat_amd import model
+    return model
+
+
+def hp_from_golden(g, sd):
+    from oracle import sat_oracle as O
+    V, m = sd["embedding.weight"].shape
+    return O.default_hparams(vocab_size=V, embed_dim=m, decoder_dim=sd["lstm.weight_hh_l0"].shape[1],
+                             encoder_dim=sd["attention.encoder_att.weight"].shape[1], attention_dim=sd["attention.encoder_att.weight"].shape[0],
+                             deep_output=bool(g["hp_deep_output"]), weight_tying=bool(g["hp_weight_tying"]),
+                             label_smoothing=float(g["hp_label_smoothing"]), att_gamma=float(g["hp_att_gamma"]))
+
+
+GOLDEN_TAGS = ["tf1", "tf0", "tf05", "smooth", "shallow", "tied", "gamma"]   # layers2 / embnorm: not built on the HIP path this round
+
+
+@pytest.mark.parametrize("tag", GOLDEN_TAGS)
+def test_golden_train_batch_and_grads(M, golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, "g4_train_%s.npz" % tag))
+    sd = {k[3:]: torch.from_numpy(g[k].copy()) for k in g.files if k.startswith("sd.")}
+    hp = hp_from_golden(g, sd)
+    dec = M.SATDecoder(hp).cuda()
+    dec.load_decoder_state(sd)
+    ann = torch.from_numpy(g["ann"])                                   # (B, D, h, w) as the encoder returns it
+    B, D, Hh, Ww = ann.shape
+    ann_bld = ann.permute(0, 2, 3, 1).reshape(B, Hh * Ww, D).contiguous().cuda().requires_grad_()
+    draws = iter(g["draws"].tolist())
+    res = dec.train_decode(ann_bld, torch.from_numpy(g["caps"]).cuda(), torch.from_numpy(g["lengths"]), float(g["epsilon"]),
+                           draw=lambda: next(draws))
+    assert next(draws, None) is None                                   # same RNG consumption as the reference (F7)
+    assert res["plan"].batch_sizes.tolist() == g["batch_sizes"].tolist()
+    assert np.array_equal(res["targets_packed"].cpu().numpy(), g["targets_packed"])
+    close(res["logits_packed"], g["logits_packed"], what="logits")
+    close(res["alphas"], g["alphas"], what="alphas")
+    close(res["ce"], g["ce"], what="ce"); close(res["ds"], g["ds"], what="ds"); close(res["acc"], g["acc"], what="acc")
+    loss = res["ce"] + res["ds"]
+    close(loss, g["loss"], what="loss")
+    loss.backward()
+    d_ann = ann_bld.grad.reshape(B, Hh, Ww, D).permute(0, 3, 1, 2)
+    close(d_ann, g["d_ann"], 2e-4, "d_ann")
+    params = dict(dec.named_parameters())
+    for k in g.files:
+        if k.startswith("g."):
+            close(params[k[2:]].grad, g[k], 2e-4, k)
+    # doubly-stochastic term: report the distance to the reference bit pattern
+    bits = np.float32(res["ds"].item()).view(np.uint32)
+    print("ds ulps vs reference:", abs(int(bits) - int(g["ds_bits"])))
+
+
+def test_c1_shapes_against_oracle_and_golden(M, golden_dir):
+    """C1 decoder shapes (N=40, L=49, D=256, A=128, n=512, V=6400, T=22), ragged lengths."""
+    from oracle import prng, sat_oracle as O
+    g = np.load(os.path.join(golden_dir, "g8_c1_decoder.npz"))
+    hp = O.default_hparams(vocab_size=6400, encoder_dim=256, embed_dim=256, attention_dim=128, decoder_dim=512)
+    sd = {k: torch.from_numpy(v) for k, v in prng.decoder_state(hp, 80).items()}
+    ann = torch.from_numpy(prng.uniform((8, 256, 7, 7), 801, 0.0, 2.0))
+    caps, lengths = prng.captions(8, 5, 22, 6400, 802, min_len=8)
+    caps, lengths = torch.from_numpy(caps), torch.from_numpy(lengths)
+    dec = M.SATDecoder(hp).cuda(); dec.load_decoder_state(sd)
+    ann_bld = ann.permute(0, 2, 3, 1).reshape(8, 49, 256).contiguous().cuda().requires_grad_()
+    res = dec.train_decode(ann_bld, caps.cuda(), lengths, 1.0)
+    lp = res["logits_packed"]
+    assert lp.shape[0] == int(g["n_tokens"])
+    close(lp[:64, :32], g["logits_head"], what="logits head vs reference")
+    close(res["alphas"][:4], g["alphas_head"], what="alphas head vs reference")
+    close(res["ce"], g["ce"], what="ce"); close(res["ds"], g["ds"], what="ds")
+    (res["ce"] + res["ds"]).backward()
+    d_ann = ann_bld.grad.reshape(8, 7, 7, 256).permute(0, 3, 1, 2)
+    close(d_ann[:2, :16], g["d_ann_head"], 2e-4, "d_ann head vs reference")
+    # full tensors against the oracle run here on the CPU
+    sdo = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    ann_o = ann.clone().requires_grad_()
+    loss_o, out_o = O.training_loss(sdo, hp, ann_o, caps, lengths, 1.0)
+    loss_o.backward()
+    close(lp, out_o["logits_packed"], what="logits vs oracle"); close(res["alphas"], out_o["alphas"], what="alphas vs oracle")
+    close(d_ann, ann_o.grad, 2e-4, "d_ann vs oracle")
+    for k, p in dec.named_parameters():
+        close(p.grad, sdo[k].grad, 2e-4, k)
+
+
+def test_c2_shapes_properties(M):
+    """C2 decoder shapes (B=128, R=5 -> N=640, L=49, D=512, V=6400, T=22): properties that hold at any size."""
+    from oracle import prng, sat_oracle as O
+    hp = O.default_hparams(vocab_size=6400, encoder_dim=512, embed_dim=256, attention_dim=128, decoder_dim=512)
+    sd = {k: torch.from_numpy(v) for k, v in prng.decoder_state(hp, 81).items()}
+    B, R, T, Lc = 128, 5, 22, 49
+    ann = torch.from_numpy(prng.uniform((B, Lc, 512), 811, 0.0, 2.0)).cuda().requires_grad_()
+    caps, lengths = prng.captions(B, R, T, 6400, 812, min_len=8)
+    caps, lengths = torch.from_numpy(caps), torch.from_numpy(lengths)
+    dec = M.SATDecoder(hp).cuda(); dec.load_decoder_state(sd)
+    res = dec.train_decode(ann, caps.cuda(), lengths, 1.0)
+    al = res["alphas"]
+    live = (torch.arange(T - 1)[None, :] < lengths.reshape(-1, 1)).cuda()
+    s = al.sum(-1)
+    assert (s[live] - 1).abs().max().item() < 1e-5             # every live step is a distribution over L
+    assert al[~live].abs().max().item() == 0.0                   # finished captions keep zero alphas (model.py:506)
+    assert res["logits_packed"].shape == (int(lengths.sum()), 6400)
+    assert torch.isfinite(res["logits_packed"]).all()
+    (res["ce"] + res["ds"]).backward()
+    torch.cuda.synchronize()
+    for k, p in dec.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+    assert dec.embedding.weight.grad[0].abs().max().item() == 0.0    # padding_idx row gets no gradient
+    # captions of one image are exchangeable: permuting them inside every image permutes the outputs
+    perm = torch.tensor([2, 0, 4, 1, 3])
+    res2 = dec.train_decode(ann.detach(), caps[:, perm].cuda(), lengths[:, perm], 1.0)
+    a1 = al.reshape(B, R, T - 1, Lc)[:, perm].reshape(B * R, T - 1, Lc)
+    # InitLSTM mixes rows of the decoder batch (F3), so only the loss-level quantities are invariant when all
+    # captions of an image start from the same state; here rows differ, so just check shapes and determinism:
+    res3 = dec.train_decode(ann.detach(), caps[:, perm].cuda(), lengths[:, perm], 1.0)
+    assert torch.equal(res2["logits_packed"], res3["logits_packed"]) and torch.equal(res2["alphas"], res3["alphas"])
+    assert a1.shape == res2["alphas"].shape
