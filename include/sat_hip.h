@@ -121,6 +121,9 @@ int sat_doubly_stochastic_fwd(const float* alphas, int32_t N, int32_t T1, int32_
 int sat_doubly_stochastic_bwd(const float* asum, const float* gscale, int32_t N, int32_t T1, int32_t L, float gamma,
                               float* dalphas, void* stream);
 
+/* out[c] = sum_r x[r*ld + c] in a fixed order (bias gradients).  scratch: ceil(rows/256)*cols floats */
+int sat_colsum(const float* x, int64_t ld, int64_t rows, int32_t cols, float* out, float* scratch, void* stream);
+
 /* ------------------------------------------------------------------ sub-module entry points
  * (drop-in for attention / init_lstm called on their own, e.g. from caption(), model.py:269,299) */
 /* att_enc = ann * W_e^T (model.py:100), hoisted */
@@ -129,6 +132,45 @@ int sat_attention_precompute(const float* ann, const float* att_enc_w, float* U,
 int sat_attention_step_fwd(const float* ann, const float* U, const float* hc, int32_t hc_ld, const float* att_f,
                            const int32_t* lengths, int32_t step, float* alphas, int32_t T1, float* Z, float* XZ,
                            int32_t B, int32_t R, int32_t L, int32_t D, int32_t A, void* stream);
+
+/* ------------------------------------------------------------------ encoder (get_encoder, model.py:16-63)
+ * The reference builds the encoder from torchvision ResNet layers (model.py:19-29) + Normalize
+ * (model.py:59) + an optional 1x1 Conv2d with bias (model.py:53).  These entry points are the layers
+ * of that nn.Sequential on NHWC fp32 activations and KRSC filters. */
+typedef struct sat_conv_geom {
+    int32_t N, H, W, C;     /* input  (N, H, W, C), C % 4 == 0                    */
+    int32_t K, R, S;        /* filter (K, R, S, C), K % 4 == 0                    */
+    int32_t stride, pad;    /* output (N, P, Q, K), P = (H + 2 pad - R)/stride + 1 */
+} sat_conv_geom;
+/* nn.Conv2d forward / autograd (input gradient, weight gradient) as implicit GEMMs on MFMA */
+int sat_conv2d_fwd(const float* x, const float* w, const float* bias /* or NULL */, float* y, const sat_conv_geom* g, void* stream);
+int sat_conv2d_dgrad(const float* dy, const float* w, float* dx, const sat_conv_geom* g, int32_t accumulate, void* stream);
+int sat_conv2d_wgrad(const float* dy, const float* x, float* dw, const sat_conv_geom* g, float* slab, int64_t slab_elems, void* stream);
+size_t sat_conv2d_wgrad_slab_bytes(const sat_conv_geom* g);
+/* torchvision Normalize(mean, std) (model.py:59) fused with NCHW -> NHWC and 3 -> 4 channel padding */
+int sat_image_normalize_nhwc4(const float* img_nchw, float* out_nhwc4, int32_t N, int32_t H, int32_t W,
+                              const float* mean3_host, const float* std3_host, void* stream);
+/* (pixels, 3) <-> (pixels, 4) zero padded; used for the stem filters */
+int sat_pad_channels_3to4(const float* src, float* dst, int64_t pixels, int32_t inverse, void* stream);
+/* nn.BatchNorm2d in training mode over a (rows, C) NHWC view, fused with the residual add and ReLU of the
+ * ResNet blocks.  scratch: sat_bn_scratch_bytes(rows, C).  Updates running stats like PyTorch. */
+size_t sat_bn_scratch_bytes(int64_t rows, int32_t C);
+int sat_bn_train_fwd(const float* x, int64_t rows, int32_t C, const float* gamma, const float* beta, float eps, float momentum,
+                     float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                     const float* residual /* or NULL */, int32_t relu, float* y, float* scratch, void* stream);
+/* eval-mode BatchNorm: y = (x - running_mean) / sqrt(running_var + eps) * gamma + beta (+ residual)(ReLU) */
+int sat_bn_eval_fwd(const float* x, int64_t rows, int32_t C, const float* running_mean, const float* running_var, float eps,
+                    const float* gamma, const float* beta, const float* residual, int32_t relu, float* y, void* stream);
+/* backward: dy is the gradient of the fused output y; dres (optional) receives the gradient of the residual input */
+int sat_bn_train_bwd(const float* dy, const float* x, const float* y, int64_t rows, int32_t C, const float* save_mean,
+                     const float* save_invstd, const float* gamma, int32_t relu, float* dx, float* dgamma, float* dbeta,
+                     float* dres, int32_t dres_accumulate, float* scratch, void* stream);
+/* nn.MaxPool2d(3, 2, 1) of the ResNet stem; argmax (N,P,Q,C) bytes keep the window position */
+int sat_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* argmax, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+int sat_maxpool3x3s2_bwd(const float* dy, const uint8_t* argmax, float* dx, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+/* encoder_size option (readme.md:118-121): AdaptiveAvgPool2d when P <= H, bilinear Upsample(align_corners=False) otherwise */
+int sat_resize_fwd(const float* x, float* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t P, int32_t Q, void* stream);
+int sat_resize_bwd(const float* dy, float* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t P, int32_t Q, void* stream);
 
 #ifdef __cplusplus
 }

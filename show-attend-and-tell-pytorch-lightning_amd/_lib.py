@@ -71,6 +71,30 @@ SYMBOLS = {
 }
 
 
+class ConvGeom(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("N", "H", "W", "C", "K", "R", "S", "stride", "pad")]
+
+
+_vp, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+SYMBOLS.update({
+    "sat_conv2d_fwd": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(ConvGeom), _vp]),
+    "sat_conv2d_dgrad": (C.c_int, [_vp, _vp, _vp, C.POINTER(ConvGeom), _i32, _vp]),
+    "sat_conv2d_wgrad": (C.c_int, [_vp, _vp, _vp, C.POINTER(ConvGeom), _vp, _i64, _vp]),
+    "sat_conv2d_wgrad_slab_bytes": (C.c_size_t, [C.POINTER(ConvGeom)]),
+    "sat_image_normalize_nhwc4": (C.c_int, [_vp, _vp, _i32, _i32, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp]),
+    "sat_pad_channels_3to4": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "sat_bn_scratch_bytes": (C.c_size_t, [_i64, _i32]),
+    "sat_bn_train_fwd": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "sat_bn_eval_fwd": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _f, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "sat_colsum": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp]),
+    "sat_bn_train_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "sat_maxpool3x3s2_fwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "sat_maxpool3x3s2_bwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "sat_resize_fwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "sat_resize_bwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+})
+
+
 class SatHipError(RuntimeError):
     pass
 

@@ -85,6 +85,12 @@ int sat_doubly_stochastic_bwd(const float* asum, const float* gscale, int32_t N,
     return ds_bwd(asum, gscale, N, T1, L, gamma, dalphas, (hipStream_t)stream);
 }
 
+int sat_colsum(const float* x, int64_t ld, int64_t rows, int32_t cols, float* out, float* scratch, void* stream) {
+    if (!x || !out || !scratch) return fail(SAT_EINVAL, "colsum: null pointer");
+    if (rows <= 0 || cols <= 0 || ld < cols) return fail(SAT_EINVAL, "colsum: bad shape");
+    return colsum_public(x, ld, rows, cols, out, scratch, (hipStream_t)stream);
+}
+
 int sat_attention_precompute(const float* ann, const float* att_enc_w, float* U, int32_t B, int32_t L, int32_t D, int32_t A, void* stream) {
     if (!ann || !att_enc_w || !U) return fail(SAT_EINVAL, "attention_precompute: null pointer");
     GemmArgs g; g.A = ann; g.lda = D; g.B = att_enc_w; g.ldb = D; g.C = U; g.ldc = A; g.M = B * L; g.N = A; g.K = D;

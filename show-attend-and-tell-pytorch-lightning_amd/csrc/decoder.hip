@@ -312,6 +312,11 @@ int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
 }
 
 
+int colsum_public(const float* x, long ld, long rows, int cols, float* out, float* scratch, hipStream_t st) {
+    Ws w; w.colpart = scratch;
+    return colsum(st, w, x, ld, (int)rows, cols, out);
+}
+
 size_t decoder_workspace_bytes(const sat_decoder_dims& d) { return layout(d, nullptr).total; }
 
 // ------------------------------------------------------------------ losses

@@ -1,0 +1,423 @@
+// Encoder (ResNet trunk, reference model.py:16-63 via torchvision) on gfx950: NHWC activations,
+// KRSC filters.  Convolutions are implicit GEMMs on the MFMA kernel of gemm.hip (forward, data
+// gradient, weight gradient); this file adds the memory-bound layers around them: input
+// normalisation (model.py:59), train-mode BatchNorm (+ReLU, +residual) forward/backward,
+// 3x3/2 max-pool, adaptive average pool / bilinear resize of the `encoder_size` option (readme.md:118-121).
+#include "../../include/sat_hip.h"
+#include "common.h"
+#include "gemm.h"
+
+namespace sat {
+
+// ------------------------------------------------------------------ input: NCHW [0,1] -> normalised NHWC, C padded 3 -> 4
+__global__ void normalize_nhwc4_kernel(const float* __restrict__ img, float* __restrict__ out, int H, int W, long total,
+                                       float m0, float m1, float m2, float s0, float s1, float s2) {
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;     // one output pixel (4 channels)
+    if (e >= total) return;
+    long hw = (long)H * W; long n = e / hw, p = e - n * hw;
+    const float* src = img + n * 3 * hw + p;
+    float4 v;
+    v.x = (src[0] - m0) / s0; v.y = (src[hw] - m1) / s1; v.z = (src[2 * hw] - m2) / s2; v.w = 0.f;
+    reinterpret_cast<float4*>(out)[e] = v;
+}
+
+// stem filters (K,R,S,3) <-> (K,R,S,4)
+__global__ void pad_c3_to_c4_kernel(const float* __restrict__ w3, float* __restrict__ w4, long n) {
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    reinterpret_cast<float4*>(w4)[e] = make_float4(w3[3 * e], w3[3 * e + 1], w3[3 * e + 2], 0.f);
+}
+__global__ void unpad_c4_to_c3_kernel(const float* __restrict__ w4, float* __restrict__ w3, long n) {
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    float4 v = reinterpret_cast<const float4*>(w4)[e];
+    w3[3 * e] = v.x; w3[3 * e + 1] = v.y; w3[3 * e + 2] = v.z;
+}
+
+// ------------------------------------------------------------------ BatchNorm (training mode)
+// Column statistics of a (rows x C) matrix, C % 4 == 0.  Block = 256 threads = TW vector-columns x RL row lanes.
+// MODE 0: sum x, sum x^2.   MODE 1: sum g, sum g*xhat with g = dy * (relu ? y > 0 : 1).
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_colstats_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
+                                                          long rows, int C, int TW, long rows_per, float* __restrict__ part0, float* __restrict__ part1) {
+    __shared__ float4 s0[256], s1[256];
+    const int tid = threadIdx.x, tc = tid % TW, tr = tid / TW, RL = 256 / TW;
+    const int c4 = blockIdx.x * TW + tc;           // vector column
+    const int C4 = C >> 2;
+    float4 a0 = make_float4(0, 0, 0, 0), a1 = a0;
+    if (c4 < C4 && tr < RL) {
+        float4 mu = a0, is = a0;
+        if (MODE == 1) { mu = reinterpret_cast<const float4*>(mean)[c4]; is = reinterpret_cast<const float4*>(invstd)[c4]; }
+        long r0 = (long)blockIdx.y * rows_per, r1 = r0 + rows_per; if (r1 > rows) r1 = rows;
+        for (long r = r0 + tr; r < r1; r += RL) {
+            float4 xv = reinterpret_cast<const float4*>(x)[r * C4 + c4];
+            if (MODE == 0) {
+                a0.x += xv.x; a0.y += xv.y; a0.z += xv.z; a0.w += xv.w;
+                a1.x += xv.x * xv.x; a1.y += xv.y * xv.y; a1.z += xv.z * xv.z; a1.w += xv.w * xv.w;
+            } else {
+                float4 g = reinterpret_cast<const float4*>(dy)[r * C4 + c4];
+                if (relu) { float4 yv = reinterpret_cast<const float4*>(y)[r * C4 + c4];
+                    g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f; }
+                a0.x += g.x; a0.y += g.y; a0.z += g.z; a0.w += g.w;
+                a1.x += g.x * (xv.x - mu.x) * is.x; a1.y += g.y * (xv.y - mu.y) * is.y;
+                a1.z += g.z * (xv.z - mu.z) * is.z; a1.w += g.w * (xv.w - mu.w) * is.w;
+            }
+        }
+    }
+    s0[tid] = a0; s1[tid] = a1;
+    __syncthreads();
+    if (tr == 0 && c4 < C4) {
+        for (int k = 1; k < RL; ++k) {     // fixed order
+            float4 b0 = s0[k * TW + tc], b1 = s1[k * TW + tc];
+            a0.x += b0.x; a0.y += b0.y; a0.z += b0.z; a0.w += b0.w;
+            a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
+        }
+        reinterpret_cast<float4*>(part0)[(long)blockIdx.y * C4 + c4] = a0;
+        reinterpret_cast<float4*>(part1)[(long)blockIdx.y * C4 + c4] = a1;
+    }
+}
+
+// forward finalise: batch mean / biased variance -> invstd, running stats (momentum, unbiased var) as nn.BatchNorm2d
+__global__ void bn_fwd_finalize_kernel(const float* __restrict__ part0, const float* __restrict__ part1, int nparts, int C, long rows,
+                                       float eps, float momentum, float* __restrict__ mean, float* __restrict__ invstd,
+                                       float* __restrict__ running_mean, float* __restrict__ running_var) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int p = 0; p < nparts; ++p) { s += (double)part0[(long)p * C + c]; q += (double)part1[(long)p * C + c]; }
+    double mu = s / (double)rows, var = q / (double)rows - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)mu;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        double unb = rows > 1 ? var * (double)rows / (double)(rows - 1) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+
+// y = (x - mean) * invstd * gamma + beta (+ residual) (ReLU).  eval mode (var_eps >= 0) passes the running
+// variance in `invstd` and the kernel takes 1/sqrt(var + eps) itself.
+__global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ res, int relu,
+                                float* __restrict__ y, long total4, int C4, float var_eps) {
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total4) return;
+    int c4 = (int)(e % C4);
+    float4 xv = reinterpret_cast<const float4*>(x)[e];
+    float4 mu = reinterpret_cast<const float4*>(mean)[c4], is = reinterpret_cast<const float4*>(invstd)[c4];
+    if (var_eps >= 0.f) { is.x = 1.f / sqrtf(is.x + var_eps); is.y = 1.f / sqrtf(is.y + var_eps); is.z = 1.f / sqrtf(is.z + var_eps); is.w = 1.f / sqrtf(is.w + var_eps); }
+    float4 g = reinterpret_cast<const float4*>(gamma)[c4], b = reinterpret_cast<const float4*>(beta)[c4];
+    float4 o;
+    o.x = (xv.x - mu.x) * is.x * g.x + b.x; o.y = (xv.y - mu.y) * is.y * g.y + b.y;
+    o.z = (xv.z - mu.z) * is.z * g.z + b.z; o.w = (xv.w - mu.w) * is.w * g.w + b.w;
+    if (res) { float4 r = reinterpret_cast<const float4*>(res)[e]; o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    reinterpret_cast<float4*>(y)[e] = o;
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part0, const float* __restrict__ part1, int nparts, int C,
+                                       float* __restrict__ dbeta, float* __restrict__ dgamma) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int p = 0; p < nparts; ++p) { s += (double)part0[(long)p * C + c]; q += (double)part1[(long)p * C + c]; }
+    dbeta[c] = (float)s; dgamma[c] = (float)q;
+}
+
+// dx = gamma * invstd * (g - dbeta/M - xhat * dgamma/M);  dres (optional) receives g (the masked upstream gradient)
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ dbeta, const float* __restrict__ dgamma, int relu, float inv_rows,
+                                    float* __restrict__ dx, float* __restrict__ dres, int dres_accumulate, long total4, int C4) {
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total4) return;
+    int c4 = (int)(e % C4);
+    float4 xv = reinterpret_cast<const float4*>(x)[e];
+    float4 g = reinterpret_cast<const float4*>(dy)[e];
+    if (relu) { float4 yv = reinterpret_cast<const float4*>(y)[e];
+        g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f; }
+    float4 mu = reinterpret_cast<const float4*>(mean)[c4], is = reinterpret_cast<const float4*>(invstd)[c4];
+    float4 ga = reinterpret_cast<const float4*>(gamma)[c4];
+    float4 db = reinterpret_cast<const float4*>(dbeta)[c4], dg = reinterpret_cast<const float4*>(dgamma)[c4];
+    float4 o;
+    o.x = ga.x * is.x * (g.x - db.x * inv_rows - (xv.x - mu.x) * is.x * dg.x * inv_rows);
+    o.y = ga.y * is.y * (g.y - db.y * inv_rows - (xv.y - mu.y) * is.y * dg.y * inv_rows);
+    o.z = ga.z * is.z * (g.z - db.z * inv_rows - (xv.z - mu.z) * is.z * dg.z * inv_rows);
+    o.w = ga.w * is.w * (g.w - db.w * inv_rows - (xv.w - mu.w) * is.w * dg.w * inv_rows);
+    reinterpret_cast<float4*>(dx)[e] = o;
+    if (dres) {
+        if (dres_accumulate) { float4 r = reinterpret_cast<float4*>(dres)[e]; g.x += r.x; g.y += r.y; g.z += r.z; g.w += r.w; }
+        reinterpret_cast<float4*>(dres)[e] = g;
+    }
+}
+
+// ------------------------------------------------------------------ max pool k=3 s=2 p=1 (torchvision ResNet stem)
+// argmax keeps the FIRST maximum in (kh, kw) scan order, like torch's max_pool2d (strict >).
+__global__ void maxpool3x3s2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ amax,
+                                        int H, int W, int C4, int P, int Q, long total4) {
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total4) return;
+    int c4 = (int)(e % C4); long t = e / C4; int q = (int)(t % Q); t /= Q; int p = (int)(t % P); long n = t / P;
+    float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    int bx = 0, by = 0, bz = 0, bw = 0;
+    for (int kh = 0; kh < 3; ++kh) {
+        int h = p * 2 - 1 + kh; if ((unsigned)h >= (unsigned)H) continue;
+        for (int kw = 0; kw < 3; ++kw) {
+            int w = q * 2 - 1 + kw; if ((unsigned)w >= (unsigned)W) continue;
+            float4 v = reinterpret_cast<const float4*>(x)[((n * H + h) * W + w) * C4 + c4];
+            int k = kh * 3 + kw;
+            if (v.x > best.x) { best.x = v.x; bx = k; }
+            if (v.y > best.y) { best.y = v.y; by = k; }
+            if (v.z > best.z) { best.z = v.z; bz = k; }
+            if (v.w > best.w) { best.w = v.w; bw = k; }
+        }
+    }
+    reinterpret_cast<float4*>(y)[e] = best;
+    reinterpret_cast<uchar4*>(amax)[e] = make_uchar4(bx, by, bz, bw);
+}
+// gather form (deterministic): every input position sums the outputs whose argmax points at it
+__global__ void maxpool3x3s2_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ amax, float* __restrict__ dx,
+                                        int H, int W, int C4, int P, int Q, long total4) {
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total4) return;
+    int c4 = (int)(e % C4); long t = e / C4; int w = (int)(t % W); t /= W; int h = (int)(t % H); long n = t / H;
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (int kh = 0; kh < 3; ++kh) {
+        int ph = h + 1 - kh; if (ph < 0 || (ph & 1)) continue; int p = ph >> 1; if (p >= P) continue;
+        for (int kw = 0; kw < 3; ++kw) {
+            int pw = w + 1 - kw; if (pw < 0 || (pw & 1)) continue; int q = pw >> 1; if (q >= Q) continue;
+            long o = ((n * P + p) * Q + q) * C4 + c4;
+            uchar4 a = reinterpret_cast<const uchar4*>(amax)[o];
+            float4 g = reinterpret_cast<const float4*>(dy)[o];
+            int k = kh * 3 + kw;
+            if (a.x == k) acc.x += g.x; if (a.y == k) acc.y += g.y; if (a.z == k) acc.z += g.z; if (a.w == k) acc.w += g.w;
+        }
+    }
+    reinterpret_cast<float4*>(dx)[e] = acc;
+}
+
+// ------------------------------------------------------------------ encoder_size resize on the final map (readme.md:118-121)
+// adaptive average pool H x W -> P x Q (torch bin edges floor(i*H/P) .. ceil((i+1)*H/P))
+__global__ void adaptive_avgpool_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C, int P, int Q, long total, int backward) {
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    if (!backward) {      // e over outputs (n,p,q,c)
+        int c = (int)(e % C); long t = e / C; int q = (int)(t % Q); t /= Q; int p = (int)(t % P); long n = t / P;
+        int h0 = (p * H) / P, h1 = ((p + 1) * H + P - 1) / P, w0 = (q * W) / Q, w1 = ((q + 1) * W + Q - 1) / Q;
+        float s = 0.f;
+        for (int h = h0; h < h1; ++h) for (int w = w0; w < w1; ++w) s += x[((n * H + h) * W + w) * C + c];
+        y[e] = s / (float)((h1 - h0) * (w1 - w0));
+    } else {              // e over inputs (n,h,w,c): x = dy (n,P,Q,c), y = dx
+        int c = (int)(e % C); long t = e / C; int w = (int)(t % W); t /= W; int h = (int)(t % H); long n = t / H;
+        float s = 0.f;
+        for (int p = 0; p < P; ++p) {
+            int h0 = (p * H) / P, h1 = ((p + 1) * H + P - 1) / P; if (h < h0 || h >= h1) continue;
+            for (int q = 0; q < Q; ++q) {
+                int w0 = (q * W) / Q, w1 = ((q + 1) * W + Q - 1) / Q; if (w < w0 || w >= w1) continue;
+                s += x[((n * P + p) * Q + q) * C + c] / (float)((h1 - h0) * (w1 - w0));
+            }
+        }
+        y[e] = s;
+    }
+}
+// bilinear resize, align_corners=False (nn.Upsample): src = (dst + 0.5) * scale - 0.5, clamped at 0
+__device__ __forceinline__ void bilinear_src(int o, int in, int out, int& i0, int& i1, float& l1) {
+    float s = ((float)o + 0.5f) * ((float)in / (float)out) - 0.5f;
+    if (s < 0.f) s = 0.f;
+    i0 = (int)s; i1 = i0 + (i0 < in - 1 ? 1 : 0); l1 = s - (float)i0;
+}
+__global__ void bilinear_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C, int P, int Q, long total) {
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    int c = (int)(e % C); long t = e / C; int q = (int)(t % Q); t /= Q; int p = (int)(t % P); long n = t / P;
+    int h0, h1, w0, w1; float lh, lw;
+    bilinear_src(p, H, P, h0, h1, lh); bilinear_src(q, W, Q, w0, w1, lw);
+    const float* b = x + n * H * W * C + c;
+    float v00 = b[((long)h0 * W + w0) * C], v01 = b[((long)h0 * W + w1) * C], v10 = b[((long)h1 * W + w0) * C], v11 = b[((long)h1 * W + w1) * C];
+    y[e] = (1.f - lh) * ((1.f - lw) * v00 + lw * v01) + lh * ((1.f - lw) * v10 + lw * v11);
+}
+__global__ void bilinear_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int C, int P, int Q, long total) {
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;     // over inputs (n,h,w,c); gather over all outputs touching it
+    if (e >= total) return;
+    int c = (int)(e % C); long t = e / C; int w = (int)(t % W); t /= W; int h = (int)(t % H); long n = t / H;
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) {
+        int h0, h1; float lh; bilinear_src(p, H, P, h0, h1, lh);
+        float wh = (h0 == h ? 1.f - lh : 0.f) + (h1 == h ? lh : 0.f);
+        if (wh == 0.f) continue;
+        for (int q = 0; q < Q; ++q) {
+            int w0, w1; float lw; bilinear_src(q, W, Q, w0, w1, lw);
+            float ww = (w0 == w ? 1.f - lw : 0.f) + (w1 == w ? lw : 0.f);
+            if (ww != 0.f) s += wh * ww * dy[((n * P + p) * Q + q) * C + c];
+        }
+    }
+    dx[e] = s;
+}
+
+}  // namespace sat
+
+using namespace sat;
+
+static int conv_geom(const sat_conv_geom* g, ConvGeom& o) {
+    SAT_REQUIRE(g, "conv: null geometry");
+    o.N = g->N; o.H = g->H; o.W = g->W; o.C = g->C; o.K = g->K; o.R = g->R; o.S = g->S; o.stride = g->stride; o.pad = g->pad;
+    SAT_REQUIRE(o.N > 0 && o.H > 0 && o.W > 0 && o.C > 0 && o.K > 0 && o.R > 0 && o.S > 0 && o.stride > 0 && o.pad >= 0, "conv: bad geometry");
+    o.P = (o.H + 2 * o.pad - o.R) / o.stride + 1; o.Q = (o.W + 2 * o.pad - o.S) / o.stride + 1;
+    SAT_REQUIRE(o.P > 0 && o.Q > 0, "conv: empty output");
+    SAT_REQUIRE(o.C % 4 == 0 && o.K % 4 == 0, "conv: C=%d and K=%d must be multiples of 4 (pad the stem to 4 channels)", o.C, o.K);
+    return SAT_OK;
+}
+
+extern "C" {
+
+int sat_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, const sat_conv_geom* geom, void* stream) {
+    ConvGeom g; SAT_TRY(conv_geom(geom, g));
+    if (!x || !w || !y) return fail(SAT_EINVAL, "conv2d_fwd: null pointer");
+    GemmArgs a;
+    a.M = g.N * g.P * g.Q; a.N = g.K; a.K = g.R * g.S * g.C;
+    a.B = w; a.ldb = a.K; a.bmode = B_ROW; a.C = y; a.ldc = g.K; a.g = g;
+    if (g.R == 1 && g.S == 1 && g.stride == 1 && g.pad == 0) { a.A = x; a.lda = g.C; a.amode = A_ROW; }   // 1x1: a plain GEMM over pixels
+    else { a.A = x; a.amode = A_CONV_FWD; }
+    if (bias) { a.epi = EPI_BIAS; a.bias = bias; }
+    return launch_gemm(a, (hipStream_t)stream);
+}
+
+int sat_conv2d_dgrad(const float* dy, const float* w, float* dx, const sat_conv_geom* geom, int accumulate, void* stream) {
+    ConvGeom g; SAT_TRY(conv_geom(geom, g));
+    if (!dy || !w || !dx) return fail(SAT_EINVAL, "conv2d_dgrad: null pointer");
+    GemmArgs a;
+    a.accumulate = accumulate; a.C = dx; a.ldc = g.C; a.g = g;
+    if (g.R == 1 && g.S == 1 && g.stride == 1 && g.pad == 0) {
+        a.M = g.N * g.H * g.W; a.N = g.C; a.K = g.K; a.A = dy; a.lda = g.K; a.amode = A_ROW; a.B = w; a.ldb = g.C; a.bmode = B_KMAJOR;
+    } else {
+        a.M = g.N * g.H * g.W; a.N = g.C; a.K = g.R * g.S * g.K; a.A = dy; a.amode = A_CONV_DGRAD; a.B = w; a.bmode = B_CONV_DGRAD_W;
+    }
+    return launch_gemm(a, (hipStream_t)stream);
+}
+
+int sat_conv2d_wgrad(const float* dy, const float* x, float* dw, const sat_conv_geom* geom, float* slab, int64_t slab_elems, void* stream) {
+    ConvGeom g; SAT_TRY(conv_geom(geom, g));
+    if (!dy || !x || !dw) return fail(SAT_EINVAL, "conv2d_wgrad: null pointer");
+    GemmArgs a;
+    a.M = g.K; a.N = g.R * g.S * g.C; a.K = g.N * g.P * g.Q;
+    a.A = dy; a.lda = g.K; a.amode = A_KMAJOR; a.C = dw; a.ldc = a.N; a.g = g; a.slab = slab; a.slab_elems = slab_elems;
+    if (g.R == 1 && g.S == 1 && g.stride == 1 && g.pad == 0) { a.B = x; a.ldb = g.C; a.bmode = B_KMAJOR; }
+    else { a.B = x; a.bmode = B_CONV_WGRAD; }
+    return launch_gemm(a, (hipStream_t)stream);
+}
+
+size_t sat_conv2d_wgrad_slab_bytes(const sat_conv_geom* geom) {
+    ConvGeom g; if (conv_geom(geom, g) != SAT_OK) return 0;
+    return gemm_slab_bytes(g.K, g.R * g.S * g.C, g.N * g.P * g.Q);
+}
+
+int sat_image_normalize_nhwc4(const float* img_nchw, float* out_nhwc4, int32_t N, int32_t H, int32_t W, const float* mean3_host, const float* std3_host, void* stream) {
+    if (!img_nchw || !out_nhwc4 || !mean3_host || !std3_host) return fail(SAT_EINVAL, "image_normalize: null pointer");
+    long total = (long)N * H * W;
+    hipLaunchKernelGGL(normalize_nhwc4_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, img_nchw, out_nhwc4, H, W, total,
+                       mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2]);
+    return launch_ok("normalize_nhwc4");
+}
+
+int sat_pad_channels_3to4(const float* src, float* dst, int64_t pixels, int32_t inverse, void* stream) {
+    if (!src || !dst) return fail(SAT_EINVAL, "pad_channels: null pointer");
+    if (inverse) hipLaunchKernelGGL(unpad_c4_to_c3_kernel, dim3(cdiv(pixels, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, (long)pixels);
+    else hipLaunchKernelGGL(pad_c3_to_c4_kernel, dim3(cdiv(pixels, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, (long)pixels);
+    return launch_ok("pad_channels");
+}
+
+static void bn_grid(long rows, int C, int& TW, long& rows_per, int& nparts) {
+    int C4 = C / 4;
+    TW = C4 < 64 ? C4 : 64;
+    while (256 % TW) --TW;                      // TW must divide 256 (C4 = 2^k * odd: fall back to a divisor)
+    rows_per = 512;
+    if (rows / rows_per > 2048) rows_per = (rows + 2047) / 2048;
+    nparts = cdiv(rows, rows_per);
+}
+
+size_t sat_bn_scratch_bytes(int64_t rows, int32_t C) {
+    if (rows <= 0 || C <= 0 || C % 4) return 0;
+    int TW, nparts; long rp; bn_grid(rows, C, TW, rp, nparts);
+    return (size_t)2 * nparts * C * sizeof(float);
+}
+
+int sat_bn_train_fwd(const float* x, int64_t rows, int32_t C, const float* gamma, const float* beta, float eps, float momentum,
+                     float* running_mean, float* running_var, float* save_mean, float* save_invstd, const float* residual, int32_t relu,
+                     float* y, float* scratch, void* stream) {
+    if (!x || !gamma || !beta || !save_mean || !save_invstd || !y || !scratch) return fail(SAT_EINVAL, "bn_train_fwd: null pointer");
+    SAT_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, "bn_train_fwd: rows=%ld C=%d (C must be a multiple of 4)", (long)rows, C);
+    hipStream_t st = (hipStream_t)stream;
+    int TW, nparts; long rp; bn_grid(rows, C, TW, rp, nparts);
+    float* p0 = scratch; float* p1 = scratch + (long)nparts * C;
+    hipLaunchKernelGGL(bn_colstats_kernel<0>, dim3(cdiv(C / 4, TW), nparts), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, 0, (long)rows, C, TW, rp, p0, p1);
+    SAT_TRY(launch_ok("bn_colstats<0>"));
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, p0, p1, nparts, C, (long)rows, eps, momentum, save_mean, save_invstd, running_mean, running_var);
+    SAT_TRY(launch_ok("bn_fwd_finalize"));
+    long total4 = rows * (C / 4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta, residual, relu, y, total4, C / 4, -1.0f);
+    return launch_ok("bn_apply");
+}
+
+int sat_bn_eval_fwd(const float* x, int64_t rows, int32_t C, const float* running_mean, const float* running_var, float eps,
+                    const float* gamma, const float* beta, const float* residual, int32_t relu, float* y, void* stream) {
+    if (!x || !running_mean || !running_var || !gamma || !beta || !y) return fail(SAT_EINVAL, "bn_eval_fwd: null pointer");
+    SAT_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && eps >= 0.f, "bn_eval_fwd: bad shape");
+    long total4 = rows * (C / 4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, (hipStream_t)stream, x, running_mean, running_var, gamma, beta, residual, relu, y, total4, C / 4, eps);
+    return launch_ok("bn_apply(eval)");
+}
+
+int sat_bn_train_bwd(const float* dy, const float* x, const float* y, int64_t rows, int32_t C, const float* save_mean, const float* save_invstd,
+                     const float* gamma, int32_t relu, float* dx, float* dgamma, float* dbeta, float* dres, int32_t dres_accumulate,
+                     float* scratch, void* stream) {
+    if (!dy || !x || !save_mean || !save_invstd || !gamma || !dx || !dgamma || !dbeta || !scratch) return fail(SAT_EINVAL, "bn_train_bwd: null pointer");
+    if (relu && !y) return fail(SAT_EINVAL, "bn_train_bwd: relu mask needs the forward output");
+    SAT_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, "bn_train_bwd: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    int TW, nparts; long rp; bn_grid(rows, C, TW, rp, nparts);
+    float* p0 = scratch; float* p1 = scratch + (long)nparts * C;
+    hipLaunchKernelGGL(bn_colstats_kernel<1>, dim3(cdiv(C / 4, TW), nparts), dim3(256), 0, st, x, dy, y, save_mean, save_invstd, relu, (long)rows, C, TW, rp, p0, p1);
+    SAT_TRY(launch_ok("bn_colstats<1>"));
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, p0, p1, nparts, C, dbeta, dgamma);
+    SAT_TRY(launch_ok("bn_bwd_finalize"));
+    long total4 = rows * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, st, x, dy, y, save_mean, save_invstd, gamma, dbeta, dgamma, relu,
+                       1.0f / (float)rows, dx, dres, dres_accumulate, total4, C / 4);
+    return launch_ok("bn_bwd_apply");
+}
+
+int sat_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* argmax, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+    if (!x || !y || !argmax) return fail(SAT_EINVAL, "maxpool_fwd: null pointer");
+    SAT_REQUIRE(C % 4 == 0, "maxpool: C must be a multiple of 4");
+    int P = (H + 2 - 3) / 2 + 1, Q = (W + 2 - 3) / 2 + 1;
+    long total4 = (long)N * P * Q * (C / 4);
+    hipLaunchKernelGGL(maxpool3x3s2_fwd_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, (hipStream_t)stream, x, y, argmax, H, W, C / 4, P, Q, total4);
+    return launch_ok("maxpool_fwd");
+}
+int sat_maxpool3x3s2_bwd(const float* dy, const uint8_t* argmax, float* dx, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+    if (!dy || !dx || !argmax) return fail(SAT_EINVAL, "maxpool_bwd: null pointer");
+    SAT_REQUIRE(C % 4 == 0, "maxpool: C must be a multiple of 4");
+    int P = (H + 2 - 3) / 2 + 1, Q = (W + 2 - 3) / 2 + 1;
+    long total4 = (long)N * H * W * (C / 4);
+    hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, (hipStream_t)stream, dy, argmax, dx, H, W, C / 4, P, Q, total4);
+    return launch_ok("maxpool_bwd");
+}
+
+int sat_resize_fwd(const float* x, float* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t P, int32_t Q, void* stream) {
+    if (!x || !y) return fail(SAT_EINVAL, "resize_fwd: null pointer");
+    long total = (long)N * P * Q * C;
+    if (P <= H) hipLaunchKernelGGL(adaptive_avgpool_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C, P, Q, total, 0);
+    else hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C, P, Q, total);
+    return launch_ok("resize_fwd");
+}
+int sat_resize_bwd(const float* dy, float* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t P, int32_t Q, void* stream) {
+    if (!dy || !dx) return fail(SAT_EINVAL, "resize_bwd: null pointer");
+    long total = (long)N * H * W * C;
+    if (P <= H) hipLaunchKernelGGL(adaptive_avgpool_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, H, W, C, P, Q, total, 1);
+    else hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, H, W, C, P, Q, total);
+    return launch_ok("resize_bwd");
+}
+
+}  // extern "C"

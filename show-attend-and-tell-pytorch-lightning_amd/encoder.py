@@ -1,0 +1,344 @@
+"""Encoder host side: the reference's ``get_encoder`` (model.py:16-63) for the ResNet family with the
+layers executed by ``libsat_hip.so`` (NHWC activations, KRSC filters, implicit-GEMM convolutions on MFMA).
+
+The returned module is an ``nn.Sequential`` whose children sit at the same indices as the reference's
+(0 Normalize, 1 conv1, 2 bn1, 3 relu, 4 maxpool, 5-8 layer1-4, 9 the 1x1 projection), so state-dict keys
+match.  The children only hold parameters; ``forward`` runs the HIP pipeline and returns the
+annotations as a (B, D, h, w) tensor in channels-last memory, i.e. (B, h*w, D) row-major underneath.
+"""
+import ctypes as C
+
+import torch
+from torch import nn
+
+from . import _lib as L
+
+#: arch -> (block kind, blocks per stage, width per group); torchvision's table
+RESNETS = {
+    "resnet18": ("basic", (2, 2, 2, 2), 64), "resnet34": ("basic", (3, 4, 6, 3), 64),
+    "resnet50": ("bottleneck", (3, 4, 6, 3), 64), "resnet101": ("bottleneck", (3, 4, 23, 3), 64),
+    "resnet152": ("bottleneck", (3, 8, 36, 3), 64),
+    "wide_resnet50_2": ("bottleneck", (3, 4, 6, 3), 128), "wide_resnet101_2": ("bottleneck", (3, 4, 23, 3), 128),
+}
+
+
+class Normalize(nn.Module):
+    """Holder of the Normalize(mean, std) constants (model.py:59); the arithmetic is fused into the NHWC
+    conversion kernel.  Unlike the reference's inplace=True it does not mutate the caller's batch."""
+
+    def __init__(self, mean, std, inplace=True):
+        super().__init__()
+        self.mean, self.std, self.inplace = [float(v) for v in mean], [float(v) for v in std], inplace
+
+
+class Block(nn.Module):
+    """Parameter holder of one torchvision BasicBlock / Bottleneck (stride on the 3x3)."""
+
+    def __init__(self, kind, cin, planes, stride, wpg):
+        super().__init__()
+        self.kind, self.stride = kind, stride
+        if kind == "basic":
+            self.cout = planes
+            self.conv1 = nn.Conv2d(cin, planes, 3, stride, 1, bias=False); self.bn1 = nn.BatchNorm2d(planes)
+            self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False); self.bn2 = nn.BatchNorm2d(planes)
+        else:
+            mid = int(planes * (wpg / 64.0)); self.cout = planes * 4
+            self.conv1 = nn.Conv2d(cin, mid, 1, 1, 0, bias=False); self.bn1 = nn.BatchNorm2d(mid)
+            self.conv2 = nn.Conv2d(mid, mid, 3, stride, 1, bias=False); self.bn2 = nn.BatchNorm2d(mid)
+            self.conv3 = nn.Conv2d(mid, self.cout, 1, 1, 0, bias=False); self.bn3 = nn.BatchNorm2d(self.cout)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = None
+        if stride != 1 or cin != self.cout:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, self.cout, 1, stride, 0, bias=False), nn.BatchNorm2d(self.cout))
+
+
+def _channels_last_(module):
+    for mod in module.modules():
+        if isinstance(mod, nn.Conv2d):
+            mod.weight.data = mod.weight.data.contiguous(memory_format=torch.channels_last)
+
+
+# ----------------------------------------------------------------------------- raw layer calls
+def _geom(N, H, W, Cc, K, R, S, stride, pad):
+    return L.ConvGeom(N=N, H=H, W=W, C=Cc, K=K, R=R, S=S, stride=stride, pad=pad)
+
+
+def _krsc(w):
+    """(K,C,R,S) parameter -> tensor whose memory is K,R,S,C."""
+    if w.dim() == 4 and not w.is_contiguous(memory_format=torch.channels_last):
+        w = w.contiguous(memory_format=torch.channels_last)
+    return w
+
+
+def _out_hw(H, W, R, S, stride, pad):
+    return (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+
+
+def conv_fwd(x, w, stride, pad, bias=None):
+    N, H, W, Cc = x.shape
+    K, _, R, S = w.shape
+    P, Q = _out_hw(H, W, R, S, stride, pad)
+    y = torch.empty(N, P, Q, K, dtype=torch.float32, device=x.device)
+    g = _geom(N, H, W, Cc, K, R, S, stride, pad)
+    L.check(L.lib().sat_conv2d_fwd(L.ptr(x), L.ptr(_krsc(w)), L.ptr(bias), L.ptr(y), C.byref(g), L.stream_ptr()), "sat_conv2d_fwd")
+    return y
+
+
+def conv_dgrad(dy, w, x_shape, stride, pad, out=None, accumulate=False):
+    N, H, W, Cc = x_shape
+    K, _, R, S = w.shape
+    dx = out if out is not None else torch.empty(N, H, W, Cc, dtype=torch.float32, device=dy.device)
+    g = _geom(N, H, W, Cc, K, R, S, stride, pad)
+    L.check(L.lib().sat_conv2d_dgrad(L.ptr(dy), L.ptr(_krsc(w)), L.ptr(dx), C.byref(g), int(accumulate), L.stream_ptr()), "sat_conv2d_dgrad")
+    return dx
+
+
+_slabs = {}
+
+
+def _slab(device, nbytes):
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    cur = _slabs.get(key)
+    if cur is None or cur.numel() * 4 < nbytes:
+        cur = torch.empty(max(nbytes // 4, 1 << 20), dtype=torch.float32, device=device)
+        _slabs[key] = cur
+    return cur
+
+
+def conv_wgrad(dy, x, w, stride, pad):
+    N, H, W, Cc = x.shape
+    K, _, R, S = w.shape
+    g = _geom(N, H, W, Cc, K, R, S, stride, pad)
+    lib = L.lib()
+    nbytes = lib.sat_conv2d_wgrad_slab_bytes(C.byref(g))
+    slab = _slab(x.device, nbytes) if nbytes else None
+    dw = torch.empty(K, R, S, Cc, dtype=torch.float32, device=x.device)       # KRSC
+    L.check(lib.sat_conv2d_wgrad(L.ptr(dy), L.ptr(x), L.ptr(dw), C.byref(g), L.ptr(slab), 0 if slab is None else slab.numel(),
+                                 L.stream_ptr()), "sat_conv2d_wgrad")
+    return dw.permute(0, 3, 1, 2)                                             # (K,C,R,S) view, channels_last memory
+
+
+def bn_fwd(x, bn, residual=None, relu=True, training=True):
+    lib = L.lib()
+    Cc = x.shape[-1]; rows = x.numel() // Cc
+    y = torch.empty_like(x)
+    if training:
+        mean = torch.empty(Cc, dtype=torch.float32, device=x.device); invstd = torch.empty_like(mean)
+        scratch = torch.empty(lib.sat_bn_scratch_bytes(rows, Cc) // 4, dtype=torch.float32, device=x.device)
+        mom = 0.1 if bn.momentum is None else float(bn.momentum)
+        L.check(lib.sat_bn_train_fwd(L.ptr(x), rows, Cc, L.ptr(bn.weight), L.ptr(bn.bias), float(bn.eps), mom, L.ptr(bn.running_mean),
+                                     L.ptr(bn.running_var), L.ptr(mean), L.ptr(invstd), L.ptr(residual), int(relu), L.ptr(y), L.ptr(scratch),
+                                     L.stream_ptr()), "sat_bn_train_fwd")
+        bn.num_batches_tracked += 1
+        return y, (mean, invstd)
+    L.check(lib.sat_bn_eval_fwd(L.ptr(x), rows, Cc, L.ptr(bn.running_mean), L.ptr(bn.running_var), float(bn.eps), L.ptr(bn.weight),
+                                L.ptr(bn.bias), L.ptr(residual), int(relu), L.ptr(y), L.stream_ptr()), "sat_bn_eval_fwd")
+    return y, None
+
+
+def bn_bwd(dy, x, y, stats, bn, relu, dres=None, dres_accumulate=False):
+    lib = L.lib()
+    Cc = x.shape[-1]; rows = x.numel() // Cc
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device); dbeta = torch.empty_like(dgamma)
+    scratch = torch.empty(lib.sat_bn_scratch_bytes(rows, Cc) // 4, dtype=torch.float32, device=x.device)
+    L.check(lib.sat_bn_train_bwd(L.ptr(dy), L.ptr(x), L.ptr(y), rows, Cc, L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(bn.weight), int(relu),
+                                 L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dres), int(dres_accumulate), L.ptr(scratch), L.stream_ptr()),
+            "sat_bn_train_bwd")
+    return dx, dgamma, dbeta
+
+
+def colsum(x2d):
+    rows, cols = x2d.shape
+    out = torch.empty(cols, dtype=torch.float32, device=x2d.device)
+    scratch = torch.empty(((rows + 255) // 256) * cols, dtype=torch.float32, device=x2d.device)
+    L.check(L.lib().sat_colsum(L.ptr(x2d), x2d.stride(0), rows, cols, L.ptr(out), L.ptr(scratch), L.stream_ptr()), "sat_colsum")
+    return out
+
+
+# ----------------------------------------------------------------------------- whole-network forward / backward
+class _Rec:
+    __slots__ = ("kind", "blk", "x", "c1", "a1", "s1", "c2", "a2", "s2", "c3", "s3", "cd", "sd", "idn", "out")
+
+
+def _block_fwd(blk, x, training):
+    r = _Rec(); r.kind, r.blk, r.x = blk.kind, blk, x
+    r.cd = r.sd = None
+    if blk.downsample is not None:
+        r.cd = conv_fwd(x, blk.downsample[0].weight, blk.stride, 0)
+        r.idn, r.sd = bn_fwd(r.cd, blk.downsample[1], None, False, training)
+    else:
+        r.idn = x
+    if blk.kind == "basic":
+        r.c1 = conv_fwd(x, blk.conv1.weight, blk.stride, 1); r.a1, r.s1 = bn_fwd(r.c1, blk.bn1, None, True, training)
+        r.c2 = conv_fwd(r.a1, blk.conv2.weight, 1, 1)
+        r.out, r.s2 = bn_fwd(r.c2, blk.bn2, r.idn, True, training)
+    else:
+        r.c1 = conv_fwd(x, blk.conv1.weight, 1, 0); r.a1, r.s1 = bn_fwd(r.c1, blk.bn1, None, True, training)
+        r.c2 = conv_fwd(r.a1, blk.conv2.weight, blk.stride, 1); r.a2, r.s2 = bn_fwd(r.c2, blk.bn2, None, True, training)
+        r.c3 = conv_fwd(r.a2, blk.conv3.weight, 1, 0)
+        r.out, r.s3 = bn_fwd(r.c3, blk.bn3, r.idn, True, training)
+    return r
+
+
+def _block_bwd(r, dout, grads, need_dx):
+    blk = r.blk
+    g = torch.empty_like(r.out)                      # gradient of the residual branch (= dout masked by the final ReLU)
+    if blk.kind == "basic":
+        dx2, grads[blk.bn2.weight], grads[blk.bn2.bias] = bn_bwd(dout, r.c2, r.out, r.s2, blk.bn2, True, dres=g)
+        grads[blk.conv2.weight] = conv_wgrad(dx2, r.a1, blk.conv2.weight, 1, 1)
+        da1 = conv_dgrad(dx2, blk.conv2.weight, r.a1.shape, 1, 1)
+        first_w, first_stride, first_pad = blk.conv1.weight, blk.stride, 1
+    else:
+        dx3, grads[blk.bn3.weight], grads[blk.bn3.bias] = bn_bwd(dout, r.c3, r.out, r.s3, blk.bn3, True, dres=g)
+        grads[blk.conv3.weight] = conv_wgrad(dx3, r.a2, blk.conv3.weight, 1, 0)
+        da2 = conv_dgrad(dx3, blk.conv3.weight, r.a2.shape, 1, 0)
+        dx2, grads[blk.bn2.weight], grads[blk.bn2.bias] = bn_bwd(da2, r.c2, r.a2, r.s2, blk.bn2, True)
+        grads[blk.conv2.weight] = conv_wgrad(dx2, r.a1, blk.conv2.weight, blk.stride, 1)
+        da1 = conv_dgrad(dx2, blk.conv2.weight, r.a1.shape, blk.stride, 1)
+        first_w, first_stride, first_pad = blk.conv1.weight, 1, 0
+    dx1, grads[blk.bn1.weight], grads[blk.bn1.bias] = bn_bwd(da1, r.c1, r.a1, r.s1, blk.bn1, True)
+    grads[first_w] = conv_wgrad(dx1, r.x, first_w, first_stride, first_pad)
+    if blk.downsample is not None:
+        dxd, grads[blk.downsample[1].weight], grads[blk.downsample[1].bias] = bn_bwd(g, r.cd, None, r.sd, blk.downsample[1], False)
+        grads[blk.downsample[0].weight] = conv_wgrad(dxd, r.x, blk.downsample[0].weight, blk.stride, 0)
+        if not need_dx:
+            return None
+        dx = conv_dgrad(dxd, blk.downsample[0].weight, r.x.shape, blk.stride, 0)
+        return conv_dgrad(dx1, first_w, r.x.shape, first_stride, first_pad, out=dx, accumulate=True)
+    if not need_dx:
+        return None
+    return conv_dgrad(dx1, first_w, r.x.shape, first_stride, first_pad, out=g, accumulate=True)   # identity path + conv path
+
+
+class EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, enc, *params):
+        lib = L.lib()
+        L.require_gpu(img, *params)
+        if img.dim() != 4 or img.shape[1] != 3 or img.dtype != torch.float32:
+            raise ValueError("encoder input must be (B,3,H,W) fp32 in [0,1]")
+        img = img.contiguous()
+        training = enc.training
+        N, _, H, W = img.shape
+        st = L.stream_ptr()
+        t = {}
+        x0 = torch.empty(N, H, W, 4, dtype=torch.float32, device=img.device)
+        mean = (C.c_float * 3)(*enc[0].mean); std = (C.c_float * 3)(*enc[0].std)
+        L.check(lib.sat_image_normalize_nhwc4(L.ptr(img), L.ptr(x0), N, H, W, mean, std, st), "sat_image_normalize_nhwc4")
+        conv1 = enc[1]
+        w3 = _krsc(conv1.weight)                                                   # (64,3,7,7), memory 64,7,7,3
+        w4 = torch.empty(conv1.out_channels, 4, 7, 7, dtype=torch.float32, device=img.device).contiguous(memory_format=torch.channels_last)
+        L.check(lib.sat_pad_channels_3to4(L.ptr(w3), L.ptr(w4), conv1.out_channels * 49, 0, st), "sat_pad_channels_3to4")
+        t["x0"], t["w4"] = x0, w4
+        t["c0"] = conv_fwd(x0, w4, 2, 3)
+        t["a0"], t["s0"] = bn_fwd(t["c0"], enc[2], None, True, training)
+        Nn, Hh, Ww, Cc = t["a0"].shape
+        P, Q = (Hh + 2 - 3) // 2 + 1, (Ww + 2 - 3) // 2 + 1
+        t["p0"] = torch.empty(Nn, P, Q, Cc, dtype=torch.float32, device=img.device)
+        t["amax"] = torch.empty(Nn, P, Q, Cc, dtype=torch.uint8, device=img.device)
+        L.check(lib.sat_maxpool3x3s2_fwd(L.ptr(t["a0"]), L.ptr(t["p0"]), L.ptr(t["amax"]), Nn, Hh, Ww, Cc, st), "sat_maxpool3x3s2_fwd")
+        x = t["p0"]
+        recs = []
+        for li in (5, 6, 7, 8):
+            for blk in enc[li]:
+                r = _block_fwd(blk, x, training)
+                recs.append(r); x = r.out
+        t["trunk"] = x
+        if enc.proj is not None:
+            x = conv_fwd(x, enc.proj.weight, 1, 0, enc.proj.bias)
+        t["proj_out"] = x
+        if enc.out_size is not None and enc.out_size != x.shape[1]:
+            Nn, Hh, Ww, Cc = x.shape
+            y = torch.empty(Nn, enc.out_size, enc.out_size, Cc, dtype=torch.float32, device=img.device)
+            L.check(lib.sat_resize_fwd(L.ptr(x), L.ptr(y), Nn, Hh, Ww, Cc, enc.out_size, enc.out_size, st), "sat_resize_fwd")
+            x = y
+        ctx.t, ctx.recs, ctx.enc = t, recs, enc
+        ctx.params = params
+        return x.permute(0, 3, 1, 2)            # (B, D, h, w) view over NHWC memory
+
+    @staticmethod
+    def backward(ctx, dann):
+        lib = L.lib()
+        enc, t, recs = ctx.enc, ctx.t, ctx.recs
+        st = L.stream_ptr()
+        grads = {}
+        d = dann.permute(0, 2, 3, 1).contiguous()                                 # NHWC (no copy when it already is)
+        if enc.out_size is not None and enc.out_size != t["proj_out"].shape[1]:
+            Nn, Hh, Ww, Cc = t["proj_out"].shape
+            dx = torch.empty_like(t["proj_out"])
+            L.check(lib.sat_resize_bwd(L.ptr(d), L.ptr(dx), Nn, Hh, Ww, Cc, enc.out_size, enc.out_size, st), "sat_resize_bwd")
+            d = dx
+        if enc.proj is not None:
+            grads[enc.proj.weight] = conv_wgrad(d, t["trunk"], enc.proj.weight, 1, 0)
+            grads[enc.proj.bias] = colsum(d.reshape(-1, d.shape[-1]))
+            d = conv_dgrad(d, enc.proj.weight, t["trunk"].shape, 1, 0) if enc.trunk_trainable else None
+        if enc.trunk_trainable:
+            for r in reversed(recs):
+                d = _block_bwd(r, d, grads, True)
+            Nn, Hh, Ww, Cc = t["a0"].shape
+            da0 = torch.empty_like(t["a0"])
+            L.check(lib.sat_maxpool3x3s2_bwd(L.ptr(d), L.ptr(t["amax"]), L.ptr(da0), Nn, Hh, Ww, Cc, st), "sat_maxpool3x3s2_bwd")
+            dc0, grads[enc[2].weight], grads[enc[2].bias] = bn_bwd(da0, t["c0"], t["a0"], t["s0"], enc[2], True)
+            dw4 = conv_wgrad(dc0, t["x0"], t["w4"], 2, 3)                          # (64,4,7,7) view of KRS4 memory
+            dw3 = torch.empty_like(_krsc(enc[1].weight))
+            L.check(lib.sat_pad_channels_3to4(L.ptr(dw4), L.ptr(dw3), enc[1].out_channels * 49, 1, st), "sat_pad_channels_3to4")
+            grads[enc[1].weight] = dw3
+        ctx.t = ctx.recs = None
+        return (None, None, *[grads.get(p) if p.requires_grad else None for p in ctx.params])
+
+
+class HipEncoder(nn.Sequential):
+    def __init__(self, norm, conv1, bn1, layers, proj, out_size):
+        mods = [norm, conv1, bn1, nn.ReLU(inplace=True), nn.MaxPool2d(3, 2, 1), *layers]
+        if proj is not None:
+            mods.append(proj)
+        super().__init__(*mods)
+        self.__dict__["proj"] = proj              # not registered twice: index 9 already owns it
+        self.out_size = out_size
+
+    @property
+    def trunk_trainable(self):
+        return any(p.requires_grad for p in self[1].parameters())
+
+    def forward(self, img):
+        params = list(self.parameters())
+        return EncoderFn.apply(img, self, *params)
+
+
+def get_encoder(args):
+    """Reference get_encoder (model.py:16-63) for resnet / wide_resnet archs; adds the README's
+    ``encoder_size`` resize (readme.md:118-121) when ``args.encoder_size`` is set."""
+    arch = args.encoder_arch
+    if arch not in RESNETS:
+        raise ValueError("Encoder not supported : {}".format(arch))
+    if getattr(args, "pretrained", False):
+        raise RuntimeError("pretrained=True needs a download; load weights with load_state_dict instead")
+    kind, depths, wpg = RESNETS[arch]
+    conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False); bn1 = nn.BatchNorm2d(64)
+    layers, cin = [], 64
+    for si, (planes, nblk) in enumerate(zip((64, 128, 256, 512), depths)):
+        blocks = []
+        for bi in range(nblk):
+            blk = Block(kind, cin, planes, 2 if (si > 0 and bi == 0) else 1, wpg)
+            cin = blk.cout; blocks.append(blk)
+        layers.append(nn.Sequential(*blocks))
+    for mod in [conv1, *layers]:
+        for sub in mod.modules():
+            if isinstance(sub, nn.Conv2d):
+                nn.init.kaiming_normal_(sub.weight, mode="fan_out", nonlinearity="relu")
+    final_dim = cin
+    inp = int(args.input_size)
+    s = (inp + 2 * 3 - 7) // 2 + 1; s = (s + 2 - 3) // 2 + 1
+    for _ in range(3):
+        s = (s + 2 - 3) // 2 + 1
+    final_size = s
+    proj = None
+    if getattr(args, "encoder_dim", None) is not None and args.encoder_dim != final_dim:
+        proj = nn.Conv2d(final_dim, args.encoder_dim, kernel_size=1, stride=1, bias=True)      # model.py:53
+    else:
+        args.encoder_dim = final_dim
+    es = getattr(args, "encoder_size", None)
+    enc = HipEncoder(Normalize(args.mean, args.std, inplace=True), conv1, bn1, layers, proj, es if (es is not None and es != final_size) else None)
+    _channels_last_(enc)
+    return enc

@@ -1,0 +1,174 @@
+"""GPU parity of the encoder layers (C ABI: sat_conv2d_*, sat_bn_*, sat_maxpool*, sat_resize_*) against torch
+fp32 on the CPU, and of the whole ResNet-18 get_encoder against the oracle's build_encoder with the same weights.
+Encoder parity is unpinned at the reference level (torchvision is absent): the oracle is the
+reference's own get_encoder logic running over the repo's ResNet definition (tests/golden/g_encoder.npz)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, tol, what=""):
+    a = a.detach().cpu().double(); b = b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(1.0, float(b.abs().max()))
+    err = float((a - b).abs().max())
+    assert err <= tol * scale, "%s: max|d|=%.3e (scale %.3g)" % (what, err, scale)
+
+
+@pytest.fixture(scope="module")
+def E():
+    import sat_amd  # noqa: F401
+    from sat_amd import encoder
+    return encoder
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2)
+
+
+CONVS = [  # N,H,W,C,K,R,stride,pad
+    (2, 9, 9, 8, 12, 3, 1, 1), (2, 10, 11, 8, 16, 3, 2, 1), (3, 8, 8, 16, 8, 1, 1, 0), (2, 9, 9, 8, 12, 1, 2, 0),
+    (2, 20, 20, 4, 8, 7, 2, 3), (1, 16, 16, 64, 64, 3, 1, 1), (4, 14, 14, 32, 128, 3, 2, 1),
+]
+
+
+@pytest.mark.parametrize("N,H,W,C,K,R,stride,pad", CONVS)
+def test_conv_fwd_dgrad_wgrad(E, N, H, W, C, K, R, stride, pad):
+    g = torch.Generator().manual_seed(N * 100 + H + C + K + R)
+    x = torch.randn(N, C, H, W, generator=g, requires_grad=True)
+    w = torch.randn(K, C, R, R, generator=g, requires_grad=True)
+    y = F.conv2d(x, w, None, stride, pad)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    xd = nhwc(x.detach()).cuda(); wd = w.detach().cuda().contiguous(memory_format=torch.channels_last)
+    yd = E.conv_fwd(xd, wd, stride, pad)
+    tol = 1e-5 * (C * R * R) ** 0.5
+    close(nchw(yd), y, tol, "conv fwd")
+    dyd = nhwc(dy).cuda()
+    close(nchw(E.conv_dgrad(dyd, wd, xd.shape, stride, pad)), x.grad, 1e-5 * (K * R * R) ** 0.5, "conv dgrad")
+    close(E.conv_wgrad(dyd, xd, wd, stride, pad), w.grad, 1e-5 * (N * y.shape[2] * y.shape[3]) ** 0.5, "conv wgrad")
+    # accumulate form
+    base = torch.randn(x.shape, generator=g)
+    acc = E.conv_dgrad(dyd, wd, xd.shape, stride, pad, out=nhwc(base).cuda(), accumulate=True)
+    close(nchw(acc), x.grad + base, 1e-5 * (K * R * R) ** 0.5, "conv dgrad accumulate")
+
+
+def test_conv_bias(E):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 16, 4, 4, generator=g); w = torch.randn(8, 16, 1, 1, generator=g); b = torch.randn(8, generator=g)
+    close(nchw(E.conv_fwd(nhwc(x).cuda(), w.cuda(), 1, 0, b.cuda())), F.conv2d(x, w, b), 2e-5, "1x1 conv + bias")
+
+
+@pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False)])
+@pytest.mark.parametrize("N,H,W,C", [(4, 5, 5, 8), (2, 16, 16, 64), (3, 7, 7, 12)])
+def test_batchnorm_train_fwd_bwd(E, N, H, W, C, relu, res):
+    g = torch.Generator().manual_seed(C + N)
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5); bn.bias.copy_(torch.randn(C, generator=g) * 0.1)
+    x = (torch.randn(N, C, H, W, generator=g) * 2 + 0.5).requires_grad_()
+    r = torch.randn(N, C, H, W, generator=g).requires_grad_() if res else None
+    y = bn(x)
+    if res: y = y + r
+    if relu: y = F.relu(y)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    bnd = torch.nn.BatchNorm2d(C).cuda()
+    with torch.no_grad():
+        bnd.weight.copy_(bn.weight); bnd.bias.copy_(bn.bias)
+    xd = nhwc(x.detach()).cuda(); rd = nhwc(r.detach()).cuda() if res else None
+    yd, stats = E.bn_fwd(xd, bnd, rd, relu, True)
+    close(nchw(yd), y, 1e-5, "bn fwd")
+    close(bnd.running_mean, bn.running_mean, 1e-5, "running_mean"); close(bnd.running_var, bn.running_var, 1e-5, "running_var")
+    assert int(bnd.num_batches_tracked) == 1
+    dres = torch.empty_like(xd) if res else None
+    dx, dgam, dbet = E.bn_bwd(nhwc(dy).cuda(), xd, yd, stats, bnd, relu, dres=dres)
+    close(nchw(dx), x.grad, 2e-5, "bn dx"); close(dgam, bn.weight.grad, 2e-5, "bn dgamma"); close(dbet, bn.bias.grad, 2e-5, "bn dbeta")
+    if res:
+        close(nchw(dres), r.grad, 1e-6, "residual grad")
+    # eval mode
+    bn.eval(); bnd.eval()
+    ye = bn(x.detach()); ye = F.relu(ye) if relu else ye
+    yde, _ = E.bn_fwd(xd, bnd, None, relu, False)
+    close(nchw(yde), ye, 1e-5, "bn eval")
+
+
+def test_maxpool_fwd_bwd_with_ties(E):
+    import sat_amd  # noqa
+    from sat_amd import _lib as L
+    g = torch.Generator().manual_seed(9)
+    x = F.relu(torch.randn(2, 8, 11, 12, generator=g)).requires_grad_()        # post-ReLU: many exact ties at 0
+    y = F.max_pool2d(x, 3, 2, 1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    xd = nhwc(x.detach()).cuda()
+    N, H, W, C = xd.shape
+    P, Q = y.shape[2], y.shape[3]
+    yd = torch.empty(N, P, Q, C, device="cuda"); am = torch.empty(N, P, Q, C, dtype=torch.uint8, device="cuda")
+    L.check(L.lib().sat_maxpool3x3s2_fwd(L.ptr(xd), L.ptr(yd), L.ptr(am), N, H, W, C, L.stream_ptr()), "maxpool fwd")
+    assert torch.equal(nchw(yd).cpu(), y.detach())
+    dx = torch.empty_like(xd)
+    L.check(L.lib().sat_maxpool3x3s2_bwd(L.ptr(nhwc(dy).cuda()), L.ptr(am), L.ptr(dx), N, H, W, C, L.stream_ptr()), "maxpool bwd")
+    close(nchw(dx), x.grad, 1e-6, "maxpool bwd (first-max tie rule)")
+
+
+@pytest.mark.parametrize("out", [7, 14, 5])
+def test_resize_fwd_bwd(E, out):
+    import sat_amd  # noqa
+    from sat_amd import _lib as L
+    g = torch.Generator().manual_seed(out)
+    x = torch.randn(2, 12, 8, 8, generator=g, requires_grad=True)
+    mod = torch.nn.AdaptiveAvgPool2d((out, out)) if out < 8 else torch.nn.Upsample((out, out), mode="bilinear", align_corners=False)
+    y = mod(x); dy = torch.randn(y.shape, generator=g); y.backward(dy)
+    xd = nhwc(x.detach()).cuda(); yd = torch.empty(2, out, out, 12, device="cuda"); dx = torch.empty_like(xd)
+    L.check(L.lib().sat_resize_fwd(L.ptr(xd), L.ptr(yd), 2, 8, 8, 12, out, out, L.stream_ptr()), "resize fwd")
+    L.check(L.lib().sat_resize_bwd(L.ptr(nhwc(dy).cuda()), L.ptr(dx), 2, 8, 8, 12, out, out, L.stream_ptr()), "resize bwd")
+    close(nchw(yd), y, 1e-6, "resize fwd"); close(nchw(dx), x.grad, 1e-6, "resize bwd")
+
+
+@pytest.mark.parametrize("arch,es", [("resnet18", None), ("resnet18", 3), ("resnet50", None)])
+def test_whole_encoder_against_oracle(E, arch, es):
+    from oracle import prng, sat_oracle as O
+    hp = O.default_hparams(encoder_arch=arch, encoder_dim=32, input_size=64, encoder_size=es)
+    torch.manual_seed(3)
+    ref = O.build_encoder(hp)                                   # CPU, train mode
+    hp2 = O.default_hparams(encoder_arch=arch, encoder_dim=32, input_size=64, encoder_size=es)
+    enc = E.get_encoder(hp2)
+    assert list(enc.state_dict().keys()) == list(ref.state_dict().keys())
+    enc.load_state_dict(ref.state_dict())
+    enc = enc.cuda().train()
+    img = torch.from_numpy(prng.uniform((4, 3, 64, 64), 77, 0.0, 1.0))
+    y_ref = ref(img.clone())
+    dy = torch.from_numpy(prng.uniform(tuple(y_ref.shape), 78))
+    y_ref.backward(dy)
+    y = enc(img.cuda())
+    assert y.shape == y_ref.shape
+    close(y, y_ref, 2e-4, "annotations")
+    y.backward(dy.cuda())
+    gref = dict(ref.named_parameters())
+    worst = 0.0
+    for k, p in enc.named_parameters():
+        assert p.grad is not None, k
+        gr = gref[k].grad
+        err = float((p.grad.cpu() - gr).abs().max()) / max(1e-6, float(gr.abs().max()))
+        worst = max(worst, err)
+        assert err <= 5e-3, "%s: relative grad error %.3e" % (k, err)
+    print("worst relative grad error:", worst)
+    # running statistics follow nn.BatchNorm2d
+    sd, sr = enc.state_dict(), ref.state_dict()
+    for k in sd:
+        if "running" in k:
+            close(sd[k], sr[k], 1e-4, k)
+        if "num_batches" in k:
+            assert int(sd[k]) == int(sr[k]), k
+    # eval mode uses the running statistics
+    enc.eval(); ref.eval()
+    with torch.no_grad():
+        close(enc(img.cuda()), ref(img.clone()), 2e-4, "eval annotations")
