@@ -37,31 +37,41 @@ __global__ void unpad_c4_to_c3_kernel(const float* __restrict__ w4, float* __res
 // ------------------------------------------------------------------ BatchNorm (training mode)
 // Column statistics of a (rows x C) matrix, C % 4 == 0.  Block = 256 threads = TW vector-columns x RL row lanes.
 // MODE 0: sum x, sum x^2.   MODE 1: sum g, sum g*xhat with g = dy * (relu ? y > 0 : 1).
+struct d4 { double x, y, z, w; };
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_colstats_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
                                                           const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
-                                                          long rows, int C, int TW, long rows_per, float* __restrict__ part0, float* __restrict__ part1) {
-    __shared__ float4 s0[256], s1[256];
+                                                          long rows, int C, int TW, long rows_per, double* __restrict__ part0, double* __restrict__ part1,
+                                                          float* __restrict__ part2) {
+    // double accumulators: these kernels are HBM-bound, the fp64 adds are free, and the sums then match the
+    // accuracy of ATen's CPU batch-norm (which accumulates float inputs in double)
+    __shared__ d4 s0[256], s1[256];
     const int tid = threadIdx.x, tc = tid % TW, tr = tid / TW, RL = 256 / TW;
     const int c4 = blockIdx.x * TW + tc;           // vector column
     const int C4 = C >> 2;
-    float4 a0 = make_float4(0, 0, 0, 0), a1 = a0;
+    d4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
     if (c4 < C4 && tr < RL) {
-        float4 mu = a0, is = a0;
-        if (MODE == 1) { mu = reinterpret_cast<const float4*>(mean)[c4]; is = reinterpret_cast<const float4*>(invstd)[c4]; }
+        float4 mu = make_float4(0, 0, 0, 0), is = mu;
         long r0 = (long)blockIdx.y * rows_per, r1 = r0 + rows_per; if (r1 > rows) r1 = rows;
+        if (MODE == 1) { mu = reinterpret_cast<const float4*>(mean)[c4]; is = reinterpret_cast<const float4*>(invstd)[c4]; }
+        else {
+            // shifted sums: d = x - (first row of this chunk) keeps sum d^2 - (sum d)^2/n well conditioned
+            mu = reinterpret_cast<const float4*>(x)[r0 * C4 + c4];
+            if (tr == 0) reinterpret_cast<float4*>(part2)[(long)blockIdx.y * C4 + c4] = mu;
+        }
         for (long r = r0 + tr; r < r1; r += RL) {
             float4 xv = reinterpret_cast<const float4*>(x)[r * C4 + c4];
             if (MODE == 0) {
+                xv.x -= mu.x; xv.y -= mu.y; xv.z -= mu.z; xv.w -= mu.w;
                 a0.x += xv.x; a0.y += xv.y; a0.z += xv.z; a0.w += xv.w;
-                a1.x += xv.x * xv.x; a1.y += xv.y * xv.y; a1.z += xv.z * xv.z; a1.w += xv.w * xv.w;
+                a1.x += (double)xv.x * xv.x; a1.y += (double)xv.y * xv.y; a1.z += (double)xv.z * xv.z; a1.w += (double)xv.w * xv.w;
             } else {
                 float4 g = reinterpret_cast<const float4*>(dy)[r * C4 + c4];
                 if (relu) { float4 yv = reinterpret_cast<const float4*>(y)[r * C4 + c4];
                     g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f; }
                 a0.x += g.x; a0.y += g.y; a0.z += g.z; a0.w += g.w;
-                a1.x += g.x * (xv.x - mu.x) * is.x; a1.y += g.y * (xv.y - mu.y) * is.y;
-                a1.z += g.z * (xv.z - mu.z) * is.z; a1.w += g.w * (xv.w - mu.w) * is.w;
+                a1.x += (double)g.x * ((xv.x - mu.x) * is.x); a1.y += (double)g.y * ((xv.y - mu.y) * is.y);
+                a1.z += (double)g.z * ((xv.z - mu.z) * is.z); a1.w += (double)g.w * ((xv.w - mu.w) * is.w);
             }
         }
     }
@@ -69,25 +79,33 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const float* __restric
     __syncthreads();
     if (tr == 0 && c4 < C4) {
         for (int k = 1; k < RL; ++k) {     // fixed order
-            float4 b0 = s0[k * TW + tc], b1 = s1[k * TW + tc];
+            d4 b0 = s0[k * TW + tc], b1 = s1[k * TW + tc];
             a0.x += b0.x; a0.y += b0.y; a0.z += b0.z; a0.w += b0.w;
             a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
         }
-        reinterpret_cast<float4*>(part0)[(long)blockIdx.y * C4 + c4] = a0;
-        reinterpret_cast<float4*>(part1)[(long)blockIdx.y * C4 + c4] = a1;
+        reinterpret_cast<d4*>(part0)[(long)blockIdx.y * C4 + c4] = a0;
+        reinterpret_cast<d4*>(part1)[(long)blockIdx.y * C4 + c4] = a1;
     }
 }
 
 // forward finalise: batch mean / biased variance -> invstd, running stats (momentum, unbiased var) as nn.BatchNorm2d
-__global__ void bn_fwd_finalize_kernel(const float* __restrict__ part0, const float* __restrict__ part1, int nparts, int C, long rows,
+__global__ void bn_fwd_finalize_kernel(const double* __restrict__ part0, const double* __restrict__ part1, const float* __restrict__ part2,
+                                       int nparts, long rows_per, int C, long rows,
                                        float eps, float momentum, float* __restrict__ mean, float* __restrict__ invstd,
                                        float* __restrict__ running_mean, float* __restrict__ running_var) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int p = 0; p < nparts; ++p) { s += (double)part0[(long)p * C + c]; q += (double)part1[(long)p * C + c]; }
-    double mu = s / (double)rows, var = q / (double)rows - mu * mu;
-    if (var < 0.0) var = 0.0;
+    // merge per-chunk (count, mean, M2) in a fixed order (Chan et al. pairwise update), in double
+    double cnt = 0.0, mu = 0.0, m2 = 0.0;
+    for (int p = 0; p < nparts; ++p) {
+        long r0 = (long)p * rows_per, r1 = r0 + rows_per; if (r1 > rows) r1 = rows;
+        double nk = (double)(r1 - r0), sd = part0[(long)p * C + c], sq = part1[(long)p * C + c];
+        double mk = (double)part2[(long)p * C + c] + sd / nk, m2k = sq - sd * sd / nk;
+        if (m2k < 0.0) m2k = 0.0;
+        double delta = mk - mu, tot = cnt + nk;
+        mu += delta * nk / tot; m2 += m2k + delta * delta * cnt * nk / tot; cnt = tot;
+    }
+    double var = m2 / (double)rows;
     mean[c] = (float)mu;
     invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
     if (running_mean) {
@@ -117,12 +135,12 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
     reinterpret_cast<float4*>(y)[e] = o;
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part0, const float* __restrict__ part1, int nparts, int C,
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part0, const double* __restrict__ part1, int nparts, int C,
                                        float* __restrict__ dbeta, float* __restrict__ dgamma) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double s = 0.0, q = 0.0;
-    for (int p = 0; p < nparts; ++p) { s += (double)part0[(long)p * C + c]; q += (double)part1[(long)p * C + c]; }
+    for (int p = 0; p < nparts; ++p) { s += part0[(long)p * C + c]; q += part1[(long)p * C + c]; }
     dbeta[c] = (float)s; dgamma[c] = (float)q;
 }
 
@@ -340,7 +358,7 @@ static void bn_grid(long rows, int C, int& TW, long& rows_per, int& nparts) {
 size_t sat_bn_scratch_bytes(int64_t rows, int32_t C) {
     if (rows <= 0 || C <= 0 || C % 4) return 0;
     int TW, nparts; long rp; bn_grid(rows, C, TW, rp, nparts);
-    return (size_t)2 * nparts * C * sizeof(float);
+    return (size_t)nparts * C * (2 * sizeof(double) + sizeof(float)) + 64;
 }
 
 int sat_bn_train_fwd(const float* x, int64_t rows, int32_t C, const float* gamma, const float* beta, float eps, float momentum,
@@ -350,10 +368,10 @@ int sat_bn_train_fwd(const float* x, int64_t rows, int32_t C, const float* gamma
     SAT_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, "bn_train_fwd: rows=%ld C=%d (C must be a multiple of 4)", (long)rows, C);
     hipStream_t st = (hipStream_t)stream;
     int TW, nparts; long rp; bn_grid(rows, C, TW, rp, nparts);
-    float* p0 = scratch; float* p1 = scratch + (long)nparts * C;
-    hipLaunchKernelGGL(bn_colstats_kernel<0>, dim3(cdiv(C / 4, TW), nparts), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, 0, (long)rows, C, TW, rp, p0, p1);
+    double* p0 = reinterpret_cast<double*>(scratch); double* p1 = p0 + (long)nparts * C; float* p2 = reinterpret_cast<float*>(p1 + (long)nparts * C);
+    hipLaunchKernelGGL(bn_colstats_kernel<0>, dim3(cdiv(C / 4, TW), nparts), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, 0, (long)rows, C, TW, rp, p0, p1, p2);
     SAT_TRY(launch_ok("bn_colstats<0>"));
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, p0, p1, nparts, C, (long)rows, eps, momentum, save_mean, save_invstd, running_mean, running_var);
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, p0, p1, p2, nparts, rp, C, (long)rows, eps, momentum, save_mean, save_invstd, running_mean, running_var);
     SAT_TRY(launch_ok("bn_fwd_finalize"));
     long total4 = rows * (C / 4);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta, residual, relu, y, total4, C / 4, -1.0f);
@@ -377,8 +395,8 @@ int sat_bn_train_bwd(const float* dy, const float* x, const float* y, int64_t ro
     SAT_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, "bn_train_bwd: bad shape");
     hipStream_t st = (hipStream_t)stream;
     int TW, nparts; long rp; bn_grid(rows, C, TW, rp, nparts);
-    float* p0 = scratch; float* p1 = scratch + (long)nparts * C;
-    hipLaunchKernelGGL(bn_colstats_kernel<1>, dim3(cdiv(C / 4, TW), nparts), dim3(256), 0, st, x, dy, y, save_mean, save_invstd, relu, (long)rows, C, TW, rp, p0, p1);
+    double* p0 = reinterpret_cast<double*>(scratch); double* p1 = p0 + (long)nparts * C;
+    hipLaunchKernelGGL(bn_colstats_kernel<1>, dim3(cdiv(C / 4, TW), nparts), dim3(256), 0, st, x, dy, y, save_mean, save_invstd, relu, (long)rows, C, TW, rp, p0, p1, nullptr);
     SAT_TRY(launch_ok("bn_colstats<1>"));
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, p0, p1, nparts, C, dbeta, dgamma);
     SAT_TRY(launch_ok("bn_bwd_finalize"));

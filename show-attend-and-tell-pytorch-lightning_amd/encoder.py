@@ -124,7 +124,7 @@ def bn_fwd(x, bn, residual=None, relu=True, training=True):
     y = torch.empty_like(x)
     if training:
         mean = torch.empty(Cc, dtype=torch.float32, device=x.device); invstd = torch.empty_like(mean)
-        scratch = torch.empty(lib.sat_bn_scratch_bytes(rows, Cc) // 4, dtype=torch.float32, device=x.device)
+        scratch = torch.empty(lib.sat_bn_scratch_bytes(rows, Cc) // 8 + 1, dtype=torch.float64, device=x.device)
         mom = 0.1 if bn.momentum is None else float(bn.momentum)
         L.check(lib.sat_bn_train_fwd(L.ptr(x), rows, Cc, L.ptr(bn.weight), L.ptr(bn.bias), float(bn.eps), mom, L.ptr(bn.running_mean),
                                      L.ptr(bn.running_var), L.ptr(mean), L.ptr(invstd), L.ptr(residual), int(relu), L.ptr(y), L.ptr(scratch),
@@ -141,7 +141,7 @@ def bn_bwd(dy, x, y, stats, bn, relu, dres=None, dres_accumulate=False):
     Cc = x.shape[-1]; rows = x.numel() // Cc
     dx = torch.empty_like(x)
     dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device); dbeta = torch.empty_like(dgamma)
-    scratch = torch.empty(lib.sat_bn_scratch_bytes(rows, Cc) // 4, dtype=torch.float32, device=x.device)
+    scratch = torch.empty(lib.sat_bn_scratch_bytes(rows, Cc) // 8 + 1, dtype=torch.float64, device=x.device)
     L.check(lib.sat_bn_train_bwd(L.ptr(dy), L.ptr(x), L.ptr(y), rows, Cc, L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(bn.weight), int(relu),
                                  L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dres), int(dres_accumulate), L.ptr(scratch), L.stream_ptr()),
             "sat_bn_train_bwd")

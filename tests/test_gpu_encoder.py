@@ -133,34 +133,70 @@ def test_resize_fwd_bwd(E, out):
     close(nchw(yd), y, 1e-6, "resize fwd"); close(nchw(dx), x.grad, 1e-6, "resize bwd")
 
 
-@pytest.mark.parametrize("arch,es", [("resnet18", None), ("resnet18", 3), ("resnet50", None)])
-def test_whole_encoder_against_oracle(E, arch, es):
+@pytest.mark.parametrize("kind,cin,planes,stride", [("basic", 16, 16, 1), ("basic", 16, 32, 2), ("bottleneck", 64, 16, 1),
+                                                     ("bottleneck", 32, 16, 2), ("bottleneck", 16, 8, 1)])
+def test_residual_block_fwd_bwd(E, kind, cin, planes, stride):
+    """One BasicBlock / Bottleneck with healthy batch statistics: HIP block forward/backward against the oracle's block."""
+    from oracle import sat_oracle as O
+    g = torch.Generator().manual_seed(cin + planes + stride)
+    torch.manual_seed(cin * 7 + planes)
+    ref = O._Residual(kind, cin, planes, stride, 64)
+    blk = E.Block(kind, cin, planes, stride, 64)
+    with torch.no_grad():
+        for p in ref.parameters():
+            if p.dim() == 1:
+                p.copy_(torch.rand(p.shape, generator=g) + 0.5)
+    blk.load_state_dict(ref.state_dict()); E._channels_last_(blk); blk = blk.cuda().train()
+    x = torch.randn(6, cin, 12, 12, generator=g).requires_grad_()
+    y = ref(x.clone()); dy = torch.randn(y.shape, generator=g); y.backward(dy)
+    xd = nhwc(x.detach()).cuda()
+    rec = E._block_fwd(blk, xd, True)
+    close(nchw(rec.out), y, 2e-5, "block out")
+    grads = {}
+    dx = E._block_bwd(rec, nhwc(dy).cuda(), grads, True)
+    close(nchw(dx), x.grad, 1e-4, "block dx")
+    refp = dict(ref.named_parameters())
+    for k, p in blk.named_parameters():
+        close(grads[p], refp[k].grad, 2e-4, k)
+
+
+@pytest.mark.parametrize("arch,es,px", [("resnet18", None, 64), ("resnet18", 3, 64), ("resnet50", None, 128)])
+def test_whole_encoder_against_oracle(E, arch, es, px):
     from oracle import prng, sat_oracle as O
-    hp = O.default_hparams(encoder_arch=arch, encoder_dim=32, input_size=64, encoder_size=es)
+    hp = O.default_hparams(encoder_arch=arch, encoder_dim=32, input_size=px, encoder_size=es)
     torch.manual_seed(3)
     ref = O.build_encoder(hp)                                   # CPU, train mode
-    hp2 = O.default_hparams(encoder_arch=arch, encoder_dim=32, input_size=64, encoder_size=es)
+    hp2 = O.default_hparams(encoder_arch=arch, encoder_dim=32, input_size=px, encoder_size=es)
     enc = E.get_encoder(hp2)
     assert list(enc.state_dict().keys()) == list(ref.state_dict().keys())
     enc.load_state_dict(ref.state_dict())
     enc = enc.cuda().train()
-    img = torch.from_numpy(prng.uniform((4, 3, 64, 64), 77, 0.0, 1.0))
+    img = torch.from_numpy(prng.uniform((8, 3, px, px), 77, 0.0, 1.0))
+    import copy
+    ref64 = copy.deepcopy(ref).double()                         # fp64 run of the same oracle: the yardstick for fp32 noise
     y_ref = ref(img.clone())
     dy = torch.from_numpy(prng.uniform(tuple(y_ref.shape), 78))
     y_ref.backward(dy)
+    y64 = ref64(img.double().clone()); y64.backward(dy.double())
     y = enc(img.cuda())
     assert y.shape == y_ref.shape
     close(y, y_ref, 2e-4, "annotations")
     y.backward(dy.cuda())
-    gref = dict(ref.named_parameters())
+    gref = dict(ref.named_parameters()); g64 = dict(ref64.named_parameters())
     worst = 0.0
     for k, p in enc.named_parameters():
         assert p.grad is not None, k
-        gr = gref[k].grad
-        err = float((p.grad.cpu() - gr).abs().max()) / max(1e-6, float(gr.abs().max()))
-        worst = max(worst, err)
-        assert err <= 5e-3, "%s: relative grad error %.3e" % (k, err)
-    print("worst relative grad error:", worst)
+        exact = g64[k].grad
+        nrm = max(1e-12, float(exact.norm()))
+        err_gpu = float((p.grad.cpu().double() - exact).norm()) / nrm
+        err_cpu = float((gref[k].grad.double() - exact).norm()) / nrm      # what fp32 itself costs on this net
+        worst = max(worst, err_gpu)
+        # A randomly initialised ResNet at batch 8 is badly conditioned (ReLU / max-pool decisions flip between fp32
+        # and fp64): the CPU fp32 oracle itself is ~2e-2 (relative L2) away from its own fp64 run on every tensor.
+        # The layer and block tests above are the tight ones; here the HIP path must be as close to fp64 as the
+        # fp32 reference is.
+        assert err_gpu <= 2 * err_cpu + 1e-3, "%s: HIP %.3e vs CPU-fp32 %.3e (relative L2 to fp64)" % (k, err_gpu, err_cpu)
+    print("worst relative grad error vs fp64:", worst)
     # running statistics follow nn.BatchNorm2d
     sd, sr = enc.state_dict(), ref.state_dict()
     for k in sd:
