@@ -398,3 +398,43 @@ def random_decoder_state(hp, seed=0):
     if not hp.weight_tying:
         sd["output.output.bias"] = U((V,), m)
     return sd
+
+
+# --------------------------------------------------------------------------
+# Whole model: encoder + decoder + losses = SAT.training_step's arithmetic
+# (model.py:589-597).  Used by the parity tests and as bench.py's "port" CPU baseline.
+# --------------------------------------------------------------------------
+
+class OracleSAT:
+    """``state_dict`` uses the reference's keys (``encoder.*`` + decoder keys)."""
+
+    def __init__(self, hp, state_dict=None, seed=42):
+        self.hp = hp
+        torch.manual_seed(seed)
+        self.encoder = build_encoder(hp)
+        if state_dict is None:
+            self.sd = random_decoder_state(hp, seed)
+        else:
+            enc = {k[len("encoder."):]: v for k, v in state_dict.items() if k.startswith("encoder.")}
+            self.encoder.load_state_dict(enc)
+            self.sd = {k: v.detach().clone() for k, v in state_dict.items() if not k.startswith("encoder.")}
+        for v in self.sd.values():
+            v.requires_grad_()
+        if hp.weight_tying and hp.deep_output:
+            self.sd["output.output.weight"] = self.sd["embedding.weight"]
+
+    def parameters(self):
+        seen, out = set(), []
+        for p in list(self.encoder.parameters()) + list(self.sd.values()):
+            if id(p) not in seen:
+                seen.add(id(p)); out.append(p)
+        return out
+
+    def named_grads(self):
+        g = {"encoder." + k: p.grad for k, p in self.encoder.named_parameters()}
+        g.update({k: p.grad for k, p in self.sd.items()})
+        return g
+
+    def step_loss(self, img, caps, lengths, epsilon=1.0, draw=None):
+        ann = self.encoder(img.clone())                    # clone: Normalize is in place (F9)
+        return training_loss(self.sd, self.hp, ann, caps, lengths, epsilon, draw)

@@ -323,11 +323,18 @@ def get_encoder(args):
             blk = Block(kind, cin, planes, 2 if (si > 0 and bi == 0) else 1, wpg)
             cin = blk.cout; blocks.append(blk)
         layers.append(nn.Sequential(*blocks))
+    final_dim = cin
+    nn.Linear(final_dim, 1000)        # torchvision builds (and the reference then drops, model.py:29) an fc layer: keep the RNG stream aligned
     for mod in [conv1, *layers]:
         for sub in mod.modules():
             if isinstance(sub, nn.Conv2d):
                 nn.init.kaiming_normal_(sub.weight, mode="fan_out", nonlinearity="relu")
-    final_dim = cin
+    # model.py:46-48 pushes a zero image through the train-mode trunk to read its output shape.  With zero
+    # biases every BatchNorm sees an all-zero batch: running_mean stays 0, running_var becomes 0.9, one batch tracked.
+    for mod in [bn1, *layers]:
+        for sub in mod.modules():
+            if isinstance(sub, nn.BatchNorm2d):
+                sub.running_var.fill_(0.9); sub.num_batches_tracked.fill_(1)
     inp = int(args.input_size)
     s = (inp + 2 * 3 - 7) // 2 + 1; s = (s + 2 - 3) // 2 + 1
     for _ in range(3):

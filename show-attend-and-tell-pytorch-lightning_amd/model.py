@@ -11,8 +11,12 @@ from types import SimpleNamespace
 import torch
 from torch import nn
 
+from torch.nn.utils.rnn import PackedSequence
+from torch.optim.lr_scheduler import MultiStepLR, ReduceLROnPlateau, ExponentialLR, CosineAnnealingWarmRestarts, OneCycleLR
+
 from . import _lib as L
 from . import decoder as Dk
+from .encoder import get_encoder  # noqa: F401  (module-level name, as in the reference)
 
 try:                                     # Lightning is optional plumbing (absent in the build image)
     import pytorch_lightning as pl
@@ -82,7 +86,10 @@ class SATDecoder(nn.Module):
 
     def __init__(self, hp):
         super().__init__()
-        if isinstance(hp, dict):
+        self._build_decoder(hp)
+
+    def _build_decoder(self, hp, encoder_factory=None):
+        if isinstance(hp, dict) and not isinstance(hp, _HParams):
             hp = _HParams(hp)
         self.hp = hp
         if hp.decoder_layers != 1:
@@ -94,6 +101,8 @@ class SATDecoder(nn.Module):
         assert 0 <= hp.label_smoothing < (hp.vocab_size - 1) / hp.vocab_size
         self.criterion = LabelSmoothing(hp.label_smoothing)
         self.pad_idx = int(hp.vocab_stoi["<PAD>"])
+        if encoder_factory is not None:                     # registered here to keep the reference's module order
+            self.encoder = encoder_factory(hp)
         self.embedding = nn.Embedding(hp.vocab_size, hp.embed_dim, max_norm=None, padding_idx=self.pad_idx)
         self.embedding_dropout = nn.Dropout(p=hp.embedding_dropout)
         self.init_lstm = InitLSTM(hp, bias=True)
@@ -121,7 +130,7 @@ class SATDecoder(nn.Module):
             if k in own:
                 own[k].copy_(torch.as_tensor(v))
 
-    def train_decode(self, ann_bld, caps, lengths, epsilon=0, draw=None):
+    def train_decode(self, ann_bld, caps, lengths, epsilon=0, draw=None, with_loss=True):
         """Decoder half of train_batch + the loss terms (model.py:487-557, 592-597).
 
         ann_bld (B, L, D) on the GPU; caps (B, R, T) int64; lengths (B, R) int64 (host or device)."""
@@ -133,7 +142,153 @@ class SATDecoder(nn.Module):
         logits_packed, alphas = Dk.DecoderTrainFn.apply(ann_bld, caps_i32, plan, teacher, bool(self.hp.deep_output), self.pad_idx, R,
                                                         *self.param_list())
         targets_packed = plan.pack(caps2[:, 1:].to(ann_bld.device).unsqueeze(-1)).squeeze(-1)
+        if not with_loss:
+            return dict(logits_packed=logits_packed, targets_packed=targets_packed, alphas=alphas, plan=plan)
         ce = self.criterion(logits_packed, targets_packed)
         ds = Dk.DoublyStochasticFn.apply(alphas, float(self.hp.att_gamma))
         return dict(logits_packed=logits_packed, targets_packed=targets_packed, alphas=alphas, ce=ce, ds=ds,
                     acc=self.criterion.last_accuracy, plan=plan)
+
+
+class SAT(SATDecoder, _Base):
+    """``class SAT(pl.LightningModule)`` of the reference (model.py:134-199) for the train-step hot path.
+
+    Same constructor kwargs (train.py:264 passes ``**vars(args)``), same sub-module attribute names and
+    state-dict keys; ``train_batch`` / ``training_step`` / ``configure_optimizers`` keep their signatures.
+    Construction order follows the reference (criterion, encoder, embedding, init_lstm, lstm, attention, beta,
+    output) so that a seed produces the same parameter stream.  Inference (``caption`` / beam search,
+    model.py:214-472) and the nltk metrics (model.py:646-718) are outside this round's scope."""
+
+    def __init__(self, **kwargs):
+        nn.Module.__init__(self)
+        hp = _HParams(kwargs)
+        for k, v in dict(encoder_size=None, embed_norm=None, pretrained_embedding=None, pretrained=False, decoder_tf=None,
+                         decoder_tf_min=0.5, epochs=10, encoder_finetune_after=-1, att_gamma=1.0, label_smoothing=0.0,
+                         dropout=0.0, embedding_dropout=0.0, weight_tying=False, deep_output=False, decoder_layers=1,
+                         lr_warmup_steps=0).items():
+            hp.setdefault(k, v)
+        self.scheduler = None
+        self.opt_init_lr = None
+        self.__dict__["_sat_global_step"] = 0
+        # reference order: criterion -> encoder -> decoder parts (model.py:148-195); get_encoder writes
+        # hp.encoder_dim back when no projection is needed (model.py:56)
+        self._build_decoder(hp, encoder_factory=get_encoder)
+        if hp.pretrained_embedding is not None:
+            import numpy as np
+            self.embedding.weight = nn.Parameter(torch.tensor(np.load(hp.pretrained_embedding), dtype=torch.float32))
+        self.special_idxs = [self.stoi("<PAD>"), self.stoi("<START>"), self.stoi("<END>")]
+
+    # Lightning gives `hparams`; without Lightning keep the same attribute
+    @property
+    def hparams(self):
+        return self.hp
+
+    def stoi(self, s):
+        return int(self.hp.vocab_stoi.get(s, self.hp.vocab_stoi["<UNK>"]))
+
+    def itos(self, i):
+        return str(self.hp.vocab_itos.get(int(i), "<UNK>"))
+
+    def decode_seq(self, seq, remove_special=False):
+        return [str(self.itos(t)) for t in seq if not (remove_special and t in self.special_idxs)]
+
+    # ------------------------------------------------------------------ train_batch (model.py:474-557)
+    def encode(self, img):
+        ann = self.encoder(img)                                  # (B, D, h, w), channels-last memory
+        B, D, h, w = ann.shape
+        return ann.permute(0, 2, 3, 1).reshape(B, h * w, D), (h, w)
+
+    def train_batch(self, batch, epsilon=0, draw=None):
+        img, encoded_captions, lengths = batch
+        ann_bld, _ = self.encode(img)
+        res = self.train_decode(ann_bld, encoded_captions, lengths, float(epsilon), draw, with_loss=False)
+        plan = res["plan"]
+        unsorted = torch.empty_like(plan.sorted_indices)
+        unsorted[plan.sorted_indices] = torch.arange(plan.N)
+        dev = ann_bld.device
+        lp = PackedSequence(res["logits_packed"], plan.batch_sizes, plan.sorted_indices.to(dev), unsorted.to(dev))
+        tp = PackedSequence(res["targets_packed"], plan.batch_sizes, plan.sorted_indices.to(dev), unsorted.to(dev))
+        self._last = res
+        return lp, tp, res["alphas"]
+
+    def teacher_forcing_epsilon(self, current_epoch=0):
+        """model.py:565-582 (host scalars)."""
+        hp = self.hp
+        if hp.decoder_tf is None:
+            return 0.0
+        if hp.decoder_tf == "always":
+            return 1.0
+        if hp.decoder_tf == "linear":
+            return 1 - (1 - hp.decoder_tf_min) * current_epoch / hp.epochs
+        if hp.decoder_tf == "inv_sigmoid":
+            l = -math.log(hp.decoder_tf_min / (1 - hp.decoder_tf_min)); g = 5.0
+            b = (1 / ((l / g) + 1)) * hp.epochs
+            return 1 / (1 + math.exp((g / b) * (current_epoch - b)))
+        if hp.decoder_tf == "exp":
+            return math.exp(math.log(hp.decoder_tf_min) / hp.epochs) ** current_epoch
+        raise ValueError("decoder_tf=%r" % (hp.decoder_tf,))
+
+    def training_step(self, batch, batch_idx=0):
+        """model.py:559-628: returns the metrics dict whose "loss" the trainer back-propagates."""
+        hp = self.hp
+        epoch = getattr(self, "current_epoch", 0) if pl is not None and isinstance(self, pl.LightningModule) else 0
+        epsilon = self.teacher_forcing_epsilon(epoch)
+        gstep = self.__dict__["_sat_global_step"]
+        if gstep == hp.encoder_finetune_after and hp.encoder_finetune_after >= 0:
+            for p in self.encoder.parameters():
+                p.requires_grad = True
+        lp, tp, alphas = self.train_batch(batch, epsilon)
+        loss = self.criterion(lp.data, tp.data)                                   # model.py:592
+        loss = loss + Dk.DoublyStochasticFn.apply(alphas, float(hp.att_gamma))      # model.py:594
+        self.__dict__["_sat_global_step"] = gstep + 1
+        return {"loss": loss, "accuracy": self.criterion.last_accuracy, "epsilon_tf": float(epsilon)}
+
+    # ------------------------------------------------------------------ configure_optimizers (model.py:720-817)
+    def configure_optimizers(self):
+        hp = self.hp
+
+        def groups(modules, weight_decay, lr):
+            decay, no_decay = [], []
+            for mod in modules:
+                for _, p in mod.named_parameters():
+                    if p.requires_grad:
+                        (no_decay if p.dim() == 1 else decay).append(p)
+            return [{"params": no_decay, "lr": lr, "weight_decay": 0.0}, {"params": decay, "lr": lr, "weight_decay": weight_decay}]
+
+        params = groups([self.init_lstm, self.lstm, self.attention, self.beta, self.output], hp.weight_decay, hp.decoder_lr)
+        if hp.embedding_lr > 0 and not hp.weight_tying:
+            params += [{"params": self.embedding.parameters(), "lr": hp.embedding_lr, "weight_decay": 0.0}]
+        if hp.encoder_finetune_after > 0 and hp.encoder_lr > 0:          # F10: mirrored as written
+            params += groups([self.encoder], hp.weight_decay, hp.encoder_lr)
+        if hp.opt == "sgd":
+            opt = torch.optim.SGD(params, lr=hp.decoder_lr, momentum=hp.momentum, nesterov=hp.nesterov)
+        elif hp.opt == "adam":
+            opt = torch.optim.Adam(params, lr=hp.decoder_lr, betas=(hp.adam_b1, hp.adam_b2))
+        elif hp.opt == "adamw":
+            opt = torch.optim.AdamW(params, lr=hp.decoder_lr, betas=(hp.adam_b1, hp.adam_b2))
+        else:
+            raise ValueError("opt=%r" % (hp.opt,))
+        self.opt_init_lr = [pg["lr"] for pg in opt.param_groups]
+        sched = getattr(hp, "scheduler", None)
+        if sched == "step":
+            self.scheduler = MultiStepLR(opt, milestones=hp.milestones, gamma=hp.lr_gamma)
+        elif sched == "plateau":
+            self.scheduler = ReduceLROnPlateau(opt, mode="max", factor=hp.lr_gamma, patience=hp.plateau_patience, min_lr=hp.min_lr)
+        elif sched == "exp":
+            self.scheduler = ExponentialLR(opt, gamma=hp.lr_gamma)
+        elif sched == "cosine":
+            adj = hp.epochs * hp.train_loader_len - hp.lr_warmup_steps
+            t0, tm = hp.cosine_iterations, hp.cosine_multi
+            if tm != 1:
+                restarts = math.floor(math.log(1 - (adj * (1 - tm) / t0)) / math.log(tm))
+                t0 = adj + hp.accumulate if restarts == 0 else math.ceil((adj + hp.accumulate) / ((1 - tm ** restarts) / (1 - tm)))
+            else:
+                restarts = math.floor(adj / t0)
+                t0 = adj + hp.accumulate if restarts == 0 else math.ceil((adj + hp.accumulate) / restarts)
+            self.scheduler = CosineAnnealingWarmRestarts(opt, T_0=int(t0), T_mult=int(tm), eta_min=hp.min_lr)
+        elif sched == "one_cycle":
+            hp.lr_warmup_steps = 0
+            self.scheduler = OneCycleLR(opt, self.opt_init_lr, epochs=hp.epochs, steps_per_epoch=hp.train_loader_len,
+                                        pct_start=hp.one_cycle_pct, cycle_momentum=False, div_factor=hp.one_cycle_div,
+                                        final_div_factor=hp.one_cycle_fdiv)
+        return opt

@@ -1,0 +1,106 @@
+"""GPU parity of the whole train step (encoder -> decoder -> losses -> backward) behind the reference's
+``SAT`` surface (train_batch / training_step / configure_optimizers) against the CPU oracle, plus the
+drop-in checks that do not need the reference at run time."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a = a.detach().cpu().double(); b = b.detach().cpu().double()
+    return float((a - b).abs().max()) / max(1.0, float(b.abs().max()))
+
+
+def make(hp_over=None, seed=42):
+    import sat_amd  # noqa: F401
+    from sat_amd import model as M
+    from oracle import sat_oracle as O
+    over = dict(encoder_arch="resnet18", encoder_dim=32, input_size=64, encoder_size=3, vocab_size=120, embed_dim=24,
+                attention_dim=16, decoder_dim=40, deep_output=True, weight_decay=0.0, decoder_lr=1e-3, embedding_lr=1e-2,
+                encoder_lr=1e-5, opt="adam", adam_b1=0.9, adam_b2=0.999, momentum=0.9, nesterov=False, scheduler=None)
+    over.update(hp_over or {})
+    hp = O.default_hparams(**over)
+    torch.manual_seed(seed)
+    model = M.SAT(**vars(hp))
+    oracle = O.OracleSAT(O.default_hparams(**over), {k: v.clone() for k, v in model.state_dict().items()})
+    return model.cuda().train(), oracle, hp
+
+
+def batch(hp, B=6, R=3, T=9, seed=5):
+    from oracle import prng
+    img = torch.from_numpy(prng.uniform((B, 3, hp.input_size, hp.input_size), seed, 0.0, 1.0))
+    caps, lengths = prng.captions(B, R, T, hp.vocab_size, seed + 1)
+    return img, torch.from_numpy(caps), torch.from_numpy(lengths)
+
+
+@pytest.mark.parametrize("eps", [1.0, 0.0])
+def test_training_step_matches_oracle(eps):
+    model, oracle, hp = make(dict(decoder_tf="always" if eps == 1.0 else None))
+    img, caps, lengths = batch(hp)
+    loss_o, out_o = oracle.step_loss(img, caps, lengths, eps)
+    loss_o.backward()
+    img_g = img.cuda()
+    metrics = model.training_step((img_g, caps.cuda(), lengths), 0)
+    assert torch.equal(img_g.cpu(), img), "the HIP encoder must not mutate its input (SURVEY F9)"
+    assert abs(metrics["loss"].item() - loss_o.item()) <= 1e-4 * max(1.0, abs(loss_o.item()))
+    assert abs(float(metrics["accuracy"]) - float(out_o["acc"])) < 1e-6
+    assert metrics["epsilon_tf"] == eps
+    lp, tp, alphas = model.train_batch((img_g, caps.cuda(), lengths), eps)
+    assert rel(lp.data, out_o["logits_packed"]) <= 2e-4 and rel(alphas, out_o["alphas"]) <= 1e-4
+    assert torch.equal(tp.data.cpu(), out_o["targets_packed"]) and lp.batch_sizes.tolist() == out_o["batch_sizes"]
+    padded, lens = torch.nn.utils.rnn.pad_packed_sequence(lp, batch_first=True)       # PackedSequence is well formed
+    assert lens.tolist() == lengths.reshape(-1).tolist() and padded.shape[0] == lengths.numel()
+    metrics["loss"].backward()
+    og = oracle.named_grads()
+    for k, p in model.named_parameters():
+        assert p.grad is not None, k
+        e = float((p.grad.cpu().double() - og[k].double()).norm()) / max(1e-9, float(og[k].double().norm()))
+        assert e <= 2e-2, "%s: relative L2 gradient error %.3e" % (k, e)        # fp32 through a batch-6 ResNet, see test_gpu_encoder
+    for k in ("attention.f_att.weight", "output.output.weight", "lstm.weight_hh_l0", "embedding.weight", "encoder.9.weight"):
+        p = dict(model.named_parameters())[k]
+        assert rel(p.grad, og[k]) <= 5e-4, k                                     # decoder-side and last-layer grads are tight
+
+
+def test_optimizer_groups_and_one_adam_step_follow_the_oracle():
+    model, oracle, hp = make(dict(encoder_finetune_after=1, decoder_tf="always"))
+    opt = model.configure_optimizers()
+    # model.py:723-746: decoder (no-decay, decay), embedding, encoder (no-decay, decay)
+    assert [len(g["params"]) > 0 for g in opt.param_groups] == [True] * 5
+    assert [g["lr"] for g in opt.param_groups] == [1e-3, 1e-3, 1e-2, 1e-5, 1e-5] and model.opt_init_lr == [1e-3, 1e-3, 1e-2, 1e-5, 1e-5]
+    img, caps, lengths = batch(hp)
+    params_o = oracle.parameters()
+    opt_o = torch.optim.Adam([{"params": [p for p in oracle.sd.values() if p is not oracle.sd["embedding.weight"]], "lr": 1e-3},
+                              {"params": [oracle.sd["embedding.weight"]], "lr": 1e-2},
+                              {"params": list(oracle.encoder.parameters()), "lr": 1e-5}])
+    for _ in range(2):
+        opt.zero_grad(); opt_o.zero_grad()
+        model.training_step((img.cuda(), caps.cuda(), lengths), 0)["loss"].backward()
+        oracle.step_loss(img, caps, lengths, 1.0)[0].backward()
+        opt.step(); opt_o.step()
+    sd = model.state_dict()
+    for k, v in oracle.sd.items():
+        assert rel(sd[k], v) <= 1e-3, k
+    l1 = model.training_step((img.cuda(), caps.cuda(), lengths), 0)["loss"].item()
+    l0 = oracle.step_loss(img, caps, lengths, 1.0)[0].item()
+    assert abs(l1 - l0) <= 2e-3 * max(1.0, abs(l0)), (l1, l0)
+    assert len(params_o) == len(list(model.parameters()))
+
+
+def test_frozen_encoder_and_state_dict_roundtrip():
+    model, oracle, hp = make()
+    for p in model.encoder.parameters():
+        p.requires_grad = False
+    img, caps, lengths = batch(hp)
+    model.training_step((img.cuda(), caps.cuda(), lengths), 0)["loss"].backward()
+    assert all(p.grad is None for p in model.encoder.parameters())
+    assert all(p.grad is not None for k, p in model.named_parameters() if not k.startswith("encoder."))
+    import sat_amd  # noqa
+    from sat_amd import model as M
+    clone = M.SAT(**vars(hp)).cuda()
+    clone.load_state_dict(model.state_dict())
+    clone.eval(); model.eval()
+    with torch.no_grad():
+        a, _ = model.encode(img.cuda()); b, _ = clone.encode(img.cuda())
+    assert torch.equal(a, b)
