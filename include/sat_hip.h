@@ -31,6 +31,19 @@ extern "C" {
 int sat_abi_version(void);
 const char* sat_last_error(void);
 
+/* ------------------------------------------------------------------ kernel timing for the roofline report
+ * Between start and stop every instrumented launch is bracketed by HIP events on its own stream; stop
+ * synchronises them and returns one entry per kernel family (process-wide; measurement runs only). */
+typedef struct sat_profile_entry {
+    char name[96];
+    int64_t launches;
+    double total_ms;      /* sum of event-measured durations          */
+    double flops;         /* algorithmic FLOPs of those launches       */
+    double bytes;         /* algorithmic bytes of those launches       */
+} sat_profile_entry;
+int sat_profile_start(void);
+int sat_profile_stop(sat_profile_entry* out, int32_t max_entries, int32_t* n_out);
+
 /* ------------------------------------------------------------------ GEMM family
  * C[MxN] = op(A)[MxK] * op(B)[KxN] on v_mfma_f32_32x32x2_f32.  Replaces nn.Linear
  * (model.py:72-73, 90-92, 119-123, 188) and its autograd.  amode/bmode/epi: enum values

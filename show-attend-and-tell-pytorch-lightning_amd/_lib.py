@@ -95,6 +95,26 @@ SYMBOLS.update({
 })
 
 
+class ProfileEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 96), ("launches", C.c_int64), ("total_ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+SYMBOLS.update({"sat_profile_start": (C.c_int, []),
+                "sat_profile_stop": (C.c_int, [C.POINTER(ProfileEntry), _i32, C.POINTER(C.c_int32)])})
+
+
+def profile_start():
+    check(lib().sat_profile_start(), "sat_profile_start")
+
+
+def profile_stop(max_entries=256):
+    buf = (ProfileEntry * max_entries)()
+    n = C.c_int32(0)
+    check(lib().sat_profile_stop(buf, max_entries, C.byref(n)), "sat_profile_stop")
+    return [dict(name=buf[i].name.decode(), launches=buf[i].launches, total_ms=buf[i].total_ms, flops=buf[i].flops, bytes=buf[i].bytes)
+            for i in range(n.value)]
+
+
 class SatHipError(RuntimeError):
     pass
 

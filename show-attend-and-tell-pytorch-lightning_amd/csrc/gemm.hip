@@ -12,6 +12,7 @@
 // buffer: the next tile's global loads are issued before the MFMAs of the current
 // one and written to the other LDS buffer afterwards (one barrier per k-tile).
 #include "gemm.h"
+#include "profile.h"
 
 namespace sat {
 
@@ -318,9 +319,21 @@ size_t gemm_slab_bytes(int M, int N, int K) {
     return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
 }
 
+static const char* mode_name(int am, int bm) {
+    if (am == A_CONV_FWD) return "conv_fwd";
+    if (am == A_CONV_DGRAD) return "conv_dgrad";
+    if (bm == B_CONV_WGRAD) return "conv_wgrad";
+    if (am == A_ROW && bm == B_ROW) return "nt";
+    if (am == A_ROW && bm == B_KMAJOR) return "nn";
+    return "tn";
+}
+
 template <int BM, int BN, int AM, int BMo>
 static int run(const KArgs& k, hipStream_t st) {
     dim3 grid(cdiv(k.N, BN), cdiv(k.M, BM), k.nsplit);
+    char pname[96];
+    if (profile_enabled()) snprintf(pname, sizeof pname, "gemm_f32_%s_%dx%d", mode_name(AM, BMo), BM, BN);
+    ProfScope prof(pname, 2.0 * k.M * k.N * k.K, 4.0 * ((double)k.M * k.K + (double)k.N * k.K + (double)k.M * k.N), st);
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AM, BMo>), grid, dim3(NTHREADS), 0, st, k);
     SAT_TRY(launch_ok("gemm_f32_kernel"));
     if (k.nsplit > 1) {
