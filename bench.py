@@ -67,7 +67,8 @@ def cpu_baseline(cfg, seconds_budget=30.0):
     from types import SimpleNamespace
     from oracle import sat_oracle as O
     hp, T, _, R = hparams(cfg)
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU's share of the host (16 cores); os.cpu_count() reports the whole machine
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("SAT_CPU_THREADS", "16")))
     torch.set_num_threads(cores)
     ns = SimpleNamespace(**hp)
     model = O.OracleSAT(ns, None, seed=42)
@@ -82,9 +83,11 @@ def cpu_baseline(cfg, seconds_budget=30.0):
         opt.step()
 
     step()
+    log("cpu baseline warm-up step done")
     t0 = time.time(); n = 0
     while True:
         step(); n += 1
+        log("cpu baseline step %d" % n)
         if time.time() - t0 > seconds_budget * 0.5 or n >= 3:
             break
     dt = (time.time() - t0) / n
@@ -92,6 +95,15 @@ def cpu_baseline(cfg, seconds_budget=30.0):
             "sample": "%d full train steps (fwd+loss+bwd+Adam, fp32) of the same model at batch %d images x %d captions after 1 warm-up; "
                       "oracle/sat_oracle.py on torch-CPU, %d threads" % (n, B, R, cores),
             "s_per_step": round(dt, 3)}
+
+
+_T0 = time.time()
+
+
+def log(msg):
+    """progress on stderr (the JSON line is the only thing on stdout)"""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench %7.1fs] %s" % (time.time() - _T0, msg), file=sys.stderr, flush=True)
 
 
 def main():
@@ -139,8 +151,10 @@ def main():
         opt.step()
         return out
 
-    for _ in range(args.warmup):
+    log("model built (%s, %d images/GPU); warm-up" % (args.config, B))
+    for i in range(args.warmup):
         out = step()
+        torch.cuda.synchronize(); log("warm-up step %d done" % i)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -156,6 +170,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     loss_val = float(out["loss"].item())
+    log("timed region: %.1f ms/step" % (dt / args.steps * 1e3))
 
     # ---- roofline of the dominant kernel: HIP events on the launch stream, two instrumented steps
     prof_steps = 2
@@ -193,7 +208,9 @@ def main():
                            "images_per_s": round(world * B / (dt / args.steps), 1), "final_loss": round(loss_val, 4)},
                 "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
+            log("CPU baseline (oracle) ...")
             line["cpu_baseline"] = cpu_baseline(args.config)
+            log("CPU baseline done")
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
