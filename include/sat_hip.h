@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SAT_HIP_ABI_VERSION 1
+#define SAT_HIP_ABI_VERSION 2
 
 int sat_abi_version(void);
 const char* sat_last_error(void);
@@ -60,6 +60,11 @@ typedef struct sat_gemm_desc {
     float* slab; int64_t slab_elems;   /* optional split-K scratch */
 } sat_gemm_desc;
 int sat_gemm_f32(const sat_gemm_desc* d, void* stream);
+/* Same contraction with explicit storage types and matrix-core choice: *_bf16 = operand stored as bf16 in HBM
+ * (pointers in the descriptor are then reinterpreted), bf16_mfma = use v_mfma_f32_32x32x16_bf16 with fp32
+ * accumulation (fp32 operands are rounded to bf16 on the way into LDS). */
+typedef struct sat_gemm_types { int32_t a_bf16, b_bf16, c_bf16, bf16_mfma; } sat_gemm_types;
+int sat_gemm_ex(const sat_gemm_desc* d, const sat_gemm_types* t, void* stream);
 
 /* ------------------------------------------------------------------ decoder (train_batch, model.py:474-557) */
 typedef struct sat_decoder_dims {
@@ -75,6 +80,7 @@ typedef struct sat_decoder_dims {
     int32_t P;            /* packed tokens = sum(lengths)                          */
     int32_t deep_output;  /* DeepOutput.deep (model.py:116)                        */
     int32_t padding_idx;  /* <PAD> id (model.py:162)                               */
+    int32_t precision;    /* 0: exact fp32 MFMA (parity mode); 1: bf16 MFMA, fp32 accumulate/state */
 } sat_decoder_dims;
 
 /* state-dict tensors of the decoder; used for weights and, with the same
@@ -160,6 +166,11 @@ int sat_conv2d_fwd(const float* x, const float* w, const float* bias /* or NULL 
 int sat_conv2d_dgrad(const float* dy, const float* w, float* dx, const sat_conv_geom* g, int32_t accumulate, void* stream);
 int sat_conv2d_wgrad(const float* dy, const float* x, float* dw, const sat_conv_geom* g, float* slab, int64_t slab_elems, void* stream);
 size_t sat_conv2d_wgrad_slab_bytes(const sat_conv_geom* g);
+/* bf16 storage variants (activations and filters bf16 in HBM, C % 8 == 0 and K % 8 == 0): bf16 MFMA, fp32
+ * accumulation; the weight gradient is produced in fp32 (master weights stay fp32). */
+int sat_conv2d_fwd_bf16(const void* x, const void* w, const float* bias, void* y, const sat_conv_geom* g, void* stream);
+int sat_conv2d_dgrad_bf16(const void* dy, const void* w, void* dx, const sat_conv_geom* g, int32_t accumulate, void* stream);
+int sat_conv2d_wgrad_bf16(const void* dy, const void* x, float* dw, const sat_conv_geom* g, float* slab, int64_t slab_elems, void* stream);
 /* torchvision Normalize(mean, std) (model.py:59) fused with NCHW -> NHWC and 3 -> 4 channel padding */
 int sat_image_normalize_nhwc4(const float* img_nchw, float* out_nhwc4, int32_t N, int32_t H, int32_t W,
                               const float* mean3_host, const float* std3_host, void* stream);

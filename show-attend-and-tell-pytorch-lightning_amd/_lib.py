@@ -23,7 +23,7 @@ class GemmDesc(C.Structure):
 
 
 class DecoderDims(C.Structure):
-    _fields_ = [(k, C.c_int32) for k in ("B", "R", "T", "L", "D", "A", "m", "n", "V", "P", "deep_output", "padding_idx")]
+    _fields_ = [(k, C.c_int32) for k in ("B", "R", "T", "L", "D", "A", "m", "n", "V", "P", "deep_output", "padding_idx", "precision")]
 
 
 PARAM_FIELDS = ("embedding", "init_f_w", "init_f_b", "init_i_w", "init_i_b", "w_ih", "w_hh", "b_ih", "b_hh",
@@ -71,6 +71,10 @@ SYMBOLS = {
 }
 
 
+class GemmTypes(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("a_bf16", "b_bf16", "c_bf16", "bf16_mfma")]
+
+
 class ConvGeom(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("N", "H", "W", "C", "K", "R", "S", "stride", "pad")]
 
@@ -81,6 +85,10 @@ SYMBOLS.update({
     "sat_conv2d_dgrad": (C.c_int, [_vp, _vp, _vp, C.POINTER(ConvGeom), _i32, _vp]),
     "sat_conv2d_wgrad": (C.c_int, [_vp, _vp, _vp, C.POINTER(ConvGeom), _vp, _i64, _vp]),
     "sat_conv2d_wgrad_slab_bytes": (C.c_size_t, [C.POINTER(ConvGeom)]),
+    "sat_conv2d_fwd_bf16": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(ConvGeom), _vp]),
+    "sat_conv2d_dgrad_bf16": (C.c_int, [_vp, _vp, _vp, C.POINTER(ConvGeom), _i32, _vp]),
+    "sat_conv2d_wgrad_bf16": (C.c_int, [_vp, _vp, _vp, C.POINTER(ConvGeom), _vp, _i64, _vp]),
+    "sat_gemm_ex": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(GemmTypes), _vp]),
     "sat_image_normalize_nhwc4": (C.c_int, [_vp, _vp, _i32, _i32, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp]),
     "sat_pad_channels_3to4": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "sat_bn_scratch_bytes": (C.c_size_t, [_i64, _i32]),
@@ -130,8 +138,8 @@ def lib():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(handle, name)          # AttributeError if the export is missing
             fn.restype, fn.argtypes = res, args
-        if handle.sat_abi_version() != 1:
-            raise SatHipError("libsat_hip.so ABI version %d != 1" % handle.sat_abi_version())
+        if handle.sat_abi_version() != 2:
+            raise SatHipError("libsat_hip.so ABI version %d != 2 (rebuild: make -C csrc)" % handle.sat_abi_version())
         _lib = handle
     return _lib
 

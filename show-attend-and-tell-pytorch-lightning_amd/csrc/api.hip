@@ -21,7 +21,13 @@ extern "C" {
 int sat_abi_version(void) { return SAT_HIP_ABI_VERSION; }
 const char* sat_last_error(void) { return last_error_buf(); }
 
-int sat_gemm_f32(const sat_gemm_desc* d, void* stream) {
+static int gemm_from_desc(const sat_gemm_desc* d, const sat_gemm_types* t, void* stream);
+int sat_gemm_f32(const sat_gemm_desc* d, void* stream) { return gemm_from_desc(d, nullptr, stream); }
+int sat_gemm_ex(const sat_gemm_desc* d, const sat_gemm_types* t, void* stream) {
+    if (!t) return fail(SAT_EINVAL, "sat_gemm_ex: null type descriptor");
+    return gemm_from_desc(d, t, stream);
+}
+static int gemm_from_desc(const sat_gemm_desc* d, const sat_gemm_types* t, void* stream) {
     if (!d) return fail(SAT_EINVAL, "sat_gemm_f32: null descriptor");
     if (d->amode != A_ROW && d->amode != A_KMAJOR) return fail(SAT_EINVAL, "sat_gemm_f32: amode %d (dense modes only)", d->amode);
     if (d->bmode != B_ROW && d->bmode != B_KMAJOR) return fail(SAT_EINVAL, "sat_gemm_f32: bmode %d (dense modes only)", d->bmode);
@@ -29,6 +35,7 @@ int sat_gemm_f32(const sat_gemm_desc* d, void* stream) {
     g.A = d->A; g.lda = d->lda; g.a_rows = d->a_rows; g.B = d->B; g.ldb = d->ldb; g.C = d->C; g.ldc = d->ldc; g.c_rows = d->c_rows;
     g.M = d->M; g.N = d->N; g.K = d->K; g.amode = d->amode; g.bmode = d->bmode; g.accumulate = d->accumulate; g.epi = d->epi;
     g.bias = d->bias; g.e0 = d->e0; g.lde0 = d->lde0; g.c0 = d->c0; g.c1 = d->c1; g.slab = d->slab; g.slab_elems = d->slab_elems;
+    if (t) { g.a_bf16 = t->a_bf16; g.b_bf16 = t->b_bf16; g.c_bf16 = t->c_bf16; g.bf16_mfma = t->bf16_mfma; }
     return launch_gemm(g, (hipStream_t)stream);
 }
 

@@ -70,6 +70,7 @@ int check_dims(const sat_decoder_dims* d) {
 }
 
 // ------------------------------------------------------------------ small launch helpers
+static thread_local int t_bf16_mfma = 0;      // set per call from sat_decoder_dims.precision
 static int gemm(hipStream_t st, int amode, int bmode, const float* A, long lda, const float* B, long ldb, float* C, long ldc,
                 int M, int N, int K, int acc = 0, int epi = EPI_NONE, const float* bias = nullptr, const int* a_rows = nullptr,
                 const int* c_rows = nullptr, const float* e0 = nullptr, long lde0 = 0, int c0 = 0, int c1 = 0, float* slab = nullptr, long slab_elems = 0) {
@@ -77,6 +78,7 @@ static int gemm(hipStream_t st, int amode, int bmode, const float* A, long lda, 
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.amode = amode; g.bmode = bmode; g.accumulate = acc; g.epi = epi; g.bias = bias; g.a_rows = a_rows; g.c_rows = c_rows;
     g.e0 = e0; g.lde0 = lde0; g.c0 = c0; g.c1 = c1; g.slab = slab; g.slab_elems = slab_elems;
+    g.bf16_mfma = t_bf16_mfma;
     return launch_gemm(g, st);
 }
 
@@ -140,6 +142,7 @@ static int flush_outputs(hipStream_t st, const sat_decoder_dims& d, const sat_de
 int decoder_fwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sat_decoder_batch& b, float* logits, float* alphas,
                        char* ws, size_t ws_bytes, hipStream_t st) {
     Ws w = layout(d, ws);
+    t_bf16_mfma = d.precision ? 1 : 0;
     SAT_REQUIRE(ws_bytes >= w.total, "decoder_fwd: workspace %zu < %zu bytes", ws_bytes, w.total);
     SAT_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, "decoder: workspace must be 256-byte aligned");
     const int N = d.B * d.R, T1 = d.T - 1, HCW = d.A + d.D + 4 * d.n, n = d.n, A = d.A, D = d.D, m = d.m;
@@ -213,6 +216,7 @@ int decoder_fwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
 int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sat_decoder_batch& b, const float* dlogits,
                        const float* alphas, const float* dalphas, const sat_decoder_params& g, float* dann, char* ws, size_t ws_bytes, hipStream_t st) {
     Ws w = layout(d, ws);
+    t_bf16_mfma = d.precision ? 1 : 0;
     SAT_REQUIRE(ws_bytes >= w.total, "decoder_bwd: workspace %zu < %zu bytes", ws_bytes, w.total);
     const int N = d.B * d.R, T1 = d.T - 1, HCW = d.A + d.D + 4 * d.n, n = d.n, A = d.A, D = d.D, m = d.m, V = d.V, P = d.P;
     const int ts = live_steps(d, b);

@@ -278,22 +278,22 @@ __global__ void bilinear_bwd_kernel(const float* __restrict__ dy, float* __restr
 
 using namespace sat;
 
-static int conv_geom(const sat_conv_geom* g, ConvGeom& o) {
+static int conv_geom(const sat_conv_geom* g, ConvGeom& o, int vec = 4) {
     SAT_REQUIRE(g, "conv: null geometry");
     o.N = g->N; o.H = g->H; o.W = g->W; o.C = g->C; o.K = g->K; o.R = g->R; o.S = g->S; o.stride = g->stride; o.pad = g->pad;
     SAT_REQUIRE(o.N > 0 && o.H > 0 && o.W > 0 && o.C > 0 && o.K > 0 && o.R > 0 && o.S > 0 && o.stride > 0 && o.pad >= 0, "conv: bad geometry");
     o.P = (o.H + 2 * o.pad - o.R) / o.stride + 1; o.Q = (o.W + 2 * o.pad - o.S) / o.stride + 1;
     SAT_REQUIRE(o.P > 0 && o.Q > 0, "conv: empty output");
-    SAT_REQUIRE(o.C % 4 == 0 && o.K % 4 == 0, "conv: C=%d and K=%d must be multiples of 4 (pad the stem to 4 channels)", o.C, o.K);
+    SAT_REQUIRE(o.C % vec == 0 && o.K % vec == 0, "conv: C=%d and K=%d must be multiples of %d (pad the stem channels)", o.C, o.K, vec);
     return SAT_OK;
 }
 
 extern "C" {
 
-int sat_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, const sat_conv_geom* geom, void* stream) {
-    ConvGeom g; SAT_TRY(conv_geom(geom, g));
+static int conv_fwd_any(const void* x, const void* w, const float* bias, void* y, const sat_conv_geom* geom, int bf16, void* stream) {
+    ConvGeom g; SAT_TRY(conv_geom(geom, g, bf16 ? 8 : 4));
     if (!x || !w || !y) return fail(SAT_EINVAL, "conv2d_fwd: null pointer");
-    GemmArgs a;
+    GemmArgs a; a.a_bf16 = a.b_bf16 = a.c_bf16 = a.bf16_mfma = bf16;
     a.M = g.N * g.P * g.Q; a.N = g.K; a.K = g.R * g.S * g.C;
     a.B = w; a.ldb = a.K; a.bmode = B_ROW; a.C = y; a.ldc = g.K; a.g = g;
     if (g.R == 1 && g.S == 1 && g.stride == 1 && g.pad == 0) { a.A = x; a.lda = g.C; a.amode = A_ROW; }   // 1x1: a plain GEMM over pixels
@@ -301,11 +301,17 @@ int sat_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
     if (bias) { a.epi = EPI_BIAS; a.bias = bias; }
     return launch_gemm(a, (hipStream_t)stream);
 }
+int sat_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, const sat_conv_geom* geom, void* stream) {
+    return conv_fwd_any(x, w, bias, y, geom, 0, stream);
+}
+int sat_conv2d_fwd_bf16(const void* x, const void* w, const float* bias, void* y, const sat_conv_geom* geom, void* stream) {
+    return conv_fwd_any(x, w, bias, y, geom, 1, stream);
+}
 
-int sat_conv2d_dgrad(const float* dy, const float* w, float* dx, const sat_conv_geom* geom, int accumulate, void* stream) {
-    ConvGeom g; SAT_TRY(conv_geom(geom, g));
+static int conv_dgrad_any(const void* dy, const void* w, void* dx, const sat_conv_geom* geom, int accumulate, int bf16, void* stream) {
+    ConvGeom g; SAT_TRY(conv_geom(geom, g, bf16 ? 8 : 4));
     if (!dy || !w || !dx) return fail(SAT_EINVAL, "conv2d_dgrad: null pointer");
-    GemmArgs a;
+    GemmArgs a; a.a_bf16 = a.b_bf16 = a.c_bf16 = a.bf16_mfma = bf16;
     a.accumulate = accumulate; a.C = dx; a.ldc = g.C; a.g = g;
     if (g.R == 1 && g.S == 1 && g.stride == 1 && g.pad == 0) {
         a.M = g.N * g.H * g.W; a.N = g.C; a.K = g.K; a.A = dy; a.lda = g.K; a.amode = A_ROW; a.B = w; a.ldb = g.C; a.bmode = B_KMAJOR;
@@ -314,16 +320,28 @@ int sat_conv2d_dgrad(const float* dy, const float* w, float* dx, const sat_conv_
     }
     return launch_gemm(a, (hipStream_t)stream);
 }
+int sat_conv2d_dgrad(const float* dy, const float* w, float* dx, const sat_conv_geom* geom, int accumulate, void* stream) {
+    return conv_dgrad_any(dy, w, dx, geom, accumulate, 0, stream);
+}
+int sat_conv2d_dgrad_bf16(const void* dy, const void* w, void* dx, const sat_conv_geom* geom, int accumulate, void* stream) {
+    return conv_dgrad_any(dy, w, dx, geom, accumulate, 1, stream);
+}
 
-int sat_conv2d_wgrad(const float* dy, const float* x, float* dw, const sat_conv_geom* geom, float* slab, int64_t slab_elems, void* stream) {
-    ConvGeom g; SAT_TRY(conv_geom(geom, g));
+static int conv_wgrad_any(const void* dy, const void* x, float* dw, const sat_conv_geom* geom, float* slab, int64_t slab_elems, int bf16, void* stream) {
+    ConvGeom g; SAT_TRY(conv_geom(geom, g, bf16 ? 8 : 4));
     if (!dy || !x || !dw) return fail(SAT_EINVAL, "conv2d_wgrad: null pointer");
-    GemmArgs a;
+    GemmArgs a; a.a_bf16 = a.b_bf16 = a.bf16_mfma = bf16; a.c_bf16 = 0;
     a.M = g.K; a.N = g.R * g.S * g.C; a.K = g.N * g.P * g.Q;
     a.A = dy; a.lda = g.K; a.amode = A_KMAJOR; a.C = dw; a.ldc = a.N; a.g = g; a.slab = slab; a.slab_elems = slab_elems;
     if (g.R == 1 && g.S == 1 && g.stride == 1 && g.pad == 0) { a.B = x; a.ldb = g.C; a.bmode = B_KMAJOR; }
     else { a.B = x; a.bmode = B_CONV_WGRAD; }
     return launch_gemm(a, (hipStream_t)stream);
+}
+int sat_conv2d_wgrad(const float* dy, const float* x, float* dw, const sat_conv_geom* geom, float* slab, int64_t slab_elems, void* stream) {
+    return conv_wgrad_any(dy, x, dw, geom, slab, slab_elems, 0, stream);
+}
+int sat_conv2d_wgrad_bf16(const void* dy, const void* x, float* dw, const sat_conv_geom* geom, float* slab, int64_t slab_elems, void* stream) {
+    return conv_wgrad_any(dy, x, dw, geom, slab, slab_elems, 1, stream);
 }
 
 size_t sat_conv2d_wgrad_slab_bytes(const sat_conv_geom* geom) {

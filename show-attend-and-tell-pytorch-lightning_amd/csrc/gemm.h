@@ -37,9 +37,11 @@ struct ConvGeom {
 };
 
 struct GemmArgs {
-    const float* A = nullptr; long lda = 0; const int* a_rows = nullptr;
-    const float* B = nullptr; long ldb = 0;
-    float* C = nullptr;       long ldc = 0; const int* c_rows = nullptr;
+    const void* A = nullptr; long lda = 0; const int* a_rows = nullptr;
+    const void* B = nullptr; long ldb = 0;
+    void* C = nullptr;        long ldc = 0; const int* c_rows = nullptr;
+    int a_bf16 = 0, b_bf16 = 0, c_bf16 = 0;   // element type in HBM (0 = fp32, 1 = bf16)
+    int bf16_mfma = 0;                        // 1: v_mfma_f32_32x32x16_bf16 (gemm_bf16.hip), 0: exact fp32 MFMA
     int M = 0, N = 0, K = 0;
     int amode = A_ROW, bmode = B_ROW;
     int accumulate = 0;                       // C += result (applied before the epilogue function)
@@ -51,8 +53,11 @@ struct GemmArgs {
     float* slab = nullptr; long slab_elems = 0;   // split-K scratch (optional)
 };
 
-// Launches on `stream`; returns SAT_OK or sets last_error.
+// Launches on `stream`; returns SAT_OK or sets last_error.  bf16_mfma requests fall back to the exact fp32
+// kernel when the operands are fp32 but not 16-byte gatherable (tiny / odd test shapes).
 int launch_gemm(const GemmArgs& a, hipStream_t stream);
+int launch_gemm_bf16(const GemmArgs& a, hipStream_t stream);
+int gemm_bf16_eligible(const GemmArgs& a);
 // Bytes of split-K scratch that lets launch_gemm fill the chip for this shape (0 = none needed).
 size_t gemm_slab_bytes(int M, int N, int K);
 

@@ -354,9 +354,11 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
     SAT_REQUIRE(g.M >= 0 && g.N >= 0 && g.K >= 0, "gemm: negative dims");
     if (g.M == 0 || g.N == 0) return SAT_OK;
     SAT_REQUIRE(g.A && g.B && g.C, "gemm: null operand");
+    if (g.bf16_mfma && gemm_bf16_eligible(g)) return launch_gemm_bf16(g, st);
+    SAT_REQUIRE(!g.a_bf16 && !g.b_bf16 && !g.c_bf16, "gemm: bf16 operands need the bf16 MFMA kernel (16-byte gatherable shapes)");
     KArgs k;
-    k.A = g.A; k.lda = g.lda; k.a_rows = g.a_rows; k.B = g.B; k.ldb = g.ldb;
-    k.C = g.C; k.ldc = g.ldc; k.c_rows = g.c_rows; k.M = g.M; k.N = g.N; k.K = g.K;
+    k.A = (const float*)g.A; k.lda = g.lda; k.a_rows = g.a_rows; k.B = (const float*)g.B; k.ldb = g.ldb;
+    k.C = (float*)g.C; k.ldc = g.ldc; k.c_rows = g.c_rows; k.M = g.M; k.N = g.N; k.K = g.K;
     k.accumulate = g.accumulate; k.epi = g.epi; k.bias = g.bias; k.e0 = g.e0; k.lde0 = g.lde0;
     k.c0 = g.c0; k.c1 = g.c1; k.g = g.g; k.slab = g.slab;
     if ((g.epi == EPI_BIAS || g.epi == EPI_BIAS_RELU) && !g.bias) return fail(SAT_EINVAL, "gemm: bias epilogue without bias");

@@ -1,0 +1,385 @@
+// bf16 MFMA GEMM / implicit GEMM for gfx950 (v_mfma_f32_32x32x16_bf16, fp32 accumulate).
+//
+// Same operand modes as gemm.hip, 16x the matrix-core rate.  Operands may live in HBM as bf16
+// (encoder activations / filter copies) or fp32 (decoder state and weights: rounded to bf16 on
+// the way into LDS); results are written as bf16 or fp32.
+//
+// LDS images (bf16):
+//   k-contiguous operand  -> [row][32 + 8]   one ds_read_b128 per 32-row x 16-k fragment,
+//                                            80-byte rows => conflict free
+//   k-major operand       -> [k][rows + 32]  kept as loaded (16-byte writes); fragments come from
+//                                            two ds_read_b64_tr_b16 (hardware transpose), row stride
+//                                            = 64 B mod 256 B => the 4 rows of a block hit disjoint banks
+// Block = 256 threads (2 x 2 waves), tile BM x BN x 32, register-staged double buffer.
+#include "gemm.h"
+#include "profile.h"
+
+namespace sat {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int KB = 32;          // k-tile
+constexpr int NT = 256;
+
+struct BArgs {
+    const void* A; long lda; const int* a_rows;
+    const void* B; long ldb;
+    void* C; long ldc; const int* c_rows;
+    int M, N, K;
+    int accumulate, epi;
+    const float* bias; const float* e0; long lde0; int c0, c1;
+    ConvGeom g;
+    int kchunk, nsplit;
+    float* slab;
+};
+
+template <typename T> struct VecN { static constexpr int n = 16 / sizeof(T); };
+
+__device__ __forceinline__ float ep_value(const BArgs& a, int row, int col, float v) {
+    switch (a.epi) {
+        case EPI_BIAS: v += a.bias[col]; break;
+        case EPI_BIAS_SIGMOID_RANGE:
+            if (a.bias) v += a.bias[col];
+            if (col >= a.c0 && col < a.c1) v = fast_sigmoid(v);
+            break;
+        case EPI_ADD_TANH: { long er = a.a_rows ? (long)a.a_rows[row] : (long)row; v = fast_tanh(v + a.e0[er * a.lde0 + col]); } break;
+        case EPI_MUL_DTANH: { float u = a.e0[(long)row * a.lde0 + col]; v *= (1.0f - u * u); } break;
+        case EPI_BIAS_RELU: v = fmaxf(0.0f, v + a.bias[col]); break;
+        default: break;
+    }
+    return v;
+}
+
+template <typename TC>
+__device__ __forceinline__ void put(const BArgs& a, int row, int col, float v) {
+    long orow = row;
+    if (a.c_rows) { int r = a.c_rows[row]; if (r < 0) return; orow = r; }
+    TC* p = reinterpret_cast<TC*>(a.C) + orow * a.ldc + col;
+    if (a.accumulate) v += (float)*p;
+    *p = (TC)ep_value(a, row, col, v);
+}
+
+// ---- 16-byte gathers (raw bits; zero when out of range) ---------------------------------------
+struct RowCtx { long base; int n, y0, x0; bool ok; };
+
+template <int AM>
+__device__ __forceinline__ void row_setup(const BArgs& a, int m, RowCtx& c) {
+    c.ok = m < a.M; c.base = 0; c.n = c.y0 = c.x0 = 0;
+    if (!c.ok) return;
+    if (AM == A_ROW) {
+        long r = m;
+        if (a.a_rows) { int g = a.a_rows[m]; if (g < 0) { c.ok = false; return; } r = g; }
+        c.base = r * a.lda;
+    } else if (AM == A_CONV_FWD) {
+        const ConvGeom& g = a.g;
+        int pq = g.P * g.Q; c.n = m / pq; int r = m - c.n * pq; int p = r / g.Q, q = r - p * g.Q;
+        c.y0 = p * g.stride - g.pad; c.x0 = q * g.stride - g.pad;
+    } else {
+        const ConvGeom& g = a.g;
+        int hw = g.H * g.W; c.n = m / hw; int r = m - c.n * hw; int h = r / g.W, w = r - h * g.W;
+        c.y0 = h + g.pad; c.x0 = w + g.pad;
+    }
+}
+
+template <int AM, typename T>
+__device__ __forceinline__ uint4 row_fetch(const BArgs& a, const RowCtx& c, int k, int kend) {
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    if (!c.ok || k >= kend) return z;
+    const T* A = reinterpret_cast<const T*>(a.A);
+    if (AM == A_ROW) return *reinterpret_cast<const uint4*>(A + c.base + k);
+    const ConvGeom& g = a.g;
+    if (AM == A_CONV_FWD) {
+        int rs = k / g.C, ch = k - rs * g.C; int r = rs / g.S, s = rs - r * g.S;
+        int y = c.y0 + r, x = c.x0 + s;
+        if ((unsigned)y >= (unsigned)g.H || (unsigned)x >= (unsigned)g.W) return z;
+        return *reinterpret_cast<const uint4*>(A + (((long)c.n * g.H + y) * g.W + x) * g.C + ch);
+    }
+    int rs = k / g.K, ko = k - rs * g.K; int r = rs / g.S, s = rs - r * g.S;
+    int ty = c.y0 - r, tx = c.x0 - s;
+    if (ty < 0 || tx < 0) return z;
+    int p = ty / g.stride, q = tx / g.stride;
+    if (p * g.stride != ty || q * g.stride != tx || p >= g.P || q >= g.Q) return z;
+    return *reinterpret_cast<const uint4*>(A + (((long)c.n * g.P + p) * g.Q + q) * g.K + ko);
+}
+
+template <typename T>
+__device__ __forceinline__ uint4 brow_fetch(const BArgs& a, int n, int k, int kend) {
+    if (n >= a.N || k >= kend) return make_uint4(0, 0, 0, 0);
+    return *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(a.B) + (long)n * a.ldb + k);
+}
+
+template <typename T>
+__device__ __forceinline__ uint4 kmajor_fetch(const void* base, long ld, int k, int kend, int j, int J) {
+    if (k >= kend || j >= J) return make_uint4(0, 0, 0, 0);
+    return *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(base) + (long)k * ld + j);
+}
+
+struct ColCtx { int r, s, ch; bool ok; };
+
+template <int BMo, typename T>
+__device__ __forceinline__ uint4 bk_fetch(const BArgs& a, const ColCtx& c, int n, int k, int kend) {
+    if (BMo == B_KMAJOR) return kmajor_fetch<T>(a.B, a.ldb, k, kend, n, a.N);
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    if (!c.ok || k >= kend) return z;
+    const ConvGeom& g = a.g;
+    const T* B = reinterpret_cast<const T*>(a.B);
+    if (BMo == B_CONV_WGRAD) {
+        int pq = g.P * g.Q; int img = k / pq; int rem = k - img * pq; int p = rem / g.Q, q = rem - p * g.Q;
+        int y = p * g.stride - g.pad + c.r, x = q * g.stride - g.pad + c.s;
+        if ((unsigned)y >= (unsigned)g.H || (unsigned)x >= (unsigned)g.W) return z;
+        return *reinterpret_cast<const uint4*>(B + (((long)img * g.H + y) * g.W + x) * g.C + c.ch);
+    }
+    int rs = k / g.K, ko = k - rs * g.K; int r = rs / g.S, s = rs - r * g.S;
+    return *reinterpret_cast<const uint4*>(B + (((long)ko * g.R + r) * g.S + s) * g.C + n);
+}
+
+// raw 16 bytes -> bf16 in LDS.  bf16 source: 8 elements (ds_write_b128); fp32 source: 4 elements (ds_write_b64)
+template <typename T>
+__device__ __forceinline__ void lds_put(__bf16* dst, const uint4& raw) {
+    if (sizeof(T) == 2) { *reinterpret_cast<uint4*>(dst) = raw; }
+    else {
+        bf16x4 o;
+        o[0] = (__bf16)__uint_as_float(raw.x); o[1] = (__bf16)__uint_as_float(raw.y);
+        o[2] = (__bf16)__uint_as_float(raw.z); o[3] = (__bf16)__uint_as_float(raw.w);
+        *reinterpret_cast<bf16x4*>(dst) = o;
+    }
+}
+
+template <int BM, int BN, int AM, int BMo, typename TA, typename TB, typename TC>
+__global__ __launch_bounds__(NT) void gemm_bf16_kernel(BArgs a) {
+    constexpr bool AK = (AM == A_KMAJOR);
+    constexpr bool BKM = (BMo != B_ROW);
+    constexpr int LDR = KB + 8;                  // k-contiguous rows
+    constexpr int LDA_K = BM + 32, LDB_K = BN + 32;   // k-major rows
+    constexpr int A_EL = AK ? KB * LDA_K : BM * LDR;
+    constexpr int B_EL = BKM ? KB * LDB_K : BN * LDR;
+    constexpr int STAGE = A_EL + B_EL;
+    constexpr int VA = VecN<TA>::n, VB = VecN<TB>::n;
+    constexpr int NVA = BM * KB / VA / NT, NVB = BN * KB / VB / NT;
+    constexpr int TM = BM / 64, TN = BN / 64;
+    __shared__ __attribute__((aligned(16))) __bf16 smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bm = blockIdx.y * BM, bn = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * a.kchunk;
+    const int kend = min(a.K, kbeg + a.kchunk);
+    const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
+    const int li = lane & 31, lh = lane >> 5;
+    // transposed-read lane roles (ds_read_b64_tr_b16): 16-lane group g -> (k half, row half)
+    const int tg = lane >> 4, ti = lane & 15;
+    const int t_h = tg >> 1, t_mh = tg & 1, t_q = ti >> 2, t_p = ti & 3;
+
+    RowCtx actx[NVA]; int a0[NVA], a1[NVA];
+    ColCtx bctx[NVB]; int b0[NVB], b1[NVB];
+#pragma unroll
+    for (int j = 0; j < NVA; ++j) {
+        int v = tid + j * NT;
+        if (!AK) { a0[j] = v / (KB / VA); a1[j] = (v % (KB / VA)) * VA; row_setup<AM>(a, bm + a0[j], actx[j]); }
+        else { a0[j] = v / (BM / VA); a1[j] = (v % (BM / VA)) * VA; }
+    }
+#pragma unroll
+    for (int j = 0; j < NVB; ++j) {
+        int v = tid + j * NT;
+        if (!BKM) { b0[j] = v / (KB / VB); b1[j] = (v % (KB / VB)) * VB; }
+        else {
+            b0[j] = v / (BN / VB); b1[j] = (v % (BN / VB)) * VB;
+            int n = bn + b1[j];
+            bctx[j].ok = n < a.N; bctx[j].r = bctx[j].s = bctx[j].ch = 0;
+            if (BMo == B_CONV_WGRAD && bctx[j].ok) { int rs = n / a.g.C; bctx[j].ch = n - rs * a.g.C; bctx[j].r = rs / a.g.S; bctx[j].s = rs - bctx[j].r * a.g.S; }
+        }
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    uint4 ra[NVA], rb[NVB];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < NVA; ++j)
+            ra[j] = AK ? kmajor_fetch<TA>(a.A, a.lda, k0 + a0[j], kend, bm + a1[j], a.M) : row_fetch<AM, TA>(a, actx[j], k0 + a1[j], kend);
+#pragma unroll
+        for (int j = 0; j < NVB; ++j)
+            rb[j] = BKM ? bk_fetch<BMo, TB>(a, bctx[j], bn + b1[j], k0 + b0[j], kend) : brow_fetch<TB>(a, bn + b0[j], k0 + b1[j], kend);
+    };
+    auto stash = [&](int buf) {
+        __bf16* as = smem + buf * STAGE; __bf16* bs = as + A_EL;
+#pragma unroll
+        for (int j = 0; j < NVA; ++j) lds_put<TA>(as + (AK ? a0[j] * LDA_K + a1[j] : a0[j] * LDR + a1[j]), ra[j]);
+#pragma unroll
+        for (int j = 0; j < NVB; ++j) lds_put<TB>(bs + (BKM ? b0[j] * LDB_K + b1[j] : b0[j] * LDR + b1[j]), rb[j]);
+    };
+
+    int cur = 0;
+    if (kbeg < kend) {
+        fetch(kbeg);
+        stash(0);
+        __syncthreads();
+        for (int k0 = kbeg; k0 < kend; k0 += KB) {
+            const bool more = (k0 + KB) < kend;
+            if (more) fetch(k0 + KB);
+            const __bf16* as = smem + cur * STAGE;
+            const __bf16* bs = as + A_EL;
+#pragma unroll
+            for (int kk = 0; kk < KB; kk += 16) {
+                bf16x8 af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    if (!AK) af[i] = *reinterpret_cast<const bf16x8*>(as + (wm + i * 32 + li) * LDR + kk + 8 * lh);
+                    else {
+                        const __bf16* p = as + (kk + 8 * t_h + t_q) * LDA_K + wm + i * 32 + 16 * t_mh + 4 * t_p;
+                        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
+                        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p + 4 * LDA_K));
+                        af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (!BKM) bf[j] = *reinterpret_cast<const bf16x8*>(bs + (wn + j * 32 + li) * LDR + kk + 8 * lh);
+                    else {
+                        const __bf16* p = bs + (kk + 8 * t_h + t_q) * LDB_K + wn + j * 32 + 16 * t_mh + 4 * t_p;
+                        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
+                        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p + 4 * LDB_K));
+                        bf[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+            if (more) stash(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = bm + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                int col = bn + wn + j * 32 + li;
+                if (row < a.M && col < a.N) {
+                    if (a.nsplit > 1) a.slab[((long)blockIdx.z * a.M + row) * a.N + col] = acc[i][j][r];
+                    else put<TC>(a, row, col, acc[i][j][r]);
+                }
+            }
+}
+
+template <typename TC>
+__global__ void splitk_reduce_b_kernel(BArgs a) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)a.M * a.N;
+    if (idx >= total) return;
+    float v = 0.f;
+    for (int z = 0; z < a.nsplit; ++z) v += a.slab[(long)z * total + idx];
+    put<TC>(a, (int)(idx / a.N), (int)(idx % a.N), v);
+}
+
+static const char* mname(int am, int bm) {
+    if (am == A_CONV_FWD) return "conv_fwd";
+    if (am == A_CONV_DGRAD) return "conv_dgrad";
+    if (bm == B_CONV_WGRAD) return "conv_wgrad";
+    if (am == A_ROW && bm == B_ROW) return "nt";
+    if (am == A_ROW && bm == B_KMAJOR) return "nn";
+    return "tn";
+}
+
+template <int BM, int BN, int AM, int BMo, typename TA, typename TB, typename TC>
+static int runb(const BArgs& k, hipStream_t st) {
+    dim3 grid(cdiv(k.N, BN), cdiv(k.M, BM), k.nsplit);
+    char pname[96];
+    if (profile_enabled()) snprintf(pname, sizeof pname, "gemm_bf16_%s_%dx%d_%s", mname(AM, BMo), BM, BN, sizeof(TA) == 2 ? "b" : "f");
+    ProfScope prof(pname, 2.0 * k.M * k.N * k.K, (double)sizeof(TA) * k.M * k.K + (double)sizeof(TB) * k.N * k.K + (double)sizeof(TC) * k.M * k.N, st);
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, AM, BMo, TA, TB, TC>), grid, dim3(NT), 0, st, k);
+    SAT_TRY(launch_ok("gemm_bf16_kernel"));
+    if (k.nsplit > 1) {
+        long total = (long)k.M * k.N;
+        hipLaunchKernelGGL(splitk_reduce_b_kernel<TC>, dim3(cdiv(total, 256)), dim3(256), 0, st, k);
+        SAT_TRY(launch_ok("splitk_reduce_b"));
+    }
+    return SAT_OK;
+}
+
+template <int AM, int BMo, typename TA, typename TB, typename TC>
+static int runb_tiles(const BArgs& k, int BMt, hipStream_t st) {
+    if (BMt == 128) return runb<128, 128, AM, BMo, TA, TB, TC>(k, st);
+    return runb<64, 64, AM, BMo, TA, TB, TC>(k, st);
+}
+
+static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// 1 when the bf16-MFMA kernel can take this problem (16-byte gathers need aligned, divisible extents)
+int gemm_bf16_eligible(const GemmArgs& g) {
+    const int va = g.a_bf16 ? 8 : 4, vb = g.b_bf16 ? 8 : 4;
+    if (!al16(g.A) || !al16(g.B)) return 0;
+    switch (g.amode) {
+        case A_ROW: if (g.K % va || g.lda % va) return 0; break;
+        case A_KMAJOR: if (g.M % va || g.lda % va) return 0; break;
+        case A_CONV_FWD: if (g.g.C % va) return 0; break;
+        case A_CONV_DGRAD: if (g.g.K % va) return 0; break;
+        default: return 0;
+    }
+    switch (g.bmode) {
+        case B_ROW: if (g.K % vb || g.ldb % vb) return 0; break;
+        case B_KMAJOR: if (g.N % vb || g.ldb % vb) return 0; break;
+        case B_CONV_WGRAD: if (g.g.C % vb) return 0; break;
+        case B_CONV_DGRAD_W: if (g.g.C % vb) return 0; break;
+        default: return 0;
+    }
+    return 1;
+}
+
+int launch_gemm_bf16(const GemmArgs& g, hipStream_t st) {
+    if (g.M == 0 || g.N == 0) return SAT_OK;
+    SAT_REQUIRE(g.A && g.B && g.C, "gemm_bf16: null operand");
+    SAT_REQUIRE(gemm_bf16_eligible(g), "gemm_bf16: operands not 16-byte gatherable (mode %d,%d M=%d N=%d K=%d)", g.amode, g.bmode, g.M, g.N, g.K);
+    BArgs k;
+    k.A = g.A; k.lda = g.lda; k.a_rows = g.a_rows; k.B = g.B; k.ldb = g.ldb; k.C = g.C; k.ldc = g.ldc; k.c_rows = g.c_rows;
+    k.M = g.M; k.N = g.N; k.K = g.K; k.accumulate = g.accumulate; k.epi = g.epi; k.bias = g.bias; k.e0 = g.e0; k.lde0 = g.lde0;
+    k.c0 = g.c0; k.c1 = g.c1; k.g = g.g; k.slab = g.slab;
+    int BMt = 64;
+    if ((long)cdiv(g.M, 128) * cdiv(g.N, 128) >= 192 && g.M >= 128 && g.N >= 128) BMt = 128;
+    long blocks = (long)cdiv(g.M, BMt) * cdiv(g.N, BMt);
+    int ns = 1;
+    if (g.slab && blocks < 256 && g.K >= 16 * KB) {
+        int want = (int)((512 + blocks - 1) / blocks), maxs = g.K / (8 * KB);
+        ns = want < maxs ? want : maxs; if (ns > 64) ns = 64; if (ns < 1) ns = 1;
+        while (ns > 1 && (long)ns * g.M * g.N > g.slab_elems) --ns;
+    }
+    int ktiles = cdiv(g.K, KB); if (ktiles < 1) ktiles = 1;
+    int per = cdiv(ktiles, ns);
+    k.kchunk = per * KB; k.nsplit = cdiv(ktiles, per);
+
+#define SAT_BCASE(AMV, BMV, TA, TB, TC) return runb_tiles<AMV, BMV, TA, TB, TC>(k, BMt, st);
+    const bool ab = g.a_bf16, bb = g.b_bf16, cb = g.c_bf16;
+    if (ab && bb) {         // encoder: bf16 activations / filters
+        if (g.amode == A_CONV_FWD && g.bmode == B_ROW && cb) SAT_BCASE(A_CONV_FWD, B_ROW, __bf16, __bf16, __bf16)
+        if (g.amode == A_ROW && g.bmode == B_ROW && cb) SAT_BCASE(A_ROW, B_ROW, __bf16, __bf16, __bf16)
+        if (g.amode == A_ROW && g.bmode == B_ROW && !cb) SAT_BCASE(A_ROW, B_ROW, __bf16, __bf16, float)
+        if (g.amode == A_CONV_DGRAD && g.bmode == B_CONV_DGRAD_W && cb) SAT_BCASE(A_CONV_DGRAD, B_CONV_DGRAD_W, __bf16, __bf16, __bf16)
+        if (g.amode == A_ROW && g.bmode == B_KMAJOR && cb) SAT_BCASE(A_ROW, B_KMAJOR, __bf16, __bf16, __bf16)
+        if (g.amode == A_ROW && g.bmode == B_KMAJOR && !cb) SAT_BCASE(A_ROW, B_KMAJOR, __bf16, __bf16, float)
+        if (g.amode == A_KMAJOR && g.bmode == B_CONV_WGRAD && !cb) SAT_BCASE(A_KMAJOR, B_CONV_WGRAD, __bf16, __bf16, float)
+        if (g.amode == A_KMAJOR && g.bmode == B_KMAJOR && !cb) SAT_BCASE(A_KMAJOR, B_KMAJOR, __bf16, __bf16, float)
+    } else if (!ab && !bb && !cb) {   // decoder: fp32 in HBM, rounded to bf16 on the way into LDS
+        if (g.amode == A_ROW && g.bmode == B_ROW) SAT_BCASE(A_ROW, B_ROW, float, float, float)
+        if (g.amode == A_ROW && g.bmode == B_KMAJOR) SAT_BCASE(A_ROW, B_KMAJOR, float, float, float)
+        if (g.amode == A_KMAJOR && g.bmode == B_KMAJOR) SAT_BCASE(A_KMAJOR, B_KMAJOR, float, float, float)
+    }
+#undef SAT_BCASE
+    return fail(SAT_EUNSUPPORTED, "gemm_bf16: combination amode=%d bmode=%d types(%d,%d,%d) not built", g.amode, g.bmode, ab, bb, cb);
+}
+
+}  // namespace sat

@@ -70,8 +70,9 @@ class PackPlan:
         return flags
 
 
-def decoder_dims(B, R, T, Lc, D, A, m, n, V, P, deep, padding_idx):
-    return L.DecoderDims(B=B, R=R, T=T, L=Lc, D=D, A=A, m=m, n=n, V=V, P=P, deep_output=int(bool(deep)), padding_idx=padding_idx)
+def decoder_dims(B, R, T, Lc, D, A, m, n, V, P, deep, padding_idx, precision=0):
+    return L.DecoderDims(B=B, R=R, T=T, L=Lc, D=D, A=A, m=m, n=n, V=V, P=P, deep_output=int(bool(deep)), padding_idx=padding_idx,
+                         precision=int(precision))
 
 
 def _params_struct(tensors):
@@ -95,7 +96,7 @@ class DecoderTrainFn(torch.autograd.Function):
     """logits_packed (P,V), alphas (N,T-1,L) = decoder(ann (B,L,D), captions) with BPTT backward."""
 
     @staticmethod
-    def forward(ctx, ann, caps_i32, plan, teacher, deep, padding_idx, R, *params):
+    def forward(ctx, ann, caps_i32, plan, teacher, deep, padding_idx, R, precision, *params):
         lib = L.lib()
         L.require_gpu(ann, caps_i32, *[p for p in params if p is not None])
         names = L.PARAM_FIELDS
@@ -113,7 +114,7 @@ class DecoderTrainFn(torch.autograd.Function):
                       beta_b=(D,), out_hidden=(m, n), out_context=(m, D), out_w=(V, m), out_b=(V,))
         for k in names:
             _check_param(k, tens[k], shapes[k])
-        dims = decoder_dims(B, R, T, Lc, D, A, m, n, V, plan.P, deep, padding_idx)
+        dims = decoder_dims(B, R, T, Lc, D, A, m, n, V, plan.P, deep, padding_idx, precision)
         ws_bytes = lib.sat_decoder_workspace_bytes(C.byref(dims))
         if ws_bytes == 0:
             raise L.SatHipError("sat_decoder_workspace_bytes: %s" % lib.sat_last_error().decode())
@@ -154,7 +155,7 @@ class DecoderTrainFn(torch.autograd.Function):
         w, g = _params_struct(tens), _params_struct(grads)
         L.check(lib.sat_decoder_train_bwd(C.byref(dims), C.byref(w), C.byref(batch), L.ptr(dlogits), L.ptr(alphas), L.ptr(dalphas),
                                           C.byref(g), L.ptr(dann), L.ptr(ctx.ws), ctx.ws_bytes, L.stream_ptr()), "sat_decoder_train_bwd")
-        return (dann, None, None, None, None, None, None, *[grads[k] for k in L.PARAM_FIELDS])
+        return (dann, None, None, None, None, None, None, None, *[grads[k] for k in L.PARAM_FIELDS])
 
 
 class LabelSmoothingFn(torch.autograd.Function):
@@ -221,7 +222,7 @@ class DoublyStochasticFn(torch.autograd.Function):
 
 
 def gemm(A, B, *, amode=0, bmode=0, M=None, N=None, K=None, out=None, accumulate=False, epi=0, bias=None, e0=None, c0=0, c1=0,
-         a_rows=None, c_rows=None, out_rows=None, slab=None):
+         a_rows=None, c_rows=None, out_rows=None, slab=None, bf16_mfma=False, out_dtype=torch.float32):
     """Thin test/driver entry to sat_gemm_f32 (dense modes).  A: (M,K) if amode=0 else (K,M); B: (N,K) if bmode=0 else (K,N)."""
     lib = L.lib()
     L.require_gpu(A, B)
@@ -232,12 +233,17 @@ def gemm(A, B, *, amode=0, bmode=0, M=None, N=None, K=None, out=None, accumulate
     if N is None:
         N = B.shape[0] if bmode == 0 else B.shape[1]
     if out is None:
-        out = torch.zeros(out_rows if out_rows is not None else M, N, dtype=torch.float32, device=A.device)
+        out = torch.zeros(out_rows if out_rows is not None else M, N, dtype=out_dtype, device=A.device)
     d = L.GemmDesc(A=A.data_ptr(), lda=A.stride(0), a_rows=None if a_rows is None else a_rows.data_ptr(),
                    B=B.data_ptr(), ldb=B.stride(0), C=out.data_ptr(), ldc=out.stride(0),
                    c_rows=None if c_rows is None else c_rows.data_ptr(), M=M, N=N, K=K, amode=amode, bmode=bmode,
                    accumulate=int(accumulate), epi=epi, bias=None if bias is None else bias.data_ptr(),
                    e0=None if e0 is None else e0.data_ptr(), lde0=0 if e0 is None else e0.stride(0), c0=c0, c1=c1,
                    slab=None if slab is None else slab.data_ptr(), slab_elems=0 if slab is None else slab.numel())
-    L.check(lib.sat_gemm_f32(C.byref(d), L.stream_ptr()), "sat_gemm_f32")
+    bf = torch.bfloat16
+    if bf16_mfma or A.dtype == bf or B.dtype == bf or out.dtype == bf:
+        t = L.GemmTypes(a_bf16=int(A.dtype == bf), b_bf16=int(B.dtype == bf), c_bf16=int(out.dtype == bf), bf16_mfma=int(bf16_mfma))
+        L.check(lib.sat_gemm_ex(C.byref(d), C.byref(t), L.stream_ptr()), "sat_gemm_ex")
+    else:
+        L.check(lib.sat_gemm_f32(C.byref(d), L.stream_ptr()), "sat_gemm_f32")
     return out

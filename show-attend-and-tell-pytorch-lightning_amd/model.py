@@ -140,7 +140,7 @@ class SATDecoder(nn.Module):
         caps2 = caps.reshape(B * R, T)
         caps_i32 = caps2.to(device=ann_bld.device, dtype=torch.int32).contiguous()
         logits_packed, alphas = Dk.DecoderTrainFn.apply(ann_bld, caps_i32, plan, teacher, bool(self.hp.deep_output), self.pad_idx, R,
-                                                        *self.param_list())
+                                                        int(getattr(self, "precision", 0)), *self.param_list())
         targets_packed = plan.pack(caps2[:, 1:].to(ann_bld.device).unsqueeze(-1)).squeeze(-1)
         if not with_loss:
             return dict(logits_packed=logits_packed, targets_packed=targets_packed, alphas=alphas, plan=plan)

@@ -208,3 +208,38 @@ def test_whole_encoder_against_oracle(E, arch, es, px):
     enc.eval(); ref.eval()
     with torch.no_grad():
         close(enc(img.cuda()), ref(img.clone()), 2e-4, "eval annotations")
+
+
+# ----------------------------------------------------------------------------- bf16 storage convolutions
+BCONVS = [(2, 9, 9, 8, 16, 3, 1, 1), (2, 10, 11, 16, 24, 3, 2, 1), (3, 8, 8, 16, 8, 1, 1, 0), (2, 9, 9, 8, 16, 1, 2, 0),
+          (2, 20, 20, 8, 16, 7, 2, 3), (1, 16, 16, 64, 64, 3, 1, 1), (4, 14, 14, 32, 128, 3, 2, 1), (8, 16, 16, 64, 256, 1, 1, 0)]
+
+
+@pytest.mark.parametrize("N,H,W,C,K,R,stride,pad", BCONVS)
+def test_conv_bf16_fwd_dgrad_wgrad(E, N, H, W, C, K, R, stride, pad):
+    import ctypes
+    import sat_amd  # noqa
+    from sat_amd import _lib as L
+    bf = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    g = torch.Generator().manual_seed(N * 100 + H + C + K + R)
+    x = bf(torch.randn(N, C, H, W, generator=g)).requires_grad_()
+    w = bf(torch.randn(K, C, R, R, generator=g)).requires_grad_()
+    y = F.conv2d(x, w, None, stride, pad)
+    dy = bf(torch.randn(y.shape, generator=g))
+    y.backward(dy)
+    xd = nhwc(x.detach()).cuda().to(torch.bfloat16)
+    wd = w.detach().permute(0, 2, 3, 1).contiguous().cuda().to(torch.bfloat16)       # KRSC
+    dyd = nhwc(dy).cuda().to(torch.bfloat16)
+    P, Q = y.shape[2], y.shape[3]
+    geom = L.ConvGeom(N=N, H=H, W=W, C=C, K=K, R=R, S=R, stride=stride, pad=pad)
+    lib = L.lib()
+    yd = torch.empty(N, P, Q, K, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.sat_conv2d_fwd_bf16(L.ptr(xd), L.ptr(wd), None, L.ptr(yd), ctypes.byref(geom), L.stream_ptr()), "conv fwd bf16")
+    close(nchw(yd.float()), y, 1e-2, "bf16 conv fwd")                    # output rounding to bf16: 2^-8 relative
+    dx = torch.empty(N, H, W, C, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.sat_conv2d_dgrad_bf16(L.ptr(dyd), L.ptr(wd), L.ptr(dx), ctypes.byref(geom), 0, L.stream_ptr()), "conv dgrad bf16")
+    close(nchw(dx.float()), x.grad, 1e-2, "bf16 conv dgrad")
+    dw = torch.empty(K, R, R, C, dtype=torch.float32, device="cuda")
+    slab = torch.empty(1 << 22, device="cuda")
+    L.check(lib.sat_conv2d_wgrad_bf16(L.ptr(dyd), L.ptr(xd), L.ptr(dw), ctypes.byref(geom), L.ptr(slab), slab.numel(), L.stream_ptr()), "conv wgrad bf16")
+    close(dw.permute(0, 3, 1, 2), w.grad, 1e-5 * (N * P * Q) ** 0.5, "bf16 conv wgrad (fp32 out)")

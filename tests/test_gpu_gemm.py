@@ -75,3 +75,53 @@ def test_gather_scatter_and_epilogues(dk):
     u = torch.tanh(torch.randn(M, N, generator=g))
     out5 = dk.gemm(Ag2.cuda(), W.cuda(), e0=u.cuda(), epi=4)
     assert (out5.cpu() - (Ag2 @ W.t()) * (1 - u * u)).abs().max().item() <= _tol(ref, K)
+
+
+# ----------------------------------------------------------------------------- bf16 MFMA kernel (csrc/gemm_bf16.hip)
+def _bf(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+BSHAPES = [(64, 64, 32), (128, 128, 64), (640, 2688, 512), (200, 72, 96), (136, 264, 40), (1024, 512, 2048), (8, 8, 8)]
+
+
+@pytest.mark.parametrize("M,N,K", BSHAPES)
+@pytest.mark.parametrize("amode,bmode", [(0, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("store", ["f32", "bf16"])
+def test_bf16_mfma_dense_modes(dk, M, N, K, amode, bmode, store):
+    """fp32 operands rounded to bf16 in-kernel, and bf16 operands in HBM: both equal the fp32 product of the
+    bf16-rounded inputs up to accumulation order."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g); B = torch.randn(K, N, generator=g)
+    ref = _bf(A) @ _bf(B)
+    dt = torch.float32 if store == "f32" else torch.bfloat16
+    Ad = (A if amode == 0 else A.t().contiguous()).to(dt).cuda()
+    Bd = (B.t().contiguous() if bmode == 0 else B).to(dt).cuda()
+    out = dk.gemm(Ad, Bd, amode=amode, bmode=bmode, bf16_mfma=True)
+    assert (out.cpu() - ref).abs().max().item() <= _tol(ref, K)
+    if store == "bf16" and not (amode == 1 and bmode == 1):
+        outb = dk.gemm(Ad, Bd, amode=amode, bmode=bmode, bf16_mfma=True, out_dtype=torch.bfloat16) if (amode, bmode) != (0, 1) or True else None
+        assert (outb.float().cpu() - ref).abs().max().item() <= 1e-2 * max(1.0, float(ref.abs().max()))
+
+
+def test_bf16_mfma_splitk_gather_epilogue(dk):
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 96, 40, 4096
+    A = torch.randn(K, M, generator=g); B = torch.randn(K, N, generator=g)
+    slab = torch.empty(4 << 20, device="cuda")
+    out = dk.gemm(A.cuda(), B.cuda(), amode=1, bmode=1, slab=slab, bf16_mfma=True)
+    ref = _bf(A).t() @ _bf(B)
+    assert (out.cpu() - ref).abs().max().item() <= _tol(ref, K)
+    src = torch.randn(300, 64, generator=g); W = torch.randn(48, 64, generator=g); bias = torch.randn(48, generator=g)
+    rows = torch.randint(0, 300, (130,), generator=g).to(torch.int32); rows[5] = -1
+    Ag = _bf(src)[rows.clamp(min=0).long()] * (rows >= 0).float()[:, None]
+    ref2 = Ag @ _bf(W).t() + bias; ref2[:, 8:24] = torch.sigmoid(ref2[:, 8:24])
+    out2 = dk.gemm(src.cuda(), W.cuda(), a_rows=rows.cuda(), bias=bias.cuda(), epi=2, c0=8, c1=24, bf16_mfma=True)
+    assert (out2.cpu() - ref2).abs().max().item() <= 3e-5
+
+
+def test_bf16_request_falls_back_to_fp32_kernel_on_odd_shapes(dk):
+    g = torch.Generator().manual_seed(12)
+    A = torch.randn(9, 7, generator=g); B = torch.randn(5, 7, generator=g)
+    out = dk.gemm(A.cuda(), B.cuda(), bf16_mfma=True)
+    assert (out.cpu() - A @ B.t()).abs().max().item() <= 1e-5
