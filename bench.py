@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--ragged", action="store_true", help="lengths ~ U{8..T-1} instead of all T-1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=None, help="override images per GPU")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
+                    help="bf16: bf16 MFMA + bf16 activations (BASELINE configs[1]); fp32: exact fp32 MFMA parity mode")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -136,6 +138,7 @@ def main():
         B = args.batch
     torch.manual_seed(42)
     model = M.SAT(**hp).to(dev).train()
+    model.set_precision(args.precision)
     broadcast_parameters(model)
     model.__dict__["_sat_global_step"] = 2          # past encoder_finetune_after: the encoder trains (and is in the optimizer)
     opt = model.configure_optimizers()
@@ -189,8 +192,9 @@ def main():
         roof = None
         if dom:
             tf = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": dom["name"], "achieved": round(tf, 2), "peak": PEAK["f32"], "unit": "TFLOP/s",
-                    "frac": round(tf / PEAK["f32"], 4), "traffic": None,
+            peak = PEAK["bf16"] if "bf16" in dom["name"] else PEAK["f32"]
+            roof = {"bound": "mfma", "kernel": dom["name"], "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(tf / peak, 4), "traffic": None,
                     "avg_launch_us": round(dom["total_ms"] * 1e3 / dom["launches"], 2), "launches_per_step": dom["launches"] // prof_steps,
                     "flops_per_launch": dom["flops"] / dom["launches"],
                     "measured_on": "%d instrumented steps right after the timed region (events add launch overhead)" % prof_steps,
@@ -199,7 +203,7 @@ def main():
                             for e in entries[:8]]}
         line = {"metric": "captions/sec (train step) at B=128, 256px, seq_len=22", "value": round(caps_per_s, 1), "unit": "captions/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
-                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
                 "config": {"workload": "%s: %s encoder_size=%s encoder_dim=%d vocab=%d T=%d, %d images/GPU x R=%d captions, "
                                        "trainable encoder, Adam, %s lengths" % (args.config.upper(), CONFIGS[args.config][0],
                                                                                CONFIGS[args.config][1], CONFIGS[args.config][2],

@@ -189,6 +189,25 @@ int sat_bn_eval_fwd(const float* x, int64_t rows, int32_t C, const float* runnin
 int sat_bn_train_bwd(const float* dy, const float* x, const float* y, int64_t rows, int32_t C, const float* save_mean,
                      const float* save_invstd, const float* gamma, int32_t relu, float* dx, float* dgamma, float* dbeta,
                      float* dres, int32_t dres_accumulate, float* scratch, void* stream);
+/* Storage-typed variants (dtype 0 = fp32, 1 = bf16 activations; statistics, affine parameters and their
+ * gradients stay fp32, reductions accumulate in double) */
+int sat_bn_train_fwd_t(int32_t dtype, const void* x, int64_t rows, int32_t C, const float* gamma, const float* beta, float eps, float momentum,
+                       float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                       const void* residual, int32_t relu, void* y, float* scratch, void* stream);
+int sat_bn_eval_fwd_t(int32_t dtype, const void* x, int64_t rows, int32_t C, const float* running_mean, const float* running_var, float eps,
+                      const float* gamma, const float* beta, const void* residual, int32_t relu, void* y, void* stream);
+int sat_bn_train_bwd_t(int32_t dtype, const void* dy, const void* x, const void* y, int64_t rows, int32_t C, const float* save_mean,
+                       const float* save_invstd, const float* gamma, int32_t relu, void* dx, float* dgamma, float* dbeta,
+                       void* dres, int32_t dres_accumulate, float* scratch, void* stream);
+int sat_maxpool3x3s2_fwd_t(int32_t dtype, const void* x, void* y, uint8_t* argmax, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+int sat_maxpool3x3s2_bwd_t(int32_t dtype, const void* dy, const uint8_t* argmax, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+/* bf16 plumbing: fp32 -> bf16 copies of filters/gradients (n % 4 == 0); Normalize fused with NCHW -> NHWC and
+ * 3 -> 8 channel padding; stem filter (K,7,7,3) fp32 -> (K,7,7,8) bf16 and its fp32 gradient back */
+int sat_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+int sat_image_normalize_nhwc8_bf16(const float* img_nchw, void* out_nhwc8, int32_t N, int32_t H, int32_t W,
+                                   const float* mean3_host, const float* std3_host, void* stream);
+int sat_stem_filter_pad(const float* w3, void* w8_bf16, int64_t pixels, void* stream);
+int sat_stem_filter_grad_unpad(const float* dw8, float* dw3, int64_t pixels, void* stream);
 /* nn.MaxPool2d(3, 2, 1) of the ResNet stem; argmax (N,P,Q,C) bytes keep the window position */
 int sat_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* argmax, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
 int sat_maxpool3x3s2_bwd(const float* dy, const uint8_t* argmax, float* dx, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);

@@ -96,6 +96,15 @@ SYMBOLS.update({
     "sat_bn_eval_fwd": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _f, _vp, _vp, _vp, _i32, _vp, _vp]),
     "sat_colsum": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp]),
     "sat_bn_train_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "sat_bn_train_fwd_t": (C.c_int, [_i32, _vp, _i64, _i32, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "sat_bn_eval_fwd_t": (C.c_int, [_i32, _vp, _i64, _i32, _vp, _vp, _f, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "sat_bn_train_bwd_t": (C.c_int, [_i32, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "sat_maxpool3x3s2_fwd_t": (C.c_int, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "sat_maxpool3x3s2_bwd_t": (C.c_int, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "sat_cast_f32_to_bf16": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "sat_image_normalize_nhwc8_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp]),
+    "sat_stem_filter_pad": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "sat_stem_filter_grad_unpad": (C.c_int, [_vp, _vp, _i64, _vp]),
     "sat_maxpool3x3s2_fwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "sat_maxpool3x3s2_bwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "sat_resize_fwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

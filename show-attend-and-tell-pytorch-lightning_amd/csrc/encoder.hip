@@ -9,6 +9,48 @@
 
 namespace sat {
 
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+// 4 consecutive activation elements as fp32, whatever the storage type (fp32: 16 B, bf16: 8 B)
+template <typename T> __device__ __forceinline__ float4 ld4(const T* p, long i4);
+template <> __device__ __forceinline__ float4 ld4<float>(const float* p, long i4) { return reinterpret_cast<const float4*>(p)[i4]; }
+template <> __device__ __forceinline__ float4 ld4<__bf16>(const __bf16* p, long i4) {
+    bf16x4 v = reinterpret_cast<const bf16x4*>(p)[i4];
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, long i4, float4 v);
+template <> __device__ __forceinline__ void st4<float>(float* p, long i4, float4 v) { reinterpret_cast<float4*>(p)[i4] = v; }
+template <> __device__ __forceinline__ void st4<__bf16>(__bf16* p, long i4, float4 v) {
+    bf16x4 o; o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+    reinterpret_cast<bf16x4*>(p)[i4] = o;
+}
+
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long n4) {
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n4) st4<__bf16>(dst, e, reinterpret_cast<const float4*>(src)[e]);
+}
+// NCHW [0,1] fp32 -> normalised NHWC bf16 with C padded 3 -> 8 (16-byte pixels for the bf16 implicit GEMM)
+__global__ void normalize_nhwc8_bf16_kernel(const float* __restrict__ img, __bf16* __restrict__ out, int H, int W, long total,
+                                            float m0, float m1, float m2, float s0, float s1, float s2) {
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    long hw = (long)H * W; long n = e / hw, p = e - n * hw;
+    const float* src = img + n * 3 * hw + p;
+    st4<__bf16>(out, 2 * e, make_float4((src[0] - m0) / s0, (src[hw] - m1) / s1, (src[2 * hw] - m2) / s2, 0.f));
+    st4<__bf16>(out, 2 * e + 1, make_float4(0.f, 0.f, 0.f, 0.f));
+}
+// stem filters (K,R,S,3) fp32 -> (K,R,S,8) bf16, and the fp32 (K,R,S,8) gradient back to (K,R,S,3)
+__global__ void pad_c3_to_c8_bf16_kernel(const float* __restrict__ w3, __bf16* __restrict__ w8, long n) {
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    st4<__bf16>(w8, 2 * e, make_float4(w3[3 * e], w3[3 * e + 1], w3[3 * e + 2], 0.f));
+    st4<__bf16>(w8, 2 * e + 1, make_float4(0.f, 0.f, 0.f, 0.f));
+}
+__global__ void unpad_c8_to_c3_kernel(const float* __restrict__ w8, float* __restrict__ w3, long n) {
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    w3[3 * e] = w8[8 * e]; w3[3 * e + 1] = w8[8 * e + 1]; w3[3 * e + 2] = w8[8 * e + 2];
+}
+
 // ------------------------------------------------------------------ input: NCHW [0,1] -> normalised NHWC, C padded 3 -> 4
 __global__ void normalize_nhwc4_kernel(const float* __restrict__ img, float* __restrict__ out, int H, int W, long total,
                                        float m0, float m1, float m2, float s0, float s1, float s2) {
@@ -38,8 +80,8 @@ __global__ void unpad_c4_to_c3_kernel(const float* __restrict__ w4, float* __res
 // Column statistics of a (rows x C) matrix, C % 4 == 0.  Block = 256 threads = TW vector-columns x RL row lanes.
 // MODE 0: sum x, sum x^2.   MODE 1: sum g, sum g*xhat with g = dy * (relu ? y > 0 : 1).
 struct d4 { double x, y, z, w; };
-template <int MODE>
-__global__ __launch_bounds__(256) void bn_colstats_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
+template <int MODE, typename T>
+__global__ __launch_bounds__(256) void bn_colstats_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
                                                           const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
                                                           long rows, int C, int TW, long rows_per, double* __restrict__ part0, double* __restrict__ part1,
                                                           float* __restrict__ part2) {
@@ -56,18 +98,18 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const float* __restric
         if (MODE == 1) { mu = reinterpret_cast<const float4*>(mean)[c4]; is = reinterpret_cast<const float4*>(invstd)[c4]; }
         else {
             // shifted sums: d = x - (first row of this chunk) keeps sum d^2 - (sum d)^2/n well conditioned
-            mu = reinterpret_cast<const float4*>(x)[r0 * C4 + c4];
+            mu = ld4<T>(x, r0 * C4 + c4);
             if (tr == 0) reinterpret_cast<float4*>(part2)[(long)blockIdx.y * C4 + c4] = mu;
         }
         for (long r = r0 + tr; r < r1; r += RL) {
-            float4 xv = reinterpret_cast<const float4*>(x)[r * C4 + c4];
+            float4 xv = ld4<T>(x, r * C4 + c4);
             if (MODE == 0) {
                 xv.x -= mu.x; xv.y -= mu.y; xv.z -= mu.z; xv.w -= mu.w;
                 a0.x += xv.x; a0.y += xv.y; a0.z += xv.z; a0.w += xv.w;
                 a1.x += (double)xv.x * xv.x; a1.y += (double)xv.y * xv.y; a1.z += (double)xv.z * xv.z; a1.w += (double)xv.w * xv.w;
             } else {
-                float4 g = reinterpret_cast<const float4*>(dy)[r * C4 + c4];
-                if (relu) { float4 yv = reinterpret_cast<const float4*>(y)[r * C4 + c4];
+                float4 g = ld4<T>(dy, r * C4 + c4);
+                if (relu) { float4 yv = ld4<T>(y, r * C4 + c4);
                     g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f; }
                 a0.x += g.x; a0.y += g.y; a0.z += g.z; a0.w += g.w;
                 a1.x += (double)g.x * ((xv.x - mu.x) * is.x); a1.y += (double)g.y * ((xv.y - mu.y) * is.y);
@@ -117,22 +159,23 @@ __global__ void bn_fwd_finalize_kernel(const double* __restrict__ part0, const d
 
 // y = (x - mean) * invstd * gamma + beta (+ residual) (ReLU).  eval mode (var_eps >= 0) passes the running
 // variance in `invstd` and the kernel takes 1/sqrt(var + eps) itself.
-__global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
-                                const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ res, int relu,
-                                float* __restrict__ y, long total4, int C4, float var_eps) {
+template <typename T>
+__global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                const float* __restrict__ gamma, const float* __restrict__ beta, const T* __restrict__ res, int relu,
+                                T* __restrict__ y, long total4, int C4, float var_eps) {
     long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total4) return;
     int c4 = (int)(e % C4);
-    float4 xv = reinterpret_cast<const float4*>(x)[e];
+    float4 xv = ld4<T>(x, e);
     float4 mu = reinterpret_cast<const float4*>(mean)[c4], is = reinterpret_cast<const float4*>(invstd)[c4];
     if (var_eps >= 0.f) { is.x = 1.f / sqrtf(is.x + var_eps); is.y = 1.f / sqrtf(is.y + var_eps); is.z = 1.f / sqrtf(is.z + var_eps); is.w = 1.f / sqrtf(is.w + var_eps); }
     float4 g = reinterpret_cast<const float4*>(gamma)[c4], b = reinterpret_cast<const float4*>(beta)[c4];
     float4 o;
     o.x = (xv.x - mu.x) * is.x * g.x + b.x; o.y = (xv.y - mu.y) * is.y * g.y + b.y;
     o.z = (xv.z - mu.z) * is.z * g.z + b.z; o.w = (xv.w - mu.w) * is.w * g.w + b.w;
-    if (res) { float4 r = reinterpret_cast<const float4*>(res)[e]; o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+    if (res) { float4 r = ld4<T>(res, e); o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
     if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-    reinterpret_cast<float4*>(y)[e] = o;
+    st4<T>(y, e, o);
 }
 
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part0, const double* __restrict__ part1, int nparts, int C,
@@ -145,16 +188,17 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part0, const d
 }
 
 // dx = gamma * invstd * (g - dbeta/M - xhat * dgamma/M);  dres (optional) receives g (the masked upstream gradient)
-__global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
                                     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const float* __restrict__ dbeta, const float* __restrict__ dgamma, int relu, float inv_rows,
-                                    float* __restrict__ dx, float* __restrict__ dres, int dres_accumulate, long total4, int C4) {
+                                    T* __restrict__ dx, T* __restrict__ dres, int dres_accumulate, long total4, int C4) {
     long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total4) return;
     int c4 = (int)(e % C4);
-    float4 xv = reinterpret_cast<const float4*>(x)[e];
-    float4 g = reinterpret_cast<const float4*>(dy)[e];
-    if (relu) { float4 yv = reinterpret_cast<const float4*>(y)[e];
+    float4 xv = ld4<T>(x, e);
+    float4 g = ld4<T>(dy, e);
+    if (relu) { float4 yv = ld4<T>(y, e);
         g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f; }
     float4 mu = reinterpret_cast<const float4*>(mean)[c4], is = reinterpret_cast<const float4*>(invstd)[c4];
     float4 ga = reinterpret_cast<const float4*>(gamma)[c4];
@@ -164,16 +208,17 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
     o.y = ga.y * is.y * (g.y - db.y * inv_rows - (xv.y - mu.y) * is.y * dg.y * inv_rows);
     o.z = ga.z * is.z * (g.z - db.z * inv_rows - (xv.z - mu.z) * is.z * dg.z * inv_rows);
     o.w = ga.w * is.w * (g.w - db.w * inv_rows - (xv.w - mu.w) * is.w * dg.w * inv_rows);
-    reinterpret_cast<float4*>(dx)[e] = o;
+    st4<T>(dx, e, o);
     if (dres) {
-        if (dres_accumulate) { float4 r = reinterpret_cast<float4*>(dres)[e]; g.x += r.x; g.y += r.y; g.z += r.z; g.w += r.w; }
-        reinterpret_cast<float4*>(dres)[e] = g;
+        if (dres_accumulate) { float4 r = ld4<T>(dres, e); g.x += r.x; g.y += r.y; g.z += r.z; g.w += r.w; }
+        st4<T>(dres, e, g);
     }
 }
 
 // ------------------------------------------------------------------ max pool k=3 s=2 p=1 (torchvision ResNet stem)
 // argmax keeps the FIRST maximum in (kh, kw) scan order, like torch's max_pool2d (strict >).
-__global__ void maxpool3x3s2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ amax,
+template <typename T>
+__global__ void maxpool3x3s2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, unsigned char* __restrict__ amax,
                                         int H, int W, int C4, int P, int Q, long total4) {
     long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total4) return;
@@ -184,7 +229,7 @@ __global__ void maxpool3x3s2_fwd_kernel(const float* __restrict__ x, float* __re
         int h = p * 2 - 1 + kh; if ((unsigned)h >= (unsigned)H) continue;
         for (int kw = 0; kw < 3; ++kw) {
             int w = q * 2 - 1 + kw; if ((unsigned)w >= (unsigned)W) continue;
-            float4 v = reinterpret_cast<const float4*>(x)[((n * H + h) * W + w) * C4 + c4];
+            float4 v = ld4<T>(x, ((n * H + h) * W + w) * C4 + c4);
             int k = kh * 3 + kw;
             if (v.x > best.x) { best.x = v.x; bx = k; }
             if (v.y > best.y) { best.y = v.y; by = k; }
@@ -192,11 +237,12 @@ __global__ void maxpool3x3s2_fwd_kernel(const float* __restrict__ x, float* __re
             if (v.w > best.w) { best.w = v.w; bw = k; }
         }
     }
-    reinterpret_cast<float4*>(y)[e] = best;
+    st4<T>(y, e, best);
     reinterpret_cast<uchar4*>(amax)[e] = make_uchar4(bx, by, bz, bw);
 }
 // gather form (deterministic): every input position sums the outputs whose argmax points at it
-__global__ void maxpool3x3s2_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ amax, float* __restrict__ dx,
+template <typename T>
+__global__ void maxpool3x3s2_bwd_kernel(const T* __restrict__ dy, const unsigned char* __restrict__ amax, T* __restrict__ dx,
                                         int H, int W, int C4, int P, int Q, long total4) {
     long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total4) return;
@@ -208,12 +254,12 @@ __global__ void maxpool3x3s2_bwd_kernel(const float* __restrict__ dy, const unsi
             int pw = w + 1 - kw; if (pw < 0 || (pw & 1)) continue; int q = pw >> 1; if (q >= Q) continue;
             long o = ((n * P + p) * Q + q) * C4 + c4;
             uchar4 a = reinterpret_cast<const uchar4*>(amax)[o];
-            float4 g = reinterpret_cast<const float4*>(dy)[o];
+            float4 g = ld4<T>(dy, o);
             int k = kh * 3 + kw;
             if (a.x == k) acc.x += g.x; if (a.y == k) acc.y += g.y; if (a.z == k) acc.z += g.z; if (a.w == k) acc.w += g.w;
         }
     }
-    reinterpret_cast<float4*>(dx)[e] = acc;
+    st4<T>(dx, e, acc);
 }
 
 // ------------------------------------------------------------------ encoder_size resize on the final map (readme.md:118-121)
@@ -364,81 +410,171 @@ int sat_pad_channels_3to4(const float* src, float* dst, int64_t pixels, int32_t 
     return launch_ok("pad_channels");
 }
 
+}  // extern "C" (typed implementations follow)
+
 static void bn_grid(long rows, int C, int& TW, long& rows_per, int& nparts) {
     int C4 = C / 4;
     TW = C4 < 64 ? C4 : 64;
-    while (256 % TW) --TW;                      // TW must divide 256 (C4 = 2^k * odd: fall back to a divisor)
+    while (256 % TW) --TW;                      // TW must divide 256
     rows_per = 512;
-    if (rows / rows_per > 2048) rows_per = (rows + 2047) / 2048;
+    if (rows / rows_per > 256) rows_per = (rows + 255) / 256;   // <= 256 partials: the finalise loop stays short
     nparts = cdiv(rows, rows_per);
 }
 
-size_t sat_bn_scratch_bytes(int64_t rows, int32_t C) {
+extern "C" size_t sat_bn_scratch_bytes(int64_t rows, int32_t C) {
     if (rows <= 0 || C <= 0 || C % 4) return 0;
     int TW, nparts; long rp; bn_grid(rows, C, TW, rp, nparts);
     return (size_t)nparts * C * (2 * sizeof(double) + sizeof(float)) + 64;
 }
 
-int sat_bn_train_fwd(const float* x, int64_t rows, int32_t C, const float* gamma, const float* beta, float eps, float momentum,
-                     float* running_mean, float* running_var, float* save_mean, float* save_invstd, const float* residual, int32_t relu,
-                     float* y, float* scratch, void* stream) {
+template <typename T>
+static int bn_train_fwd_t(const T* x, int64_t rows, int32_t C, const float* gamma, const float* beta, float eps, float momentum,
+                          float* running_mean, float* running_var, float* save_mean, float* save_invstd, const T* residual, int32_t relu,
+                          T* y, float* scratch, hipStream_t st) {
     if (!x || !gamma || !beta || !save_mean || !save_invstd || !y || !scratch) return fail(SAT_EINVAL, "bn_train_fwd: null pointer");
     SAT_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, "bn_train_fwd: rows=%ld C=%d (C must be a multiple of 4)", (long)rows, C);
-    hipStream_t st = (hipStream_t)stream;
     int TW, nparts; long rp; bn_grid(rows, C, TW, rp, nparts);
     double* p0 = reinterpret_cast<double*>(scratch); double* p1 = p0 + (long)nparts * C; float* p2 = reinterpret_cast<float*>(p1 + (long)nparts * C);
-    hipLaunchKernelGGL(bn_colstats_kernel<0>, dim3(cdiv(C / 4, TW), nparts), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, 0, (long)rows, C, TW, rp, p0, p1, p2);
+    hipLaunchKernelGGL((bn_colstats_kernel<0, T>), dim3(cdiv(C / 4, TW), nparts), dim3(256), 0, st, x, (const T*)nullptr, (const T*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, 0, (long)rows, C, TW, rp, p0, p1, p2);
     SAT_TRY(launch_ok("bn_colstats<0>"));
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, p0, p1, p2, nparts, rp, C, (long)rows, eps, momentum, save_mean, save_invstd, running_mean, running_var);
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, p0, p1, p2, nparts, rp, C, (long)rows, eps, momentum, save_mean, save_invstd, running_mean, running_var);
     SAT_TRY(launch_ok("bn_fwd_finalize"));
     long total4 = rows * (C / 4);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta, residual, relu, y, total4, C / 4, -1.0f);
+    hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(cdiv(total4, 256)), dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta, residual, relu, y, total4, C / 4, -1.0f);
     return launch_ok("bn_apply");
 }
 
-int sat_bn_eval_fwd(const float* x, int64_t rows, int32_t C, const float* running_mean, const float* running_var, float eps,
-                    const float* gamma, const float* beta, const float* residual, int32_t relu, float* y, void* stream) {
+template <typename T>
+static int bn_eval_fwd_t(const T* x, int64_t rows, int32_t C, const float* running_mean, const float* running_var, float eps,
+                         const float* gamma, const float* beta, const T* residual, int32_t relu, T* y, hipStream_t st) {
     if (!x || !running_mean || !running_var || !gamma || !beta || !y) return fail(SAT_EINVAL, "bn_eval_fwd: null pointer");
     SAT_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && eps >= 0.f, "bn_eval_fwd: bad shape");
     long total4 = rows * (C / 4);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, (hipStream_t)stream, x, running_mean, running_var, gamma, beta, residual, relu, y, total4, C / 4, eps);
+    hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(cdiv(total4, 256)), dim3(256), 0, st, x, running_mean, running_var, gamma, beta, residual, relu, y, total4, C / 4, eps);
     return launch_ok("bn_apply(eval)");
 }
 
-int sat_bn_train_bwd(const float* dy, const float* x, const float* y, int64_t rows, int32_t C, const float* save_mean, const float* save_invstd,
-                     const float* gamma, int32_t relu, float* dx, float* dgamma, float* dbeta, float* dres, int32_t dres_accumulate,
-                     float* scratch, void* stream) {
+template <typename T>
+static int bn_train_bwd_t(const T* dy, const T* x, const T* y, int64_t rows, int32_t C, const float* save_mean, const float* save_invstd,
+                          const float* gamma, int32_t relu, T* dx, float* dgamma, float* dbeta, T* dres, int32_t dres_accumulate,
+                          float* scratch, hipStream_t st) {
     if (!dy || !x || !save_mean || !save_invstd || !gamma || !dx || !dgamma || !dbeta || !scratch) return fail(SAT_EINVAL, "bn_train_bwd: null pointer");
     if (relu && !y) return fail(SAT_EINVAL, "bn_train_bwd: relu mask needs the forward output");
     SAT_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, "bn_train_bwd: bad shape");
-    hipStream_t st = (hipStream_t)stream;
     int TW, nparts; long rp; bn_grid(rows, C, TW, rp, nparts);
     double* p0 = reinterpret_cast<double*>(scratch); double* p1 = p0 + (long)nparts * C;
-    hipLaunchKernelGGL(bn_colstats_kernel<1>, dim3(cdiv(C / 4, TW), nparts), dim3(256), 0, st, x, dy, y, save_mean, save_invstd, relu, (long)rows, C, TW, rp, p0, p1, nullptr);
+    hipLaunchKernelGGL((bn_colstats_kernel<1, T>), dim3(cdiv(C / 4, TW), nparts), dim3(256), 0, st, x, dy, y, save_mean, save_invstd, relu, (long)rows, C, TW, rp, p0, p1, (float*)nullptr);
     SAT_TRY(launch_ok("bn_colstats<1>"));
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, p0, p1, nparts, C, dbeta, dgamma);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, p0, p1, nparts, C, dbeta, dgamma);
     SAT_TRY(launch_ok("bn_bwd_finalize"));
     long total4 = rows * (C / 4);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, st, x, dy, y, save_mean, save_invstd, gamma, dbeta, dgamma, relu,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(cdiv(total4, 256)), dim3(256), 0, st, x, dy, y, save_mean, save_invstd, gamma, dbeta, dgamma, relu,
                        1.0f / (float)rows, dx, dres, dres_accumulate, total4, C / 4);
     return launch_ok("bn_bwd_apply");
 }
 
-int sat_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* argmax, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+template <typename T>
+static int maxpool_fwd_t(const T* x, T* y, uint8_t* argmax, int32_t N, int32_t H, int32_t W, int32_t C, hipStream_t st) {
     if (!x || !y || !argmax) return fail(SAT_EINVAL, "maxpool_fwd: null pointer");
     SAT_REQUIRE(C % 4 == 0, "maxpool: C must be a multiple of 4");
     int P = (H + 2 - 3) / 2 + 1, Q = (W + 2 - 3) / 2 + 1;
     long total4 = (long)N * P * Q * (C / 4);
-    hipLaunchKernelGGL(maxpool3x3s2_fwd_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, (hipStream_t)stream, x, y, argmax, H, W, C / 4, P, Q, total4);
+    hipLaunchKernelGGL(maxpool3x3s2_fwd_kernel<T>, dim3(cdiv(total4, 256)), dim3(256), 0, st, x, y, argmax, H, W, C / 4, P, Q, total4);
     return launch_ok("maxpool_fwd");
 }
-int sat_maxpool3x3s2_bwd(const float* dy, const uint8_t* argmax, float* dx, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+template <typename T>
+static int maxpool_bwd_t(const T* dy, const uint8_t* argmax, T* dx, int32_t N, int32_t H, int32_t W, int32_t C, hipStream_t st) {
     if (!dy || !dx || !argmax) return fail(SAT_EINVAL, "maxpool_bwd: null pointer");
     SAT_REQUIRE(C % 4 == 0, "maxpool: C must be a multiple of 4");
     int P = (H + 2 - 3) / 2 + 1, Q = (W + 2 - 3) / 2 + 1;
     long total4 = (long)N * H * W * (C / 4);
-    hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, (hipStream_t)stream, dy, argmax, dx, H, W, C / 4, P, Q, total4);
+    hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel<T>, dim3(cdiv(total4, 256)), dim3(256), 0, st, dy, argmax, dx, H, W, C / 4, P, Q, total4);
     return launch_ok("maxpool_bwd");
+}
+
+extern "C" {
+
+#define SAT_BY_DTYPE(dtype, CALLF, CALLB)                                                \
+    do {                                                                                 \
+        if ((dtype) == 0) return CALLF;                                                  \
+        if ((dtype) == 1) return CALLB;                                                  \
+        return fail(SAT_EINVAL, "dtype %d (0 = fp32, 1 = bf16)", (int)(dtype));           \
+    } while (0)
+typedef __bf16 bf;
+
+int sat_bn_train_fwd_t(int32_t dtype, const void* x, int64_t rows, int32_t C, const float* gamma, const float* beta, float eps, float momentum,
+                       float* running_mean, float* running_var, float* save_mean, float* save_invstd, const void* residual, int32_t relu,
+                       void* y, float* scratch, void* stream) {
+    SAT_BY_DTYPE(dtype,
+        bn_train_fwd_t<float>((const float*)x, rows, C, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, (const float*)residual, relu, (float*)y, scratch, (hipStream_t)stream),
+        bn_train_fwd_t<bf>((const bf*)x, rows, C, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, (const bf*)residual, relu, (bf*)y, scratch, (hipStream_t)stream));
+}
+int sat_bn_train_fwd(const float* x, int64_t rows, int32_t C, const float* gamma, const float* beta, float eps, float momentum,
+                     float* running_mean, float* running_var, float* save_mean, float* save_invstd, const float* residual, int32_t relu,
+                     float* y, float* scratch, void* stream) {
+    return sat_bn_train_fwd_t(0, x, rows, C, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, residual, relu, y, scratch, stream);
+}
+int sat_bn_eval_fwd_t(int32_t dtype, const void* x, int64_t rows, int32_t C, const float* running_mean, const float* running_var, float eps,
+                      const float* gamma, const float* beta, const void* residual, int32_t relu, void* y, void* stream) {
+    SAT_BY_DTYPE(dtype,
+        bn_eval_fwd_t<float>((const float*)x, rows, C, running_mean, running_var, eps, gamma, beta, (const float*)residual, relu, (float*)y, (hipStream_t)stream),
+        bn_eval_fwd_t<bf>((const bf*)x, rows, C, running_mean, running_var, eps, gamma, beta, (const bf*)residual, relu, (bf*)y, (hipStream_t)stream));
+}
+int sat_bn_eval_fwd(const float* x, int64_t rows, int32_t C, const float* running_mean, const float* running_var, float eps,
+                    const float* gamma, const float* beta, const float* residual, int32_t relu, float* y, void* stream) {
+    return sat_bn_eval_fwd_t(0, x, rows, C, running_mean, running_var, eps, gamma, beta, residual, relu, y, stream);
+}
+int sat_bn_train_bwd_t(int32_t dtype, const void* dy, const void* x, const void* y, int64_t rows, int32_t C, const float* save_mean,
+                       const float* save_invstd, const float* gamma, int32_t relu, void* dx, float* dgamma, float* dbeta, void* dres,
+                       int32_t dres_accumulate, float* scratch, void* stream) {
+    SAT_BY_DTYPE(dtype,
+        bn_train_bwd_t<float>((const float*)dy, (const float*)x, (const float*)y, rows, C, save_mean, save_invstd, gamma, relu, (float*)dx, dgamma, dbeta, (float*)dres, dres_accumulate, scratch, (hipStream_t)stream),
+        bn_train_bwd_t<bf>((const bf*)dy, (const bf*)x, (const bf*)y, rows, C, save_mean, save_invstd, gamma, relu, (bf*)dx, dgamma, dbeta, (bf*)dres, dres_accumulate, scratch, (hipStream_t)stream));
+}
+int sat_bn_train_bwd(const float* dy, const float* x, const float* y, int64_t rows, int32_t C, const float* save_mean, const float* save_invstd,
+                     const float* gamma, int32_t relu, float* dx, float* dgamma, float* dbeta, float* dres, int32_t dres_accumulate,
+                     float* scratch, void* stream) {
+    return sat_bn_train_bwd_t(0, dy, x, y, rows, C, save_mean, save_invstd, gamma, relu, dx, dgamma, dbeta, dres, dres_accumulate, scratch, stream);
+}
+int sat_maxpool3x3s2_fwd_t(int32_t dtype, const void* x, void* y, uint8_t* argmax, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+    SAT_BY_DTYPE(dtype, maxpool_fwd_t<float>((const float*)x, (float*)y, argmax, N, H, W, C, (hipStream_t)stream),
+                 maxpool_fwd_t<bf>((const bf*)x, (bf*)y, argmax, N, H, W, C, (hipStream_t)stream));
+}
+int sat_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* argmax, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+    return sat_maxpool3x3s2_fwd_t(0, x, y, argmax, N, H, W, C, stream);
+}
+int sat_maxpool3x3s2_bwd_t(int32_t dtype, const void* dy, const uint8_t* argmax, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+    SAT_BY_DTYPE(dtype, maxpool_bwd_t<float>((const float*)dy, argmax, (float*)dx, N, H, W, C, (hipStream_t)stream),
+                 maxpool_bwd_t<bf>((const bf*)dy, argmax, (bf*)dx, N, H, W, C, (hipStream_t)stream));
+}
+int sat_maxpool3x3s2_bwd(const float* dy, const uint8_t* argmax, float* dx, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+    return sat_maxpool3x3s2_bwd_t(0, dy, argmax, dx, N, H, W, C, stream);
+}
+
+/* bf16 plumbing: casts and the 8-channel stem layout */
+int sat_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
+    if (!src || !dst) return fail(SAT_EINVAL, "cast: null pointer");
+    SAT_REQUIRE(n % 4 == 0, "cast: element count must be a multiple of 4");
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, src, (bf*)dst, (long)(n / 4));
+    return launch_ok("cast_f32_bf16");
+}
+int sat_image_normalize_nhwc8_bf16(const float* img_nchw, void* out_nhwc8, int32_t N, int32_t H, int32_t W, const float* mean3_host, const float* std3_host, void* stream) {
+    if (!img_nchw || !out_nhwc8 || !mean3_host || !std3_host) return fail(SAT_EINVAL, "image_normalize: null pointer");
+    long total = (long)N * H * W;
+    hipLaunchKernelGGL(normalize_nhwc8_bf16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, img_nchw, (bf*)out_nhwc8, H, W, total,
+                       mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2]);
+    return launch_ok("normalize_nhwc8_bf16");
+}
+int sat_stem_filter_pad(const float* w3, void* w8_bf16, int64_t pixels, void* stream) {
+    if (!w3 || !w8_bf16) return fail(SAT_EINVAL, "stem_filter_pad: null pointer");
+    hipLaunchKernelGGL(pad_c3_to_c8_bf16_kernel, dim3(cdiv(pixels, 256)), dim3(256), 0, (hipStream_t)stream, w3, (bf*)w8_bf16, (long)pixels);
+    return launch_ok("pad_c3_to_c8_bf16");
+}
+int sat_stem_filter_grad_unpad(const float* dw8, float* dw3, int64_t pixels, void* stream) {
+    if (!dw8 || !dw3) return fail(SAT_EINVAL, "stem_filter_grad_unpad: null pointer");
+    hipLaunchKernelGGL(unpad_c8_to_c3_kernel, dim3(cdiv(pixels, 256)), dim3(256), 0, (hipStream_t)stream, dw8, dw3, (long)pixels);
+    return launch_ok("unpad_c8_to_c3");
 }
 
 int sat_resize_fwd(const float* x, float* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t P, int32_t Q, void* stream) {

@@ -74,22 +74,42 @@ def _out_hw(H, W, R, S, stride, pad):
     return (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
 
 
+BF16 = torch.bfloat16
+
+
+def _is_bf(t):
+    return t.dtype == BF16
+
+
+def cast_bf16(t):
+    """fp32 -> bf16 copy through the library (filters, small gradient maps)."""
+    t = t.contiguous() if t.dim() != 4 else _krsc(t)
+    out = torch.empty(t.shape, dtype=BF16, device=t.device)
+    if t.dim() == 4:
+        out = out.contiguous(memory_format=torch.channels_last)
+    L.check(L.lib().sat_cast_f32_to_bf16(L.ptr(t), L.ptr(out), t.numel(), L.stream_ptr()), "sat_cast_f32_to_bf16")
+    return out
+
+
 def conv_fwd(x, w, stride, pad, bias=None):
+    """x NHWC (fp32 or bf16); w (K,C,R,S) in KRSC memory with x's dtype."""
     N, H, W, Cc = x.shape
     K, _, R, S = w.shape
     P, Q = _out_hw(H, W, R, S, stride, pad)
-    y = torch.empty(N, P, Q, K, dtype=torch.float32, device=x.device)
+    y = torch.empty(N, P, Q, K, dtype=x.dtype, device=x.device)
     g = _geom(N, H, W, Cc, K, R, S, stride, pad)
-    L.check(L.lib().sat_conv2d_fwd(L.ptr(x), L.ptr(_krsc(w)), L.ptr(bias), L.ptr(y), C.byref(g), L.stream_ptr()), "sat_conv2d_fwd")
+    fn = L.lib().sat_conv2d_fwd_bf16 if _is_bf(x) else L.lib().sat_conv2d_fwd
+    L.check(fn(L.ptr(x), L.ptr(_krsc(w)), L.ptr(bias), L.ptr(y), C.byref(g), L.stream_ptr()), "sat_conv2d_fwd")
     return y
 
 
 def conv_dgrad(dy, w, x_shape, stride, pad, out=None, accumulate=False):
     N, H, W, Cc = x_shape
     K, _, R, S = w.shape
-    dx = out if out is not None else torch.empty(N, H, W, Cc, dtype=torch.float32, device=dy.device)
+    dx = out if out is not None else torch.empty(N, H, W, Cc, dtype=dy.dtype, device=dy.device)
     g = _geom(N, H, W, Cc, K, R, S, stride, pad)
-    L.check(L.lib().sat_conv2d_dgrad(L.ptr(dy), L.ptr(_krsc(w)), L.ptr(dx), C.byref(g), int(accumulate), L.stream_ptr()), "sat_conv2d_dgrad")
+    fn = L.lib().sat_conv2d_dgrad_bf16 if _is_bf(dy) else L.lib().sat_conv2d_dgrad
+    L.check(fn(L.ptr(dy), L.ptr(_krsc(w)), L.ptr(dx), C.byref(g), int(accumulate), L.stream_ptr()), "sat_conv2d_dgrad")
     return dx
 
 
@@ -100,21 +120,22 @@ def _slab(device, nbytes):
     key = (device.index if device.index is not None else torch.cuda.current_device())
     cur = _slabs.get(key)
     if cur is None or cur.numel() * 4 < nbytes:
-        cur = torch.empty(max(nbytes // 4, 1 << 20), dtype=torch.float32, device=device)
+        cur = torch.empty(max(nbytes // 4, 4 << 20), dtype=torch.float32, device=device)
         _slabs[key] = cur
     return cur
 
 
 def conv_wgrad(dy, x, w, stride, pad):
+    """fp32 gradient of the (K,C,R,S) filter, whatever the activation storage."""
     N, H, W, Cc = x.shape
     K, _, R, S = w.shape
     g = _geom(N, H, W, Cc, K, R, S, stride, pad)
     lib = L.lib()
-    nbytes = lib.sat_conv2d_wgrad_slab_bytes(C.byref(g))
-    slab = _slab(x.device, nbytes) if nbytes else None
+    nbytes = max(lib.sat_conv2d_wgrad_slab_bytes(C.byref(g)), 16 << 20)
+    slab = _slab(x.device, nbytes)
     dw = torch.empty(K, R, S, Cc, dtype=torch.float32, device=x.device)       # KRSC
-    L.check(lib.sat_conv2d_wgrad(L.ptr(dy), L.ptr(x), L.ptr(dw), C.byref(g), L.ptr(slab), 0 if slab is None else slab.numel(),
-                                 L.stream_ptr()), "sat_conv2d_wgrad")
+    fn = lib.sat_conv2d_wgrad_bf16 if _is_bf(x) else lib.sat_conv2d_wgrad
+    L.check(fn(L.ptr(dy), L.ptr(x), L.ptr(dw), C.byref(g), L.ptr(slab), slab.numel(), L.stream_ptr()), "sat_conv2d_wgrad")
     return dw.permute(0, 3, 1, 2)                                             # (K,C,R,S) view, channels_last memory
 
 
@@ -122,17 +143,18 @@ def bn_fwd(x, bn, residual=None, relu=True, training=True):
     lib = L.lib()
     Cc = x.shape[-1]; rows = x.numel() // Cc
     y = torch.empty_like(x)
+    dt = int(_is_bf(x))
     if training:
         mean = torch.empty(Cc, dtype=torch.float32, device=x.device); invstd = torch.empty_like(mean)
         scratch = torch.empty(lib.sat_bn_scratch_bytes(rows, Cc) // 8 + 1, dtype=torch.float64, device=x.device)
         mom = 0.1 if bn.momentum is None else float(bn.momentum)
-        L.check(lib.sat_bn_train_fwd(L.ptr(x), rows, Cc, L.ptr(bn.weight), L.ptr(bn.bias), float(bn.eps), mom, L.ptr(bn.running_mean),
-                                     L.ptr(bn.running_var), L.ptr(mean), L.ptr(invstd), L.ptr(residual), int(relu), L.ptr(y), L.ptr(scratch),
-                                     L.stream_ptr()), "sat_bn_train_fwd")
+        L.check(lib.sat_bn_train_fwd_t(dt, L.ptr(x), rows, Cc, L.ptr(bn.weight), L.ptr(bn.bias), float(bn.eps), mom, L.ptr(bn.running_mean),
+                                       L.ptr(bn.running_var), L.ptr(mean), L.ptr(invstd), L.ptr(residual), int(relu), L.ptr(y), L.ptr(scratch),
+                                       L.stream_ptr()), "sat_bn_train_fwd")
         bn.num_batches_tracked += 1
         return y, (mean, invstd)
-    L.check(lib.sat_bn_eval_fwd(L.ptr(x), rows, Cc, L.ptr(bn.running_mean), L.ptr(bn.running_var), float(bn.eps), L.ptr(bn.weight),
-                                L.ptr(bn.bias), L.ptr(residual), int(relu), L.ptr(y), L.stream_ptr()), "sat_bn_eval_fwd")
+    L.check(lib.sat_bn_eval_fwd_t(dt, L.ptr(x), rows, Cc, L.ptr(bn.running_mean), L.ptr(bn.running_var), float(bn.eps), L.ptr(bn.weight),
+                                  L.ptr(bn.bias), L.ptr(residual), int(relu), L.ptr(y), L.stream_ptr()), "sat_bn_eval_fwd")
     return y, None
 
 
@@ -142,9 +164,9 @@ def bn_bwd(dy, x, y, stats, bn, relu, dres=None, dres_accumulate=False):
     dx = torch.empty_like(x)
     dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device); dbeta = torch.empty_like(dgamma)
     scratch = torch.empty(lib.sat_bn_scratch_bytes(rows, Cc) // 8 + 1, dtype=torch.float64, device=x.device)
-    L.check(lib.sat_bn_train_bwd(L.ptr(dy), L.ptr(x), L.ptr(y), rows, Cc, L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(bn.weight), int(relu),
-                                 L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dres), int(dres_accumulate), L.ptr(scratch), L.stream_ptr()),
-            "sat_bn_train_bwd")
+    L.check(lib.sat_bn_train_bwd_t(int(_is_bf(x)), L.ptr(dy), L.ptr(x), L.ptr(y), rows, Cc, L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(bn.weight),
+                                   int(relu), L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dres), int(dres_accumulate), L.ptr(scratch),
+                                   L.stream_ptr()), "sat_bn_train_bwd")
     return dx, dgamma, dbeta
 
 
@@ -161,41 +183,44 @@ class _Rec:
     __slots__ = ("kind", "blk", "x", "c1", "a1", "s1", "c2", "a2", "s2", "c3", "s3", "cd", "sd", "idn", "out")
 
 
-def _block_fwd(blk, x, training):
+def _block_fwd(blk, x, training, W=None):
+    """W maps a filter parameter to the tensor the kernels read (its bf16 copy in bf16 mode)."""
+    W = W or (lambda p: p)
     r = _Rec(); r.kind, r.blk, r.x = blk.kind, blk, x
     r.cd = r.sd = None
     if blk.downsample is not None:
-        r.cd = conv_fwd(x, blk.downsample[0].weight, blk.stride, 0)
+        r.cd = conv_fwd(x, W(blk.downsample[0].weight), blk.stride, 0)
         r.idn, r.sd = bn_fwd(r.cd, blk.downsample[1], None, False, training)
     else:
         r.idn = x
     if blk.kind == "basic":
-        r.c1 = conv_fwd(x, blk.conv1.weight, blk.stride, 1); r.a1, r.s1 = bn_fwd(r.c1, blk.bn1, None, True, training)
-        r.c2 = conv_fwd(r.a1, blk.conv2.weight, 1, 1)
+        r.c1 = conv_fwd(x, W(blk.conv1.weight), blk.stride, 1); r.a1, r.s1 = bn_fwd(r.c1, blk.bn1, None, True, training)
+        r.c2 = conv_fwd(r.a1, W(blk.conv2.weight), 1, 1)
         r.out, r.s2 = bn_fwd(r.c2, blk.bn2, r.idn, True, training)
     else:
-        r.c1 = conv_fwd(x, blk.conv1.weight, 1, 0); r.a1, r.s1 = bn_fwd(r.c1, blk.bn1, None, True, training)
-        r.c2 = conv_fwd(r.a1, blk.conv2.weight, blk.stride, 1); r.a2, r.s2 = bn_fwd(r.c2, blk.bn2, None, True, training)
-        r.c3 = conv_fwd(r.a2, blk.conv3.weight, 1, 0)
+        r.c1 = conv_fwd(x, W(blk.conv1.weight), 1, 0); r.a1, r.s1 = bn_fwd(r.c1, blk.bn1, None, True, training)
+        r.c2 = conv_fwd(r.a1, W(blk.conv2.weight), blk.stride, 1); r.a2, r.s2 = bn_fwd(r.c2, blk.bn2, None, True, training)
+        r.c3 = conv_fwd(r.a2, W(blk.conv3.weight), 1, 0)
         r.out, r.s3 = bn_fwd(r.c3, blk.bn3, r.idn, True, training)
     return r
 
 
-def _block_bwd(r, dout, grads, need_dx):
+def _block_bwd(r, dout, grads, need_dx, W=None):
+    W = W or (lambda p: p)
     blk = r.blk
     g = torch.empty_like(r.out)                      # gradient of the residual branch (= dout masked by the final ReLU)
     if blk.kind == "basic":
         dx2, grads[blk.bn2.weight], grads[blk.bn2.bias] = bn_bwd(dout, r.c2, r.out, r.s2, blk.bn2, True, dres=g)
         grads[blk.conv2.weight] = conv_wgrad(dx2, r.a1, blk.conv2.weight, 1, 1)
-        da1 = conv_dgrad(dx2, blk.conv2.weight, r.a1.shape, 1, 1)
+        da1 = conv_dgrad(dx2, W(blk.conv2.weight), r.a1.shape, 1, 1)
         first_w, first_stride, first_pad = blk.conv1.weight, blk.stride, 1
     else:
         dx3, grads[blk.bn3.weight], grads[blk.bn3.bias] = bn_bwd(dout, r.c3, r.out, r.s3, blk.bn3, True, dres=g)
         grads[blk.conv3.weight] = conv_wgrad(dx3, r.a2, blk.conv3.weight, 1, 0)
-        da2 = conv_dgrad(dx3, blk.conv3.weight, r.a2.shape, 1, 0)
+        da2 = conv_dgrad(dx3, W(blk.conv3.weight), r.a2.shape, 1, 0)
         dx2, grads[blk.bn2.weight], grads[blk.bn2.bias] = bn_bwd(da2, r.c2, r.a2, r.s2, blk.bn2, True)
         grads[blk.conv2.weight] = conv_wgrad(dx2, r.a1, blk.conv2.weight, blk.stride, 1)
-        da1 = conv_dgrad(dx2, blk.conv2.weight, r.a1.shape, blk.stride, 1)
+        da1 = conv_dgrad(dx2, W(blk.conv2.weight), r.a1.shape, blk.stride, 1)
         first_w, first_stride, first_pad = blk.conv1.weight, 1, 0
     dx1, grads[blk.bn1.weight], grads[blk.bn1.bias] = bn_bwd(da1, r.c1, r.a1, r.s1, blk.bn1, True)
     grads[first_w] = conv_wgrad(dx1, r.x, first_w, first_stride, first_pad)
@@ -204,14 +229,18 @@ def _block_bwd(r, dout, grads, need_dx):
         grads[blk.downsample[0].weight] = conv_wgrad(dxd, r.x, blk.downsample[0].weight, blk.stride, 0)
         if not need_dx:
             return None
-        dx = conv_dgrad(dxd, blk.downsample[0].weight, r.x.shape, blk.stride, 0)
-        return conv_dgrad(dx1, first_w, r.x.shape, first_stride, first_pad, out=dx, accumulate=True)
+        dx = conv_dgrad(dxd, W(blk.downsample[0].weight), r.x.shape, blk.stride, 0)
+        return conv_dgrad(dx1, W(first_w), r.x.shape, first_stride, first_pad, out=dx, accumulate=True)
     if not need_dx:
         return None
-    return conv_dgrad(dx1, first_w, r.x.shape, first_stride, first_pad, out=g, accumulate=True)   # identity path + conv path
+    return conv_dgrad(dx1, W(first_w), r.x.shape, first_stride, first_pad, out=g, accumulate=True)   # identity path + conv path
 
 
 class EncoderFn(torch.autograd.Function):
+    """img (B,3,H,W) fp32 in [0,1] -> annotations (B,D,h,w) fp32 (NHWC memory).  ``enc.precision``:
+    "fp32" = fp32 activations on the exact fp32 MFMA kernel (parity mode); "bf16" = bf16 activations and
+    filter copies on the bf16 MFMA kernel, fp32 statistics / gradients of parameters / master weights."""
+
     @staticmethod
     def forward(ctx, img, enc, *params):
         lib = L.lib()
@@ -220,71 +249,120 @@ class EncoderFn(torch.autograd.Function):
             raise ValueError("encoder input must be (B,3,H,W) fp32 in [0,1]")
         img = img.contiguous()
         training = enc.training
+        bf = enc.precision == "bf16"
+        adt = BF16 if bf else torch.float32
         N, _, H, W = img.shape
         st = L.stream_ptr()
         t = {}
-        x0 = torch.empty(N, H, W, 4, dtype=torch.float32, device=img.device)
+        wcopy = {}
+
+        def Wt(p):                       # the tensor the kernels read for filter parameter p
+            if not bf:
+                return p
+            c = wcopy.get(p)
+            if c is None:
+                c = wcopy[p] = cast_bf16(p)
+            return c
+
         mean = (C.c_float * 3)(*enc[0].mean); std = (C.c_float * 3)(*enc[0].std)
-        L.check(lib.sat_image_normalize_nhwc4(L.ptr(img), L.ptr(x0), N, H, W, mean, std, st), "sat_image_normalize_nhwc4")
         conv1 = enc[1]
         w3 = _krsc(conv1.weight)                                                   # (64,3,7,7), memory 64,7,7,3
-        w4 = torch.empty(conv1.out_channels, 4, 7, 7, dtype=torch.float32, device=img.device).contiguous(memory_format=torch.channels_last)
-        L.check(lib.sat_pad_channels_3to4(L.ptr(w3), L.ptr(w4), conv1.out_channels * 49, 0, st), "sat_pad_channels_3to4")
-        t["x0"], t["w4"] = x0, w4
-        t["c0"] = conv_fwd(x0, w4, 2, 3)
+        cpad = 8 if bf else 4
+        x0 = torch.empty(N, H, W, cpad, dtype=adt, device=img.device)
+        wp = torch.empty(conv1.out_channels, cpad, 7, 7, dtype=adt, device=img.device).contiguous(memory_format=torch.channels_last)
+        if bf:
+            L.check(lib.sat_image_normalize_nhwc8_bf16(L.ptr(img), L.ptr(x0), N, H, W, mean, std, st), "sat_image_normalize_nhwc8_bf16")
+            L.check(lib.sat_stem_filter_pad(L.ptr(w3), L.ptr(wp), conv1.out_channels * 49, st), "sat_stem_filter_pad")
+        else:
+            L.check(lib.sat_image_normalize_nhwc4(L.ptr(img), L.ptr(x0), N, H, W, mean, std, st), "sat_image_normalize_nhwc4")
+            L.check(lib.sat_pad_channels_3to4(L.ptr(w3), L.ptr(wp), conv1.out_channels * 49, 0, st), "sat_pad_channels_3to4")
+        t["x0"], t["wp"] = x0, wp
+        t["c0"] = conv_fwd(x0, wp, 2, 3)
         t["a0"], t["s0"] = bn_fwd(t["c0"], enc[2], None, True, training)
         Nn, Hh, Ww, Cc = t["a0"].shape
         P, Q = (Hh + 2 - 3) // 2 + 1, (Ww + 2 - 3) // 2 + 1
-        t["p0"] = torch.empty(Nn, P, Q, Cc, dtype=torch.float32, device=img.device)
+        t["p0"] = torch.empty(Nn, P, Q, Cc, dtype=adt, device=img.device)
         t["amax"] = torch.empty(Nn, P, Q, Cc, dtype=torch.uint8, device=img.device)
-        L.check(lib.sat_maxpool3x3s2_fwd(L.ptr(t["a0"]), L.ptr(t["p0"]), L.ptr(t["amax"]), Nn, Hh, Ww, Cc, st), "sat_maxpool3x3s2_fwd")
+        L.check(lib.sat_maxpool3x3s2_fwd_t(int(bf), L.ptr(t["a0"]), L.ptr(t["p0"]), L.ptr(t["amax"]), Nn, Hh, Ww, Cc, st), "sat_maxpool3x3s2_fwd")
         x = t["p0"]
         recs = []
         for li in (5, 6, 7, 8):
             for blk in enc[li]:
-                r = _block_fwd(blk, x, training)
+                r = _block_fwd(blk, x, training, Wt)
                 recs.append(r); x = r.out
         t["trunk"] = x
         if enc.proj is not None:
-            x = conv_fwd(x, enc.proj.weight, 1, 0, enc.proj.bias)
+            Nn, Hh, Ww, Cc = x.shape
+            D = enc.proj.out_channels
+            if bf:        # 1x1 projection: bf16 x bf16 -> fp32 annotations (+bias) on the bf16 MFMA kernel
+                from .decoder import gemm
+                y = torch.empty(Nn, Hh, Ww, D, dtype=torch.float32, device=img.device)
+                gemm(x.view(-1, Cc), Wt(enc.proj.weight).view(D, Cc), out=y.view(-1, D), bias=enc.proj.bias, epi=1, bf16_mfma=True)
+                x = y
+            else:
+                x = conv_fwd(x, enc.proj.weight, 1, 0, enc.proj.bias)
+        elif bf:
+            raise NotImplementedError("bf16 encoder without the 1x1 projection (encoder_dim == trunk width) is not built")
         t["proj_out"] = x
         if enc.out_size is not None and enc.out_size != x.shape[1]:
             Nn, Hh, Ww, Cc = x.shape
             y = torch.empty(Nn, enc.out_size, enc.out_size, Cc, dtype=torch.float32, device=img.device)
             L.check(lib.sat_resize_fwd(L.ptr(x), L.ptr(y), Nn, Hh, Ww, Cc, enc.out_size, enc.out_size, st), "sat_resize_fwd")
             x = y
-        ctx.t, ctx.recs, ctx.enc = t, recs, enc
+        ctx.t, ctx.recs, ctx.enc, ctx.Wt, ctx.bf = t, recs, enc, Wt, bf
         ctx.params = params
         return x.permute(0, 3, 1, 2)            # (B, D, h, w) view over NHWC memory
 
     @staticmethod
     def backward(ctx, dann):
         lib = L.lib()
-        enc, t, recs = ctx.enc, ctx.t, ctx.recs
+        enc, t, recs, Wt, bf = ctx.enc, ctx.t, ctx.recs, ctx.Wt, ctx.bf
         st = L.stream_ptr()
         grads = {}
-        d = dann.permute(0, 2, 3, 1).contiguous()                                 # NHWC (no copy when it already is)
+        cb = getattr(enc, "grad_ready", None)          # optional hook: called with {param: grad} as stages finish
+        d = dann.permute(0, 2, 3, 1).contiguous()                                 # NHWC fp32 (no copy when it already is)
         if enc.out_size is not None and enc.out_size != t["proj_out"].shape[1]:
             Nn, Hh, Ww, Cc = t["proj_out"].shape
             dx = torch.empty_like(t["proj_out"])
             L.check(lib.sat_resize_bwd(L.ptr(d), L.ptr(dx), Nn, Hh, Ww, Cc, enc.out_size, enc.out_size, st), "sat_resize_bwd")
             d = dx
         if enc.proj is not None:
-            grads[enc.proj.weight] = conv_wgrad(d, t["trunk"], enc.proj.weight, 1, 0)
             grads[enc.proj.bias] = colsum(d.reshape(-1, d.shape[-1]))
-            d = conv_dgrad(d, enc.proj.weight, t["trunk"].shape, 1, 0) if enc.trunk_trainable else None
+            if bf:
+                from .decoder import gemm
+                D = enc.proj.out_channels; Cc = t["trunk"].shape[-1]
+                db = cast_bf16(d.reshape(-1, D))
+                dw = torch.empty(D, Cc, dtype=torch.float32, device=d.device)
+                gemm(db, t["trunk"].view(-1, Cc), amode=1, bmode=1, out=dw, slab=_slab(d.device, 16 << 20), bf16_mfma=True)
+                grads[enc.proj.weight] = dw.view(D, Cc, 1, 1)
+                if enc.trunk_trainable:
+                    dtr = torch.empty(t["trunk"].shape, dtype=BF16, device=d.device)
+                    gemm(db, Wt(enc.proj.weight).view(D, Cc), amode=0, bmode=1, out=dtr.view(-1, Cc), bf16_mfma=True)
+                    d = dtr
+            else:
+                grads[enc.proj.weight] = conv_wgrad(d, t["trunk"], enc.proj.weight, 1, 0)
+                d = conv_dgrad(d, enc.proj.weight, t["trunk"].shape, 1, 0) if enc.trunk_trainable else None
         if enc.trunk_trainable:
-            for r in reversed(recs):
-                d = _block_bwd(r, d, grads, True)
+            n_per_stage = [len(enc[li]) for li in (5, 6, 7, 8)]
+            bounds, acc = [], 0
+            for n in n_per_stage:
+                acc += n; bounds.append(acc)
+            for idx in range(len(recs) - 1, -1, -1):
+                d = _block_bwd(recs[idx], d, grads, True, Wt)
+                if cb is not None and idx in (bounds[2], bounds[1], bounds[0]):      # a ResNet stage just finished
+                    cb(dict(grads))
             Nn, Hh, Ww, Cc = t["a0"].shape
             da0 = torch.empty_like(t["a0"])
-            L.check(lib.sat_maxpool3x3s2_bwd(L.ptr(d), L.ptr(t["amax"]), L.ptr(da0), Nn, Hh, Ww, Cc, st), "sat_maxpool3x3s2_bwd")
+            L.check(lib.sat_maxpool3x3s2_bwd_t(int(bf), L.ptr(d), L.ptr(t["amax"]), L.ptr(da0), Nn, Hh, Ww, Cc, st), "sat_maxpool3x3s2_bwd")
             dc0, grads[enc[2].weight], grads[enc[2].bias] = bn_bwd(da0, t["c0"], t["a0"], t["s0"], enc[2], True)
-            dw4 = conv_wgrad(dc0, t["x0"], t["w4"], 2, 3)                          # (64,4,7,7) view of KRS4 memory
+            dwp = conv_wgrad(dc0, t["x0"], t["wp"], 2, 3)                          # (64,cpad,7,7) view of KRS{4,8} fp32 memory
             dw3 = torch.empty_like(_krsc(enc[1].weight))
-            L.check(lib.sat_pad_channels_3to4(L.ptr(dw4), L.ptr(dw3), enc[1].out_channels * 49, 1, st), "sat_pad_channels_3to4")
+            if bf:
+                L.check(lib.sat_stem_filter_grad_unpad(L.ptr(dwp), L.ptr(dw3), enc[1].out_channels * 49, st), "sat_stem_filter_grad_unpad")
+            else:
+                L.check(lib.sat_pad_channels_3to4(L.ptr(dwp), L.ptr(dw3), enc[1].out_channels * 49, 1, st), "sat_pad_channels_3to4")
             grads[enc[1].weight] = dw3
-        ctx.t = ctx.recs = None
+        ctx.t = ctx.recs = ctx.Wt = None
         return (None, None, *[grads.get(p) if p.requires_grad else None for p in ctx.params])
 
 
@@ -296,6 +374,7 @@ class HipEncoder(nn.Sequential):
         super().__init__(*mods)
         self.__dict__["proj"] = proj              # not registered twice: index 9 already owns it
         self.out_size = out_size
+        self.precision = "fp32"                   # or "bf16" (see EncoderFn)
 
     @property
     def trunk_trainable(self):

@@ -140,7 +140,7 @@ class SATDecoder(nn.Module):
         caps2 = caps.reshape(B * R, T)
         caps_i32 = caps2.to(device=ann_bld.device, dtype=torch.int32).contiguous()
         logits_packed, alphas = Dk.DecoderTrainFn.apply(ann_bld, caps_i32, plan, teacher, bool(self.hp.deep_output), self.pad_idx, R,
-                                                        int(getattr(self, "precision", 0)), *self.param_list())
+                                                        int(getattr(self, "sat_precision", "fp32") == "bf16"), *self.param_list())
         targets_packed = plan.pack(caps2[:, 1:].to(ann_bld.device).unsqueeze(-1)).squeeze(-1)
         if not with_loss:
             return dict(logits_packed=logits_packed, targets_packed=targets_packed, alphas=alphas, plan=plan)
@@ -173,10 +173,20 @@ class SAT(SATDecoder, _Base):
         # reference order: criterion -> encoder -> decoder parts (model.py:148-195); get_encoder writes
         # hp.encoder_dim back when no projection is needed (model.py:56)
         self._build_decoder(hp, encoder_factory=get_encoder)
+        self.set_precision(hp.get("hip_precision", "fp32"))
         if hp.pretrained_embedding is not None:
             import numpy as np
             self.embedding.weight = nn.Parameter(torch.tensor(np.load(hp.pretrained_embedding), dtype=torch.float32))
         self.special_idxs = [self.stoi("<PAD>"), self.stoi("<START>"), self.stoi("<END>")]
+
+    def set_precision(self, mode):
+        """"fp32": exact fp32 MFMA everywhere (parity mode).  "bf16": bf16 matrix cores with fp32 accumulation --
+        bf16 activations/filter copies in the encoder, fp32 decoder state rounded on the way into LDS; master
+        weights, gradients of parameters, statistics and losses stay fp32."""
+        if mode not in ("fp32", "bf16"):
+            raise ValueError("hip_precision must be 'fp32' or 'bf16'")
+        self.sat_precision = mode
+        self.encoder.precision = mode
 
     # Lightning gives `hparams`; without Lightning keep the same attribute
     @property

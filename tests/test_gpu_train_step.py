@@ -13,7 +13,7 @@ def rel(a, b):
     return float((a - b).abs().max()) / max(1.0, float(b.abs().max()))
 
 
-def make(hp_over=None, seed=42):
+def make(hp_over=None, seed=42, damp_residual=None):
     import sat_amd  # noqa: F401
     from sat_amd import model as M
     from oracle import sat_oracle as O
@@ -24,6 +24,10 @@ def make(hp_over=None, seed=42):
     hp = O.default_hparams(**over)
     torch.manual_seed(seed)
     model = M.SAT(**vars(hp))
+    if damp_residual is not None:              # scale the last BatchNorm of every residual branch (a well-conditioned net)
+        with torch.no_grad():
+            for blk in [b for li in (5, 6, 7, 8) for b in model.encoder[li]]:
+                (blk.bn3 if blk.kind == "bottleneck" else blk.bn2).weight.fill_(damp_residual)
     oracle = O.OracleSAT(O.default_hparams(**over), {k: v.clone() for k, v in model.state_dict().items()})
     return model.cuda().train(), oracle, hp
 
@@ -104,3 +108,40 @@ def test_frozen_encoder_and_state_dict_roundtrip():
     with torch.no_grad():
         a, _ = model.encode(img.cuda()); b, _ = clone.encode(img.cuda())
     assert torch.equal(a, b)
+
+
+def test_bf16_mode_tracks_the_fp32_oracle():
+    """hip_precision="bf16" (BASELINE configs[1]) has no reference counterpart (the reference only has fp16 AMP).
+    Stated tolerance against the fp32 oracle: loss 2e-2 relative, logits 6e-2 of their range, alphas 2e-2 absolute,
+    decoder-side gradients 0.15 relative L2, encoder gradients cosine >= 0.9 with the fp32 ones (bf16 has 8 significant
+    bits; ReLU decisions flip near zero and compound over the residual stack, test_gpu_encoder.py quantifies one block;
+    accumulation, statistics and master weights are fp32)."""
+    model, oracle, hp = make(dict(decoder_tf="always", encoder_dim=32, embed_dim=32, attention_dim=16, decoder_dim=64, vocab_size=128,
+                                  input_size=128, encoder_size=None), damp_residual=0.25)
+    model.set_precision("bf16")
+    img, caps, lengths = batch(hp, B=16)        # 128 px, batch 16: 256 samples per channel in the last stage's BatchNorms
+    loss_o, out_o = oracle.step_loss(img, caps, lengths, 1.0)
+    loss_o.backward()
+    lp, tp, alphas = model.train_batch((img.cuda(), caps.cuda(), lengths), 1.0)
+    assert lp.data.dtype == torch.float32 and alphas.dtype == torch.float32
+    assert rel(lp.data, out_o["logits_packed"]) <= 6e-2
+    assert float((alphas.cpu() - out_o["alphas"]).abs().max()) <= 2e-2
+    m = model.training_step((img.cuda(), caps.cuda(), lengths), 0)
+    assert abs(m["loss"].item() - loss_o.item()) <= 2e-2 * abs(loss_o.item())
+    m["loss"].backward()
+    og = oracle.named_grads()
+    worst = 0.0
+    for k, p in model.named_parameters():
+        assert p.grad is not None and p.grad.dtype == torch.float32 and torch.isfinite(p.grad).all(), k
+        e = float((p.grad.cpu().double() - og[k].double()).norm()) / max(1e-9, float(og[k].double().norm()))
+        worst = max(worst, e)
+        print("%-40s %.3e" % (k, e))
+        # the batch-8 ResNet amplifies rounding in front of its BatchNorms (test_gpu_encoder: fp32 itself is 2e-2 off
+        # fp64 there); decoder-side tensors are well conditioned
+        if k.startswith("encoder.") and not k.startswith("encoder.9"):
+            a, b = p.grad.cpu().double().flatten(), og[k].double().flatten()
+            cos = float(a @ b / (a.norm() * b.norm() + 1e-30))
+            assert cos >= 0.9, "%s: cosine with the fp32 gradient %.3f" % (k, cos)
+        else:
+            assert e <= 0.15, "%s: relative L2 gradient error %.3e" % (k, e)
+    print("bf16 mode: worst relative L2 gradient error", worst)
