@@ -77,84 +77,127 @@ __global__ void unpad_c4_to_c3_kernel(const float* __restrict__ w4, float* __res
 }
 
 // ------------------------------------------------------------------ BatchNorm (training mode)
-// Column statistics of a (rows x C) matrix, C % 4 == 0.  Block = 256 threads = TW vector-columns x RL row lanes.
-// MODE 0: sum x, sum x^2.   MODE 1: sum g, sum g*xhat with g = dy * (relu ? y > 0 : 1).
-struct d4 { double x, y, z, w; };
+// Column statistics of a (rows x C) activation matrix, streamed at 16 bytes per lane.
+//   MODE 0: sum (x - s), sum (x - s)^2 with the shift s = first row (keeps the variance well conditioned)
+//   MODE 1: sum g, sum g * xhat          with g = dy * (relu ? y > 0 : 1)
+// Block = 256 threads = CV vector columns x RL row lanes; each block owns a row chunk and writes one partial
+// per channel.  Accumulation is in double (these kernels are HBM-bound; the fp64 adds are free and the sums
+// then match ATen's CPU batch-norm, which accumulates float inputs in double).  Fixed order => deterministic.
+template <typename T> struct EPT { static constexpr int n = 16 / sizeof(T); };          // elements per 16-byte vector
+template <typename T, int N> __device__ __forceinline__ void ldv(const T* p, long iv, float (&o)[N]);
+template <> __device__ __forceinline__ void ldv<float, 4>(const float* p, long iv, float (&o)[4]) {
+    float4 v = reinterpret_cast<const float4*>(p)[iv]; o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+template <> __device__ __forceinline__ void ldv<__bf16, 8>(const __bf16* p, long iv, float (&o)[8]) {
+    typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+    b8 v = reinterpret_cast<const b8*>(p)[iv];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+}
+
 template <int MODE, typename T>
 __global__ __launch_bounds__(256) void bn_colstats_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
                                                           const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
-                                                          long rows, int C, int TW, long rows_per, double* __restrict__ part0, double* __restrict__ part1,
-                                                          float* __restrict__ part2) {
-    // double accumulators: these kernels are HBM-bound, the fp64 adds are free, and the sums then match the
-    // accuracy of ATen's CPU batch-norm (which accumulates float inputs in double)
-    __shared__ d4 s0[256], s1[256];
-    const int tid = threadIdx.x, tc = tid % TW, tr = tid / TW, RL = 256 / TW;
-    const int c4 = blockIdx.x * TW + tc;           // vector column
-    const int C4 = C >> 2;
-    d4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
-    if (c4 < C4 && tr < RL) {
-        float4 mu = make_float4(0, 0, 0, 0), is = mu;
+                                                          long rows, int C, int CV, long rows_per, double* __restrict__ part0, double* __restrict__ part1) {
+    constexpr int E = EPT<T>::n;
+    __shared__ double sh[2][256][E > 4 ? 4 : E];      // reduced in two halves when E == 8
+    const int tid = threadIdx.x, tc = tid % CV, tr = tid / CV, RL = 256 / CV;
+    const int cv = blockIdx.x * CV + tc;              // vector column
+    const int CVT = C / E;
+    double a0[E], a1[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) { a0[i] = 0.0; a1[i] = 0.0; }
+    const bool act = cv < CVT && tr < RL;
+    if (act) {
+        float mu[E], is[E];
+        if (MODE == 1) {
+#pragma unroll
+            for (int i = 0; i < E; ++i) { mu[i] = mean[cv * E + i]; is[i] = invstd[cv * E + i]; }
+        } else ldv<T, E>(x, cv, mu);                 // shift = row 0
         long r0 = (long)blockIdx.y * rows_per, r1 = r0 + rows_per; if (r1 > rows) r1 = rows;
-        if (MODE == 1) { mu = reinterpret_cast<const float4*>(mean)[c4]; is = reinterpret_cast<const float4*>(invstd)[c4]; }
-        else {
-            // shifted sums: d = x - (first row of this chunk) keeps sum d^2 - (sum d)^2/n well conditioned
-            mu = ld4<T>(x, r0 * C4 + c4);
-            if (tr == 0) reinterpret_cast<float4*>(part2)[(long)blockIdx.y * C4 + c4] = mu;
+        long r = r0 + tr;
+        for (; r + 3L * RL < r1; r += 4L * RL) {     // 4 independent 16-byte loads in flight per operand
+            float xv[4][E], gv[4][E], yv[4][E];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                ldv<T, E>(x, (r + (long)u * RL) * CVT + cv, xv[u]);
+                if (MODE == 1) { ldv<T, E>(dy, (r + (long)u * RL) * CVT + cv, gv[u]); if (relu) ldv<T, E>(y, (r + (long)u * RL) * CVT + cv, yv[u]); }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < E; ++i) {
+                    if (MODE == 0) { float d = xv[u][i] - mu[i]; a0[i] += d; a1[i] += (double)d * d; }
+                    else { float g = (relu && !(yv[u][i] > 0.f)) ? 0.f : gv[u][i]; a0[i] += g; a1[i] += (double)g * ((xv[u][i] - mu[i]) * is[i]); }
+                }
         }
-        for (long r = r0 + tr; r < r1; r += RL) {
-            float4 xv = ld4<T>(x, r * C4 + c4);
-            if (MODE == 0) {
-                xv.x -= mu.x; xv.y -= mu.y; xv.z -= mu.z; xv.w -= mu.w;
-                a0.x += xv.x; a0.y += xv.y; a0.z += xv.z; a0.w += xv.w;
-                a1.x += (double)xv.x * xv.x; a1.y += (double)xv.y * xv.y; a1.z += (double)xv.z * xv.z; a1.w += (double)xv.w * xv.w;
-            } else {
-                float4 g = ld4<T>(dy, r * C4 + c4);
-                if (relu) { float4 yv = ld4<T>(y, r * C4 + c4);
-                    g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f; }
-                a0.x += g.x; a0.y += g.y; a0.z += g.z; a0.w += g.w;
-                a1.x += (double)g.x * ((xv.x - mu.x) * is.x); a1.y += (double)g.y * ((xv.y - mu.y) * is.y);
-                a1.z += (double)g.z * ((xv.z - mu.z) * is.z); a1.w += (double)g.w * ((xv.w - mu.w) * is.w);
+        for (; r < r1; r += RL) {
+            float xv[E], gv[E], yv[E];
+            ldv<T, E>(x, r * CVT + cv, xv);
+            if (MODE == 1) { ldv<T, E>(dy, r * CVT + cv, gv); if (relu) ldv<T, E>(y, r * CVT + cv, yv); }
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                if (MODE == 0) { float d = xv[i] - mu[i]; a0[i] += d; a1[i] += (double)d * d; }
+                else { float g = (relu && !(yv[i] > 0.f)) ? 0.f : gv[i]; a0[i] += g; a1[i] += (double)g * ((xv[i] - mu[i]) * is[i]); }
             }
         }
     }
-    s0[tid] = a0; s1[tid] = a1;
-    __syncthreads();
-    if (tr == 0 && c4 < C4) {
-        for (int k = 1; k < RL; ++k) {     // fixed order
-            d4 b0 = s0[k * TW + tc], b1 = s1[k * TW + tc];
-            a0.x += b0.x; a0.y += b0.y; a0.z += b0.z; a0.w += b0.w;
-            a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
+    // combine the RL row lanes in a fixed order, 4 channels at a time
+#pragma unroll
+    for (int h = 0; h < E; h += 4) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sh[0][tid][i] = a0[h + i]; sh[1][tid][i] = a1[h + i]; }
+        __syncthreads();
+        if (tr == 0 && cv < CVT) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                double s0 = 0.0, s1 = 0.0;
+                for (int k = 0; k < RL; ++k) { s0 += sh[0][k * CV + tc][i]; s1 += sh[1][k * CV + tc][i]; }
+                part0[(long)blockIdx.y * C + cv * E + h + i] = s0;
+                part1[(long)blockIdx.y * C + cv * E + h + i] = s1;
+            }
         }
-        reinterpret_cast<d4*>(part0)[(long)blockIdx.y * C4 + c4] = a0;
-        reinterpret_cast<d4*>(part1)[(long)blockIdx.y * C4 + c4] = a1;
     }
 }
 
-// forward finalise: batch mean / biased variance -> invstd, running stats (momentum, unbiased var) as nn.BatchNorm2d
-__global__ void bn_fwd_finalize_kernel(const double* __restrict__ part0, const double* __restrict__ part1, const float* __restrict__ part2,
-                                       int nparts, long rows_per, int C, long rows,
-                                       float eps, float momentum, float* __restrict__ mean, float* __restrict__ invstd,
-                                       float* __restrict__ running_mean, float* __restrict__ running_var) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
+// Finalise: one 64-lane wave per channel sums the partials (lane-strided, then a fixed xor tree).
+// forward : mean / biased variance -> invstd, running stats (momentum, unbiased variance) as nn.BatchNorm2d
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <typename T>
+__global__ void bn_fwd_finalize_kernel(const double* __restrict__ part0, const double* __restrict__ part1, const T* __restrict__ x,
+                                       int nparts, int C, long rows, float eps, float momentum, float* __restrict__ mean,
+                                       float* __restrict__ invstd, float* __restrict__ running_mean, float* __restrict__ running_var) {
+    const int lane = threadIdx.x & 63, c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (c >= C) return;
-    // merge per-chunk (count, mean, M2) in a fixed order (Chan et al. pairwise update), in double
-    double cnt = 0.0, mu = 0.0, m2 = 0.0;
-    for (int p = 0; p < nparts; ++p) {
-        long r0 = (long)p * rows_per, r1 = r0 + rows_per; if (r1 > rows) r1 = rows;
-        double nk = (double)(r1 - r0), sd = part0[(long)p * C + c], sq = part1[(long)p * C + c];
-        double mk = (double)part2[(long)p * C + c] + sd / nk, m2k = sq - sd * sd / nk;
-        if (m2k < 0.0) m2k = 0.0;
-        double delta = mk - mu, tot = cnt + nk;
-        mu += delta * nk / tot; m2 += m2k + delta * delta * cnt * nk / tot; cnt = tot;
+    double s = 0.0, q = 0.0;
+    for (int p = lane; p < nparts; p += 64) { s += part0[(long)p * C + c]; q += part1[(long)p * C + c]; }
+    s = wave_sum_d(s); q = wave_sum_d(q);
+    if (lane == 0) {
+        const double n = (double)rows, shift = (double)(float)x[c];
+        double var = (q - s * s / n) / n; if (var < 0.0) var = 0.0;
+        const double mu = shift + s / n;
+        mean[c] = (float)mu;
+        invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (running_mean) {
+            double unb = rows > 1 ? var * n / (n - 1.0) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+        }
     }
-    double var = m2 / (double)rows;
-    mean[c] = (float)mu;
-    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (running_mean) {
-        double unb = rows > 1 ? var * (double)rows / (double)(rows - 1) : var;
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
-    }
+}
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part0, const double* __restrict__ part1, int nparts, int C,
+                                       float* __restrict__ dbeta, float* __restrict__ dgamma) {
+    const int lane = threadIdx.x & 63, c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int p = lane; p < nparts; p += 64) { s += part0[(long)p * C + c]; q += part1[(long)p * C + c]; }
+    s = wave_sum_d(s); q = wave_sum_d(q);
+    if (lane == 0) { dbeta[c] = (float)s; dgamma[c] = (float)q; }
 }
 
 // y = (x - mean) * invstd * gamma + beta (+ residual) (ReLU).  eval mode (var_eps >= 0) passes the running
@@ -176,15 +219,6 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict
     if (res) { float4 r = ld4<T>(res, e); o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
     if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
     st4<T>(y, e, o);
-}
-
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part0, const double* __restrict__ part1, int nparts, int C,
-                                       float* __restrict__ dbeta, float* __restrict__ dgamma) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int p = 0; p < nparts; ++p) { s += part0[(long)p * C + c]; q += part1[(long)p * C + c]; }
-    dbeta[c] = (float)s; dgamma[c] = (float)q;
 }
 
 // dx = gamma * invstd * (g - dbeta/M - xhat * dgamma/M);  dres (optional) receives g (the masked upstream gradient)
@@ -412,19 +446,25 @@ int sat_pad_channels_3to4(const float* src, float* dst, int64_t pixels, int32_t 
 
 }  // extern "C" (typed implementations follow)
 
-static void bn_grid(long rows, int C, int& TW, long& rows_per, int& nparts) {
-    int C4 = C / 4;
-    TW = C4 < 64 ? C4 : 64;
-    while (256 % TW) --TW;                      // TW must divide 256
-    rows_per = 512;
-    if (rows / rows_per > 256) rows_per = (rows + 255) / 256;   // <= 256 partials: the finalise loop stays short
+static void bn_grid(long rows, int C, int E, int& CV, long& rows_per, int& nparts) {
+    int CVT = C / E;
+    CV = CVT < 256 ? CVT : 256;
+    while (256 % CV) --CV;                      // CV must divide 256
+    int RL = 256 / CV;
+    int colblocks = cdiv(CVT, CV);
+    long want = 2048 / colblocks; if (want < 1) want = 1;         // ~8 blocks per CU
+    rows_per = cdiv(rows, want);
+    long minrows = (long)RL * 8; if (rows_per < minrows) rows_per = minrows;
     nparts = cdiv(rows, rows_per);
 }
 
 extern "C" size_t sat_bn_scratch_bytes(int64_t rows, int32_t C) {
     if (rows <= 0 || C <= 0 || C % 4) return 0;
-    int TW, nparts; long rp; bn_grid(rows, C, TW, rp, nparts);
-    return (size_t)nparts * C * (2 * sizeof(double) + sizeof(float)) + 64;
+    int CV, nparts; long rp; bn_grid(rows, C, 4, CV, rp, nparts);
+    int CV8 = 0, np8 = 0; long rp8 = 0;
+    if (C % 8 == 0) bn_grid(rows, C, 8, CV8, rp8, np8);
+    int np = nparts > np8 ? nparts : np8;
+    return (size_t)np * C * 2 * sizeof(double) + 64;
 }
 
 template <typename T>
@@ -433,12 +473,14 @@ static int bn_train_fwd_t(const T* x, int64_t rows, int32_t C, const float* gamm
                           T* y, float* scratch, hipStream_t st) {
     if (!x || !gamma || !beta || !save_mean || !save_invstd || !y || !scratch) return fail(SAT_EINVAL, "bn_train_fwd: null pointer");
     SAT_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, "bn_train_fwd: rows=%ld C=%d (C must be a multiple of 4)", (long)rows, C);
-    int TW, nparts; long rp; bn_grid(rows, C, TW, rp, nparts);
-    double* p0 = reinterpret_cast<double*>(scratch); double* p1 = p0 + (long)nparts * C; float* p2 = reinterpret_cast<float*>(p1 + (long)nparts * C);
-    hipLaunchKernelGGL((bn_colstats_kernel<0, T>), dim3(cdiv(C / 4, TW), nparts), dim3(256), 0, st, x, (const T*)nullptr, (const T*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, 0, (long)rows, C, TW, rp, p0, p1, p2);
+    constexpr int E = EPT<T>::n;
+    SAT_REQUIRE(C % E == 0, "bn_train_fwd: C=%d must be a multiple of %d for this storage type", C, E);
+    int CV, nparts; long rp; bn_grid(rows, C, E, CV, rp, nparts);
+    double* p0 = reinterpret_cast<double*>(scratch); double* p1 = p0 + (long)nparts * C;
+    hipLaunchKernelGGL((bn_colstats_kernel<0, T>), dim3(cdiv(C / E, CV), nparts), dim3(256), 0, st, x, (const T*)nullptr, (const T*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, 0, (long)rows, C, CV, rp, p0, p1);
     SAT_TRY(launch_ok("bn_colstats<0>"));
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, p0, p1, p2, nparts, rp, C, (long)rows, eps, momentum, save_mean, save_invstd, running_mean, running_var);
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel<T>, dim3(cdiv(C, 4)), dim3(256), 0, st, p0, p1, x, nparts, C, (long)rows, eps, momentum, save_mean, save_invstd, running_mean, running_var);
     SAT_TRY(launch_ok("bn_fwd_finalize"));
     long total4 = rows * (C / 4);
     hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(cdiv(total4, 256)), dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta, residual, relu, y, total4, C / 4, -1.0f);
@@ -462,11 +504,13 @@ static int bn_train_bwd_t(const T* dy, const T* x, const T* y, int64_t rows, int
     if (!dy || !x || !save_mean || !save_invstd || !gamma || !dx || !dgamma || !dbeta || !scratch) return fail(SAT_EINVAL, "bn_train_bwd: null pointer");
     if (relu && !y) return fail(SAT_EINVAL, "bn_train_bwd: relu mask needs the forward output");
     SAT_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, "bn_train_bwd: bad shape");
-    int TW, nparts; long rp; bn_grid(rows, C, TW, rp, nparts);
+    constexpr int E = EPT<T>::n;
+    SAT_REQUIRE(C % E == 0, "bn_train_bwd: C=%d must be a multiple of %d for this storage type", C, E);
+    int CV, nparts; long rp; bn_grid(rows, C, E, CV, rp, nparts);
     double* p0 = reinterpret_cast<double*>(scratch); double* p1 = p0 + (long)nparts * C;
-    hipLaunchKernelGGL((bn_colstats_kernel<1, T>), dim3(cdiv(C / 4, TW), nparts), dim3(256), 0, st, x, dy, y, save_mean, save_invstd, relu, (long)rows, C, TW, rp, p0, p1, (float*)nullptr);
+    hipLaunchKernelGGL((bn_colstats_kernel<1, T>), dim3(cdiv(C / E, CV), nparts), dim3(256), 0, st, x, dy, y, save_mean, save_invstd, relu, (long)rows, C, CV, rp, p0, p1);
     SAT_TRY(launch_ok("bn_colstats<1>"));
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, p0, p1, nparts, C, dbeta, dgamma);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, p0, p1, nparts, C, dbeta, dgamma);
     SAT_TRY(launch_ok("bn_bwd_finalize"));
     long total4 = rows * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(cdiv(total4, 256)), dim3(256), 0, st, x, dy, y, save_mean, save_invstd, gamma, dbeta, dgamma, relu,

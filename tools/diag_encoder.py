@@ -5,7 +5,8 @@ import torch
 import sat_amd  # noqa
 from sat_amd import encoder as E
 from oracle import prng, sat_oracle as O
-arch, px = sys.argv[1] if len(sys.argv) > 1 else "resnet50", 128
+arch = sys.argv[1] if len(sys.argv) > 1 else "resnet50"
+px = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 hp = O.default_hparams(encoder_arch=arch, encoder_dim=32, input_size=px)
 torch.manual_seed(3); ref = O.build_encoder(hp)
 enc = E.get_encoder(O.default_hparams(encoder_arch=arch, encoder_dim=32, input_size=px)); enc.load_state_dict(ref.state_dict()); enc = enc.cuda().train()
