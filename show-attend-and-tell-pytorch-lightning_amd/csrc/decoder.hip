@@ -99,7 +99,7 @@ static int live_steps(const sat_decoder_dims& d, const sat_decoder_batch& b) {
 }
 
 static size_t att_fwd_lds(int L, int A, int vw) { return (size_t)(ATT_RMAX * L + ATT_RMAX * A + A + ATT_RMAX * ATT_THREADS * vw) * 4; }
-static size_t att_bwd_lds(int L, int A, int D) { return (size_t)(2 * ATT_RMAX * L + ATT_RMAX * A + A + ATT_RMAX * D + 4 * ATT_RMAX * A + 4 * A) * 4; }
+static size_t att_bwd_lds(int L, int A, int D) { return (size_t)(2 * ATT_RMAX * L + ATT_RMAX * A + A + ATT_RMAX * D + ATTB_WAVES * ATT_RMAX * A + ATTB_WAVES * A) * 4; }
 
 int launch_attention_fwd(hipStream_t st, const float* ann, const float* U, const float* hc, int hc_ld, const float* wf,
                                 const int* lengths, int step, float* alphas, int T1, float* Z, float* XZ, int B, int R, int L, int D, int A) {
@@ -265,13 +265,13 @@ int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
                            w.C_all + (long)(t + 1) * N * n, w.dHout + (long)t * N * n, w.dHc, w.dCc, dhc + A + D, HCW, b.lengths, t, N, n);
         SAT_TRY(launch_ok("lstm_cell_bwd"));
         // d(beta*z) = dG * W_ih[:, m:]
-        SAT_TRY(gemm(st, A_ROW, B_KMAJOR, dhc + A + D, HCW, p.w_ih + m, m + D, w.dXZ, D, N, D, 4 * n));
-        hipLaunchKernelGGL(attention_bwd_kernel, dim3(d.B), dim3(ATT_THREADS), lds_b, st, b.ann, w.U, hc, HCW, p.att_f, b.lengths, t, alphas,
+        SAT_TRY(gemm(st, A_ROW, B_KMAJOR, dhc + A + D, HCW, p.w_ih + m, m + D, w.dXZ, D, N, D, 4 * n, 0, EPI_NONE, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, slab, se));
+        hipLaunchKernelGGL(attention_bwd_kernel, dim3(d.B), dim3(ATTB_THREADS), lds_b, st, b.ann, w.U, hc, HCW, p.att_f, b.lengths, t, alphas,
                            dalphas, T1, w.Z + (long)t * N * D, w.dZout + (long)t * N * D, w.dXZ, w.DZ + (long)t * N * D, dhc, HCW, w.dU, w.dwf_part,
                            d.R, d.L, D, A);
         SAT_TRY(launch_ok("attention_bwd"));
         // dh_{t-1} += [dq | dbeta_pre | dG] * Wcat
-        SAT_TRY(gemm(st, A_ROW, B_KMAJOR, dhc, HCW, w.Wcat, n, w.dHc, n, N, n, HCW, 1));
+        SAT_TRY(gemm(st, A_ROW, B_KMAJOR, dhc, HCW, w.Wcat, n, w.dHc, n, N, n, HCW, 1, EPI_NONE, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, slab, se));
     }
     // now dHc = dL/dh0 and dCc = dL/dc0
 

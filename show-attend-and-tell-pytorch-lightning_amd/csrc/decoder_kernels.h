@@ -281,7 +281,9 @@ __global__ void lstm_cell_bwd_kernel(const float* __restrict__ gates, int g_ld, 
 //   dalpha_l = dz . ann[b,l,:] + dalpha_ext ; ds = alpha (dalpha - sum alpha dalpha)
 //   dpre_lk = ds_l L^-1/2 w_k (1 - tanh^2(U_lk + q_k)) ; dq_k = sum_l dpre ; dU += sum_r dpre ; dw_k += sum ds L^-1/2 tanh
 // dyn LDS: [RMAX*L alpha][RMAX*L dalpha/ds][RMAX*A q][A w][RMAX*D dz][4*RMAX*A dq partial][4*A dw partial]
-__global__ __launch_bounds__(ATT_THREADS) void attention_bwd_kernel(
+constexpr int ATTB_WAVES = 16;                 // 1024 threads: one block per image, so hide latency with waves
+constexpr int ATTB_THREADS = ATTB_WAVES * 64;
+__global__ __launch_bounds__(ATTB_THREADS) void attention_bwd_kernel(
     const float* __restrict__ ann, const float* __restrict__ U, const float* __restrict__ hc, int hc_ld,
     const float* __restrict__ wf, const int* __restrict__ lengths, int step,
     const float* __restrict__ alphas, const float* __restrict__ dalphas_ext, int T1,
@@ -294,12 +296,12 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bwd_kernel(
     float* s_q = s_da + ATT_RMAX * L;         // [RMAX][A]
     float* s_w = s_q + ATT_RMAX * A;          // [A]
     float* s_dz = s_w + A;                    // [RMAX][D]
-    float* s_dq = s_dz + ATT_RMAX * D;        // [4][RMAX][A]
-    float* s_dw = s_dq + 4 * ATT_RMAX * A;    // [4][A]
+    float* s_dq = s_dz + ATT_RMAX * D;        // [waves][RMAX][A]
+    float* s_dw = s_dq + ATTB_WAVES * ATT_RMAX * A;    // [waves][A]
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float scale = 1.0f / sqrtf((float)L);
-    for (int k = tid; k < A; k += ATT_THREADS) s_w[k] = wf[k];
-    for (int e = tid; e < 4 * A; e += ATT_THREADS) s_dw[e] = 0.f;
+    for (int k = tid; k < A; k += ATTB_THREADS) s_w[k] = wf[k];
+    for (int e = tid; e < ATTB_WAVES * A; e += ATTB_THREADS) s_dw[e] = 0.f;
 
     for (int r0 = 0; r0 < R; r0 += ATT_RMAX) {
         const int rn = min(ATT_RMAX, R - r0);
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bwd_kernel(
         const bool any = lmask != 0;
         __syncthreads();
         // gate backward + dz for every row of the chunk (dead rows: zeros)
-        for (int e = tid; e < rn * D; e += ATT_THREADS) {
+        for (int e = tid; e < rn * D; e += ATTB_THREADS) {
             int r = e / D, d = e - r * D; long row = i0 + r;
             float dz = 0.f, dbp = 0.f;
             if (((lmask >> r) & 1u)) {
@@ -322,14 +324,14 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bwd_kernel(
             dhc[row * dhc_ld + A + d] = dbp;
         }
         if (!any) {
-            for (int e = tid; e < rn * A; e += ATT_THREADS) { int r = e / A, k = e - r * A; dhc[(long)(i0 + r) * dhc_ld + k] = 0.f; }
+            for (int e = tid; e < rn * A; e += ATTB_THREADS) { int r = e / A, k = e - r * A; dhc[(long)(i0 + r) * dhc_ld + k] = 0.f; }
             continue;
         }
-        for (int e = tid; e < rn * A; e += ATT_THREADS) { int r = e / A, k = e - r * A; s_q[r * A + k] = hc[(long)(i0 + r) * hc_ld + k]; }
-        for (int e = tid; e < rn * L; e += ATT_THREADS) { int r = e / L, l = e - r * L; s_al[r * L + l] = ((lmask >> r) & 1u) ? alphas[((long)(i0 + r) * T1 + step) * L + l] : 0.f; }
+        for (int e = tid; e < rn * A; e += ATTB_THREADS) { int r = e / A, k = e - r * A; s_q[r * A + k] = hc[(long)(i0 + r) * hc_ld + k]; }
+        for (int e = tid; e < rn * L; e += ATTB_THREADS) { int r = e / L, l = e - r * L; s_al[r * L + l] = ((lmask >> r) & 1u) ? alphas[((long)(i0 + r) * T1 + step) * L + l] : 0.f; }
         __syncthreads();
         // ---- dalpha[r][l] = dz[r] . ann[b,l,:]  (wave per location)
-        for (int l = wave; l < L; l += 4) {
+        for (int l = wave; l < L; l += ATTB_WAVES) {
             float part[ATT_RMAX];
 #pragma unroll
             for (int r = 0; r < ATT_RMAX; ++r) part[r] = 0.f;
@@ -347,7 +349,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bwd_kernel(
         }
         __syncthreads();
         // ---- softmax backward, wave per row: ds = alpha * (dalpha - sum alpha*dalpha)
-        for (int r = wave; r < rn; r += 4) {
+        for (int r = wave; r < rn; r += ATTB_WAVES) {
             if (!((lmask >> r) & 1u)) continue;
             float dot = 0.f;
             for (int l = lane; l < L; l += 64) dot += s_al[r * L + l] * s_da[r * L + l];
@@ -363,7 +365,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bwd_kernel(
             for (int r = 0; r < ATT_RMAX; ++r) dq[r] = 0.f;
             if (k < A) {
                 const float w = s_w[k];
-                for (int l = wave; l < L; l += 4) {
+                for (int l = wave; l < L; l += ATTB_WAVES) {
                     const long uo = ((long)b * L + l) * A + k;
                     const float uv = U[uo];
                     float du = 0.f;
@@ -382,15 +384,15 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bwd_kernel(
             }
         }
         __syncthreads();
-        for (int e = tid; e < rn * A; e += ATT_THREADS) {
+        for (int e = tid; e < rn * A; e += ATTB_THREADS) {
             int r = e / A, k = e - r * A;
             float s = 0.f;
-            if (((lmask >> r) & 1u)) for (int w = 0; w < 4; ++w) s += s_dq[(w * ATT_RMAX + r) * A + k];
+            if (((lmask >> r) & 1u)) for (int w = 0; w < ATTB_WAVES; ++w) s += s_dq[(w * ATT_RMAX + r) * A + k];
             dhc[(long)(i0 + r) * dhc_ld + k] = s;
         }
     }
     __syncthreads();
-    for (int k = tid; k < A; k += ATT_THREADS) dwf_part[(long)b * A + k] += s_dw[k] + s_dw[A + k] + s_dw[2 * A + k] + s_dw[3 * A + k];
+    for (int k = tid; k < A; k += ATTB_THREADS) { float sw = 0.f; for (int w = 0; w < ATTB_WAVES; ++w) sw += s_dw[w * A + k]; dwf_part[(long)b * A + k] += sw; }
 }
 
 // dann[b,l,d] (+)= sum over this image's caption rows r and steps t of alpha[i,t,l] * DZ[t][i][d]

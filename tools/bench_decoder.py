@@ -9,10 +9,11 @@ from oracle import prng, sat_oracle as O
 ap = argparse.ArgumentParser()
 ap.add_argument("--B", type=int, default=128); ap.add_argument("--R", type=int, default=5); ap.add_argument("--T", type=int, default=22)
 ap.add_argument("--L", type=int, default=49); ap.add_argument("--D", type=int, default=512); ap.add_argument("--V", type=int, default=6400)
-ap.add_argument("--steps", type=int, default=10); ap.add_argument("--ragged", action="store_true")
+ap.add_argument("--steps", type=int, default=10); ap.add_argument("--ragged", action="store_true"); ap.add_argument("--bf16", action="store_true")
 a = ap.parse_args()
 hp = O.default_hparams(vocab_size=a.V, encoder_dim=a.D, embed_dim=256, attention_dim=128, decoder_dim=512)
 dec = M.SATDecoder(hp).cuda()
+if a.bf16: dec.sat_precision = "bf16"
 ann = torch.from_numpy(prng.uniform((a.B, a.L, a.D), 1, 0.0, 2.0)).cuda().requires_grad_()
 caps, lengths = prng.captions(a.B, a.R, a.T, a.V, 2, ragged=a.ragged, min_len=8)
 caps, lengths = torch.from_numpy(caps).cuda(), torch.from_numpy(lengths)
