@@ -140,6 +140,22 @@ int sat_doubly_stochastic_fwd(const float* alphas, int32_t N, int32_t T1, int32_
 int sat_doubly_stochastic_bwd(const float* asum, const float* gscale, int32_t N, int32_t T1, int32_t L, float gamma,
                               float* dalphas, void* stream);
 
+/* ------------------------------------------------------------------ inference: SAT.forward / caption (model.py:214-472)
+ * The reference decodes one image at a time with the beam as the batch (model.py:260-266).  `begin` computes att_enc
+ * and the initial state of `beams` rows (InitLSTM over the expanded annotations, F3 reshape: model.py:265-269);
+ * `step` is one pass of model.py:298-327 for the live beams (h, c updated in place; d->B/R/T/P are ignored);
+ * `sat_beam_scores` = log_softmax(logit / temperature) with the special tokens masked and the parent scores added
+ * (model.py:330-351); `sat_topk` = torch.topk on the flattened scores (model.py:343, 359). */
+size_t sat_decoder_infer_workspace_bytes(const sat_decoder_dims* d, int32_t max_beams);
+int sat_decoder_infer_begin(const sat_decoder_dims* d, const sat_decoder_params* w, const float* ann /* (L, D) */, int32_t beams,
+                            int32_t max_beams, float* h /* (beams, n) */, float* c, void* workspace, size_t workspace_bytes, void* stream);
+int sat_decoder_infer_step(const sat_decoder_dims* d, const sat_decoder_params* w, const float* ann, const int32_t* tokens, int32_t beams,
+                           int32_t max_beams, float* h, float* c, float* logits /* (beams, V) */, float* alpha /* (beams, L) */,
+                           void* workspace, size_t workspace_bytes, void* stream);
+int sat_beam_scores(const float* logits, int32_t beams, int32_t V, float temperature, const int32_t* masked_ids /* device */,
+                    int32_t n_masked, const float* parent_scores /* (beams) or NULL */, float* scores, void* stream);
+int sat_topk(const float* x, float* work /* n floats scratch */, int64_t n, int32_t k, float* values, int32_t* indices, void* stream);
+
 /* out[c] = sum_r x[r*ld + c] in a fixed order (bias gradients).  scratch: ceil(rows/256)*cols floats */
 int sat_colsum(const float* x, int64_t ld, int64_t rows, int32_t cols, float* out, float* scratch, void* stream);
 

@@ -438,3 +438,91 @@ class OracleSAT:
     def step_loss(self, img, caps, lengths, epsilon=1.0, draw=None):
         ann = self.encoder(img.clone())                    # clone: Normalize is in place (F9)
         return training_loss(self.sd, self.hp, ann, caps, lengths, epsilon, draw)
+
+
+# --------------------------------------------------------------------------
+# a11. Inference: SAT.forward / caption beam search (model.py:237-472), "beam" sampling.
+# --------------------------------------------------------------------------
+
+def beam_search(sd, hp, ann_img, beamk=3, max_gen_length=32, temperature=1.0, rescore_method=None, rescore_reward=0.5,
+                return_all=False, lstm_fn=lstm_step):
+    """Per-image beam search exactly as the reference runs it (one image at a time, the beam is the batch).
+    ann_img (B,D,h,w).  Returns (captions, scores, alphas, perplexities) lists like model.py:472."""
+    stoi = hp.vocab_stoi
+    START, PAD, END, UNK = int(stoi["<START>"]), int(stoi["<PAD>"]), int(stoi["<END>"]), int(stoi["<UNK>"])
+    V, layers, n = hp.vocab_size, hp.decoder_layers, hp.decoder_dim
+    temps = temperature if isinstance(temperature, list) else [temperature]
+    captions, cap_scores, cap_alphas, cap_ppl = [], [], [], []
+    _, _, Hh, Ww = ann_img.shape
+    for idx in range(ann_img.shape[0]):
+        k = beamk
+        annots = ann_img[idx].expand(k, *ann_img[idx].shape)
+        h, c = init_state(sd, annots, layers, n)                          # F3: odd beams start with h/c swapped
+        top_preds = torch.full((1, k), START, dtype=torch.long)
+        top_scores = torch.zeros(k)
+        alphas = torch.zeros(1, k, Hh, Ww)
+        fin_caps, fin_alphas, fin_scores, fin_ppl = [], [], [], []
+
+        def rescore(s, step):
+            if rescore_method == "LN":
+                return s / step
+            if rescore_method == "WR":
+                return s + rescore_reward * step
+            if rescore_method == "BAR":
+                return s + rescore_reward * (-torch.mean(top_scores))
+            return s
+
+        step = 0
+        while True:
+            T = temps[step % len(temps)]
+            y = embed(sd, top_preds[step])
+            z, alpha = soft_attention(sd, annots, h[-1])
+            x = torch.cat([y, beta_gate(sd, h[-1]) * z], dim=1).unsqueeze(0)
+            h, c = lstm_fn(sd, x, h, c, layers)
+            scores = F.log_softmax(deep_output(sd, y, h[-1], z, hp.deep_output) / T, dim=1)
+            scores[:, [START, PAD]] = float("-inf")                      # model.py:333
+            if step == 0:
+                scores[:, [END, UNK]] = float("-inf")                    # model.py:340
+                top_scores, pred_idx = torch.topk(scores[0], k)
+                top_preds = torch.cat([top_preds, pred_idx.unsqueeze(0)], 0)
+                alphas = torch.cat([alphas, alpha.unsqueeze(0)], 0)
+            else:
+                seq = scores + top_scores.unsqueeze(1)
+                _, pred_idx = torch.topk(seq.reshape(-1), k, dim=0)      # model.py:359
+                top_scores = seq.reshape(-1)[pred_idx]
+                keep = torch.div(pred_idx, V, rounding_mode="floor")
+                word = torch.remainder(pred_idx, V).unsqueeze(0)
+                top_preds = torch.cat([top_preds[:, keep], word], 0)
+                alphas = torch.cat([alphas[:, keep], alpha.unsqueeze(0)[:, keep]], 0)
+                h, c = h[:, keep], c[:, keep]
+                annots = annots[keep]
+            complete = top_preds[step + 1] == END
+            if bool(complete.any()):
+                for i in torch.nonzero(complete).flatten().tolist():
+                    fin_caps.append(top_preds[:, i][1:-1].tolist())
+                    fin_alphas.append(alphas[:, i][1:-1].clone())
+                    fin_scores.append(float(rescore(top_scores[i], step)))
+                    fin_ppl.append(float(torch.exp(-top_scores[i] / step)))
+                inc = ~complete
+                top_preds, alphas, top_scores = top_preds[:, inc], alphas[:, inc], top_scores[inc]
+                h, c, annots = h[:, inc], c[:, inc], annots[inc]
+                k = int(inc.sum())
+                if k == 0:
+                    break
+            if step >= max_gen_length:
+                for i in range(top_preds.shape[1]):
+                    fin_caps.append(top_preds[:, i][1:-1].tolist())
+                    fin_alphas.append(alphas[:, i][1:-1].clone())
+                    fin_scores.append(float(rescore(top_scores[i], step)))
+                    fin_ppl.append(float(torch.exp(-top_scores[i] / step)))
+                break
+            step += 1
+        if return_all:
+            order = [i for _, i in sorted([[fin_scores[i], i] for i in range(len(fin_scores))], reverse=True)]
+            captions.append([fin_caps[i] for i in order]); cap_alphas.append([fin_alphas[i] for i in order])
+            cap_scores.append([fin_scores[i] for i in order]); cap_ppl.append([fin_ppl[i] for i in order])
+        else:
+            best = fin_scores.index(max(fin_scores))
+            captions.append(fin_caps[best]); cap_alphas.append(fin_alphas[best])
+            cap_scores.append(fin_scores[best]); cap_ppl.append(fin_ppl[best])
+    return captions, cap_scores, cap_alphas, cap_ppl

@@ -116,6 +116,14 @@ class ProfileEntry(C.Structure):
     _fields_ = [("name", C.c_char * 96), ("launches", C.c_int64), ("total_ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
 
 
+SYMBOLS.update({
+    "sat_decoder_infer_workspace_bytes": (C.c_size_t, [C.POINTER(DecoderDims), _i32]),
+    "sat_decoder_infer_begin": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), _vp, _i32, _i32, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "sat_decoder_infer_step": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp,
+                                         C.c_size_t, _vp]),
+    "sat_beam_scores": (C.c_int, [_vp, _i32, _i32, _f, _vp, _i32, _vp, _vp, _vp]),
+    "sat_topk": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
+})
 SYMBOLS.update({"sat_profile_start": (C.c_int, []),
                 "sat_profile_stop": (C.c_int, [C.POINTER(ProfileEntry), _i32, C.POINTER(C.c_int32)])})
 

@@ -92,6 +92,32 @@ int sat_doubly_stochastic_bwd(const float* asum, const float* gscale, int32_t N,
     return ds_bwd(asum, gscale, N, T1, L, gamma, dalphas, (hipStream_t)stream);
 }
 
+size_t sat_decoder_infer_workspace_bytes(const sat_decoder_dims* d, int32_t max_beams) {
+    if (check_dims(d) != SAT_OK || max_beams < 1) return 0;
+    return decoder_infer_workspace_bytes(*d, max_beams);
+}
+int sat_decoder_infer_begin(const sat_decoder_dims* d, const sat_decoder_params* w, const float* ann, int32_t beams, int32_t max_beams,
+                            float* h, float* c, void* workspace, size_t workspace_bytes, void* stream) {
+    SAT_TRY(check_dims(d)); SAT_TRY(check_params(d, w, "decoder_infer_begin"));
+    if (!ann || !h || !c || !workspace) return fail(SAT_EINVAL, "decoder_infer_begin: null pointer");
+    return decoder_infer_begin(*d, *w, ann, beams, max_beams, h, c, (char*)workspace, workspace_bytes, (hipStream_t)stream);
+}
+int sat_decoder_infer_step(const sat_decoder_dims* d, const sat_decoder_params* w, const float* ann, const int32_t* tokens, int32_t beams,
+                           int32_t max_beams, float* h, float* c, float* logits, float* alpha, void* workspace, size_t workspace_bytes, void* stream) {
+    SAT_TRY(check_dims(d)); SAT_TRY(check_params(d, w, "decoder_infer_step"));
+    if (!ann || !tokens || !h || !c || !logits || !alpha || !workspace) return fail(SAT_EINVAL, "decoder_infer_step: null pointer");
+    return decoder_infer_step(*d, *w, ann, tokens, beams, max_beams, h, c, logits, alpha, (char*)workspace, workspace_bytes, (hipStream_t)stream);
+}
+int sat_beam_scores(const float* logits, int32_t beams, int32_t V, float temperature, const int32_t* masked_ids, int32_t n_masked,
+                    const float* parent_scores, float* scores, void* stream) {
+    if (!logits || !scores || (n_masked > 0 && !masked_ids)) return fail(SAT_EINVAL, "beam_scores: null pointer");
+    return beam_scores(logits, beams, V, temperature, masked_ids, n_masked, parent_scores, scores, (hipStream_t)stream);
+}
+int sat_topk(const float* x, float* work, int64_t n, int32_t k, float* values, int32_t* indices, void* stream) {
+    if (!x || !work || !values || !indices) return fail(SAT_EINVAL, "topk: null pointer");
+    return topk(x, work, n, k, values, indices, (hipStream_t)stream);
+}
+
 int sat_colsum(const float* x, int64_t ld, int64_t rows, int32_t cols, float* out, float* scratch, void* stream) {
     if (!x || !out || !scratch) return fail(SAT_EINVAL, "colsum: null pointer");
     if (rows <= 0 || cols <= 0 || ld < cols) return fail(SAT_EINVAL, "colsum: bad shape");

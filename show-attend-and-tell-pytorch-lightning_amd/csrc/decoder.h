@@ -13,6 +13,13 @@ int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
                 const float* alphas, const float* dalphas, const sat_decoder_params& g, float* dann, char* ws, size_t ws_bytes, hipStream_t st);
 int launch_attention_fwd(hipStream_t st, const float* ann, const float* U, const float* hc, int hc_ld, const float* wf,
                          const int* lengths, int step, float* alphas, int T1, float* Z, float* XZ, int B, int R, int L, int D, int A);
+size_t decoder_infer_workspace_bytes(const sat_decoder_dims& d, int Kmax);
+int decoder_infer_begin(const sat_decoder_dims& d, const sat_decoder_params& p, const float* ann, int K, int Kmax, float* h, float* c,
+                        char* ws, size_t ws_bytes, hipStream_t st);
+int decoder_infer_step(const sat_decoder_dims& d, const sat_decoder_params& p, const float* ann, const int* tokens, int K, int Kmax,
+                       float* h, float* c, float* logits, float* alpha, char* ws, size_t ws_bytes, hipStream_t st);
+int beam_scores(const float* logits, int K, int V, float temperature, const int* masked, int n_masked, const float* parent, float* scores, hipStream_t st);
+int topk(const float* x, float* work, long n, int k, float* values, int* indices, hipStream_t st);
 int colsum_public(const float* x, long ld, long rows, int cols, float* out, float* scratch, hipStream_t st);
 int ce_fwd(const float* logits, const int* targets, int P, int V, float smoothing, float* lse_rows, float* loss_rows, int* correct_rows, float* out, hipStream_t st);
 int ce_bwd(const float* logits, const int* targets, const float* lse_rows, int P, int V, float smoothing, const float* gscale, float* dlogits, hipStream_t st);

@@ -323,6 +323,81 @@ int colsum_public(const float* x, long ld, long rows, int cols, float* out, floa
 
 size_t decoder_workspace_bytes(const sat_decoder_dims& d) { return layout(d, nullptr).total; }
 
+// ------------------------------------------------------------------ inference: one image, K live beams
+struct InferWs { size_t total; float *U, *Wcat, *bcat, *mean, *f, *init_img, *hc, *Z, *XZ, *Y, *u; int* ones; };
+static InferWs infer_layout(const sat_decoder_dims& d, int Kmax, char* base) {
+    InferWs w; size_t off = 0;
+    const long HCW = d.A + d.D + 4L * d.n;
+    auto take = [&](size_t elems) { size_t o = off; off += (elems * 4 + 255) & ~(size_t)255; return base ? base + o : (char*)nullptr; };
+    w.U = (float*)take((size_t)d.L * d.A); w.Wcat = (float*)take((size_t)HCW * d.n); w.bcat = (float*)take((size_t)HCW);
+    w.mean = (float*)take(d.D); w.f = (float*)take(d.m); w.init_img = (float*)take(2 * (size_t)d.n);
+    w.hc = (float*)take((size_t)Kmax * HCW); w.Z = (float*)take((size_t)Kmax * d.D); w.XZ = (float*)take((size_t)Kmax * d.D);
+    w.Y = (float*)take((size_t)Kmax * d.m); w.u = (float*)take((size_t)Kmax * d.m); w.ones = (int*)take(Kmax);
+    w.total = off;
+    return w;
+}
+size_t decoder_infer_workspace_bytes(const sat_decoder_dims& d, int Kmax) { return infer_layout(d, Kmax, nullptr).total; }
+
+// model.py:255-281 for one image: att_enc, the stacked step weights, and the initial state of K beams (F3 reshape)
+int decoder_infer_begin(const sat_decoder_dims& d, const sat_decoder_params& p, const float* ann, int K, int Kmax, float* h, float* c,
+                        char* ws, size_t ws_bytes, hipStream_t st) {
+    InferWs w = infer_layout(d, Kmax, ws);
+    SAT_REQUIRE(ws_bytes >= w.total && K >= 1 && K <= Kmax, "decoder_infer_begin: workspace %zu < %zu or bad beam count %d/%d", ws_bytes, w.total, K, Kmax);
+    t_bf16_mfma = d.precision ? 1 : 0;
+    const int n = d.n, A = d.A, D = d.D, m = d.m;
+    SAT_CHECK_HIP(hipMemcpyAsync(w.Wcat, p.att_dec, (size_t)A * n * 4, hipMemcpyDeviceToDevice, st));
+    SAT_CHECK_HIP(hipMemcpyAsync(w.Wcat + (long)A * n, p.beta_w, (size_t)D * n * 4, hipMemcpyDeviceToDevice, st));
+    SAT_CHECK_HIP(hipMemcpyAsync(w.Wcat + (long)(A + D) * n, p.w_hh, (size_t)4 * n * n * 4, hipMemcpyDeviceToDevice, st));
+    SAT_CHECK_HIP(hipMemsetAsync(w.bcat, 0, (size_t)A * 4, st));
+    SAT_CHECK_HIP(hipMemcpyAsync(w.bcat + A, p.beta_b, (size_t)D * 4, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(add_kernel, dim3(cdiv(4 * n, 256)), dim3(256), 0, st, w.bcat + A + D, p.b_ih, p.b_hh, (long)4 * n);
+    SAT_TRY(launch_ok("bias add"));
+    hipLaunchKernelGGL(fill_int_kernel, dim3(cdiv(Kmax, 256)), dim3(256), 0, st, w.ones, (long)Kmax, 1);
+    SAT_TRY(launch_ok("fill ones"));
+    SAT_TRY(gemm(st, A_ROW, B_ROW, ann, D, p.att_enc, D, w.U, A, d.L, A, D));
+    hipLaunchKernelGGL(ann_mean_kernel, dim3(1), dim3(256), 0, st, ann, w.mean, d.L, D);
+    SAT_TRY(launch_ok("ann_mean"));
+    SAT_TRY(gemm(st, A_ROW, B_ROW, w.mean, D, p.init_f_w, D, w.f, m, 1, m, D, 0, EPI_BIAS, p.init_f_b));
+    SAT_TRY(gemm(st, A_ROW, B_ROW, w.f, m, p.init_i_w, m, w.init_img, 2 * n, 1, 2 * n, m, 0, EPI_BIAS, p.init_i_b));
+    hipLaunchKernelGGL(init_expand_kernel, dim3(cdiv(2L * K * n, 256)), dim3(256), 0, st, w.init_img, h, c, K, K, n);   // one image, R = K rows
+    return launch_ok("init_expand");
+}
+
+// model.py:298-327: embedding -> attention -> beta gate -> LSTM -> deep output for the K live beams of one image
+int decoder_infer_step(const sat_decoder_dims& d, const sat_decoder_params& p, const float* ann, const int* tokens, int K, int Kmax,
+                       float* h, float* c, float* logits, float* alpha, char* ws, size_t ws_bytes, hipStream_t st) {
+    InferWs w = infer_layout(d, Kmax, ws);
+    SAT_REQUIRE(ws_bytes >= w.total && K >= 1 && K <= Kmax, "decoder_infer_step: workspace or beam count");
+    t_bf16_mfma = d.precision ? 1 : 0;
+    const int n = d.n, A = d.A, D = d.D, m = d.m, HCW = A + D + 4 * n;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(K), dim3(64), 0, st, p.embedding, tokens, w.Y, K, m);
+    SAT_TRY(launch_ok("embedding gather"));
+    SAT_TRY(gemm(st, A_ROW, B_ROW, h, n, w.Wcat, n, w.hc, HCW, K, HCW, n, 0, EPI_BIAS_SIGMOID_RANGE, w.bcat, nullptr, nullptr, nullptr, 0, A, A + D));
+    SAT_TRY(launch_attention_fwd(st, ann, w.U, w.hc, HCW, p.att_f, w.ones, 0, alpha, 1, w.Z, w.XZ, 1, K, d.L, D, A));
+    SAT_TRY(gemm(st, A_ROW, B_ROW, w.Y, m, p.w_ih, m + D, w.hc + A + D, HCW, K, 4 * n, m, 1));
+    SAT_TRY(gemm(st, A_ROW, B_ROW, w.XZ, D, p.w_ih + m, m + D, w.hc + A + D, HCW, K, 4 * n, D, 1));
+    hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(cdiv((long)K * n, 256)), dim3(256), 0, st, w.hc + A + D, HCW, (const float*)nullptr, c, h, c, h, w.ones, 0, K, n);
+    SAT_TRY(launch_ok("lstm_cell_fwd"));
+    if (d.deep_output) {
+        SAT_TRY(gemm(st, A_ROW, B_ROW, h, n, p.out_hidden, n, w.u, m, K, m, n));
+        SAT_TRY(gemm(st, A_ROW, B_ROW, w.Z, D, p.out_context, D, w.u, m, K, m, D, 1, EPI_ADD_TANH, nullptr, nullptr, nullptr, w.Y, m));
+    } else {
+        SAT_TRY(gemm(st, A_ROW, B_ROW, h, n, p.out_hidden, n, w.u, m, K, m, n));
+    }
+    return gemm(st, A_ROW, B_ROW, w.u, m, p.out_w, m, logits, d.V, K, d.V, m, 0, p.out_b ? EPI_BIAS : EPI_NONE, p.out_b);
+}
+
+int beam_scores(const float* logits, int K, int V, float temperature, const int* masked, int n_masked, const float* parent, float* scores, hipStream_t st) {
+    SAT_REQUIRE(K > 0 && V > 0 && temperature > 0.f, "beam_scores: bad arguments");
+    hipLaunchKernelGGL(beam_scores_kernel, dim3(K), dim3(256), 0, st, logits, V, 1.0f / temperature, masked, n_masked, parent, scores);
+    return launch_ok("beam_scores");
+}
+int topk(const float* x, float* work, long n, int k, float* values, int* indices, hipStream_t st) {
+    SAT_REQUIRE(n > 0 && k > 0 && k <= n, "topk: bad arguments (n=%ld k=%d)", n, k);
+    hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(1024), 0, st, x, work, n, k, values, indices);
+    return launch_ok("topk");
+}
+
 // ------------------------------------------------------------------ losses
 int ce_fwd(const float* logits, const int* targets, int P, int V, float smoothing, float* lse_rows, float* loss_rows, int* correct_rows, float* out, hipStream_t st) {
     SAT_REQUIRE(P > 0 && V > 0, "ce_fwd: empty input (P=%d V=%d)", P, V);

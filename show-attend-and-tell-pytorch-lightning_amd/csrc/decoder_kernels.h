@@ -24,6 +24,11 @@ __global__ void fill_kernel(float* p, long n, float v) {
     if (i < n) p[i] = v;
 }
 
+__global__ void fill_int_kernel(int* p, long n, int v) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
 // dst[r, :] = src[idx(r), :]  (embedding gather; tok < 0 -> zeros)
 __global__ void gather_rows_kernel(const float* __restrict__ table, const int* __restrict__ tok, float* __restrict__ out, int rows, int width) {
     int r = blockIdx.x;
@@ -238,11 +243,11 @@ __global__ void lstm_cell_fwd_kernel(float* __restrict__ gates, int g_ld, const 
         return;
     }
     float* g = gates + (long)i * g_ld;
-    const float* y = gy + (long)i * 4 * n;
-    float gi = fast_sigmoid(g[j] + y[j]);
-    float gf = fast_sigmoid(g[n + j] + y[n + j]);
-    float gg = fast_tanh(g[2 * n + j] + y[2 * n + j]);
-    float go = fast_sigmoid(g[3 * n + j] + y[3 * n + j]);
+    const float* y = gy ? gy + (long)i * 4 * n : nullptr;
+    float gi = fast_sigmoid(g[j] + (y ? y[j] : 0.f));
+    float gf = fast_sigmoid(g[n + j] + (y ? y[n + j] : 0.f));
+    float gg = fast_tanh(g[2 * n + j] + (y ? y[2 * n + j] : 0.f));
+    float go = fast_sigmoid(g[3 * n + j] + (y ? y[3 * n + j] : 0.f));
     float c = gf * c_prev[idx] + gi * gg;
     c_new[idx] = c;
     h_new[idx] = go * fast_tanh(c);
@@ -576,6 +581,63 @@ __global__ void scatter_rows_kernel(const float* __restrict__ src, const int* __
     if (r >= rows) return;
     int p = prow[r];
     for (int c = threadIdx.x; c < width; c += blockDim.x) dst[(long)r * width + c] = (p >= 0) ? src[(long)p * width + c] : 0.f;
+}
+
+
+// ------------------------------------------------------------------ inference (beam search, model.py:329-343, 351-359)
+// scores[r, v] = log_softmax(logits[r, :] / T)[v] (+ parent[r]); masked token ids become -inf.  One block per beam row.
+__global__ __launch_bounds__(256) void beam_scores_kernel(const float* __restrict__ logits, int V, float inv_temp,
+                                                          const int* __restrict__ masked, int n_masked,
+                                                          const float* __restrict__ parent, float* __restrict__ scores) {
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const float* x = logits + (long)r * V;
+    __shared__ float s_m[4], s_s[4];
+    float mx = -INFINITY, sum = 0.f;
+    for (int v = tid; v < V; v += 256) {
+        float xv = x[v] * inv_temp;
+        if (xv > mx) { sum = sum * __expf(mx - xv) + 1.f; mx = xv; } else sum += __expf(xv - mx);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        float om = __shfl_xor(mx, o, 64), os = __shfl_xor(sum, o, 64);
+        float nm = fmaxf(mx, om);
+        float fa = (mx == nm) ? 1.f : __expf(mx - nm), fb = (om == nm) ? 1.f : __expf(om - nm);
+        sum = sum * fa + os * fb; mx = nm;
+    }
+    if ((tid & 63) == 0) { s_m[tid >> 6] = mx; s_s[tid >> 6] = sum; }
+    __syncthreads();
+    float M = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3])), S = 0.f;
+    for (int k = 0; k < 4; ++k) S += (s_m[k] == M) ? s_s[k] : s_s[k] * __expf(s_m[k] - M);
+    const float lse = M + __logf(S), add = parent ? parent[r] : 0.f;
+    float* o = scores + (long)r * V;
+    for (int v = tid; v < V; v += 256) o[v] = x[v] * inv_temp - lse + add;
+    __syncthreads();
+    for (int k = tid; k < n_masked; k += 256) { int id = masked[k]; if (id >= 0 && id < V) o[id] = -INFINITY; }
+}
+
+// top-k of a flat array, descending, ties to the lowest index (torch.topk on the flattened beam scores, model.py:359).
+// Single block; `work` is a scratch copy of x that gets the winners knocked out.
+__global__ __launch_bounds__(1024) void topk_kernel(const float* __restrict__ x, float* __restrict__ work, long n, int k,
+                                                    float* __restrict__ values, int* __restrict__ indices) {
+    __shared__ float s_v[16]; __shared__ long s_i[16];
+    const int tid = threadIdx.x;
+    for (long i = tid; i < n; i += 1024) work[i] = x[i];
+    __syncthreads();
+    for (int it = 0; it < k; ++it) {
+        float bv = -INFINITY; long bi = 0x7fffffffffffffffL;
+        for (long i = tid; i < n; i += 1024) { float v = work[i]; if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; } }
+        for (int o = 32; o > 0; o >>= 1) {
+            float ov = __shfl_xor(bv, o, 64); long oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if ((tid & 63) == 0) { s_v[tid >> 6] = bv; s_i[tid >> 6] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 16; ++w) if (s_v[w] > bv || (s_v[w] == bv && s_i[w] < bi)) { bv = s_v[w]; bi = s_i[w]; }
+            values[it] = bv; indices[it] = (int)bi;
+            if (bi < n) work[bi] = -INFINITY;
+        }
+        __syncthreads();
+    }
 }
 
 }  // namespace sat

@@ -130,6 +130,124 @@ class SATDecoder(nn.Module):
             if k in own:
                 own[k].copy_(torch.as_tensor(v))
 
+    # ------------------------------------------------------------------ inference (model.py:214-472)
+    def _params_struct(self):
+        tens = dict(zip(L.PARAM_FIELDS, self.param_list()))
+        return Dk._params_struct(tens), tens
+
+    @torch.no_grad()
+    def beam_decode(self, ann_bld, hw, beamk=3, max_gen_length=32, temperature=1.0, sample_method="beam", sample_topk=3,
+                    decoder_noise=None, rescore_method=None, rescore_reward=0.5, return_all=False):
+        """SAT.forward's per-image beam search (model.py:260-472) on annotations (B, L, D).  The decode step,
+        log-softmax / masking and top-k run in the library; the beam bookkeeping (which hypotheses to keep, finished
+        lists, rescoring) stays on the host like in the reference."""
+        import ctypes as C
+        if sample_method != "beam":
+            raise NotImplementedError("sample_method=%r: only 'beam' is built on the HIP path this round" % (sample_method,))
+        if decoder_noise:
+            raise NotImplementedError("decoder_noise is not built on the HIP path")
+        lib = L.lib()
+        L.require_gpu(ann_bld)
+        hp = self.hp
+        dev = ann_bld.device
+        B, Lc, D = ann_bld.shape
+        Hh, Ww = hw
+        V, m = self.embedding.weight.shape
+        n = self.lstm.weight_hh_l0.shape[1]
+        A = self.attention.decoder_att.weight.shape[0]
+        START, PAD = int(hp.vocab_stoi["<START>"]), int(hp.vocab_stoi["<PAD>"])
+        END, UNK = int(hp.vocab_stoi["<END>"]), int(hp.vocab_stoi["<UNK>"])
+        temps = temperature if isinstance(temperature, list) else [temperature]
+        dims = Dk.decoder_dims(1, beamk, 2, Lc, D, A, m, n, V, 0, hp.deep_output, self.pad_idx,
+                               int(getattr(self, "sat_precision", "fp32") == "bf16"))
+        w, _keep = self._params_struct()
+        ws_bytes = lib.sat_decoder_infer_workspace_bytes(C.byref(dims), beamk)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        mask_rest = torch.tensor([START, PAD], dtype=torch.int32, device=dev)
+        mask_first = torch.tensor([START, PAD, END, UNK], dtype=torch.int32, device=dev)
+        work = torch.empty(beamk * V, **f32)
+        captions, cap_scores, cap_alphas, cap_ppl = [], [], [], []
+        st = L.stream_ptr
+        for idx in range(B):
+            k = beamk
+            ann = ann_bld[idx].contiguous()
+            h = torch.empty(k, n, **f32); c = torch.empty(k, n, **f32)
+            L.check(lib.sat_decoder_infer_begin(C.byref(dims), C.byref(w), L.ptr(ann), k, beamk, L.ptr(h), L.ptr(c), L.ptr(ws), ws_bytes, st()),
+                    "sat_decoder_infer_begin")
+            top_preds = torch.full((1, k), START, dtype=torch.int64, device=dev)
+            top_scores = torch.zeros(k, **f32)
+            alphas = torch.zeros(1, k, Lc, **f32)
+            fin_caps, fin_alphas, fin_scores, fin_ppl = [], [], [], []
+
+            def rescore(s, step):
+                if rescore_method == "LN":
+                    return s / step
+                if rescore_method == "WR":
+                    return s + rescore_reward * step
+                if rescore_method == "BAR":
+                    return s + rescore_reward * (-top_scores.mean())
+                return s
+
+            step = 0
+            while True:
+                T = float(temps[step % len(temps)])
+                tok = top_preds[step].to(torch.int32).contiguous()
+                logits = torch.empty(k, V, **f32); alpha = torch.empty(k, Lc, **f32)
+                L.check(lib.sat_decoder_infer_step(C.byref(dims), C.byref(w), L.ptr(ann), L.ptr(tok), k, beamk, L.ptr(h), L.ptr(c), L.ptr(logits),
+                                                   L.ptr(alpha), L.ptr(ws), ws_bytes, st()), "sat_decoder_infer_step")
+                scores = torch.empty(k, V, **f32)
+                vals = torch.empty(k, **f32); inds = torch.empty(k, dtype=torch.int32, device=dev)
+                if step == 0:
+                    L.check(lib.sat_beam_scores(L.ptr(logits), k, V, T, L.ptr(mask_first), 4, None, L.ptr(scores), st()), "sat_beam_scores")
+                    L.check(lib.sat_topk(L.ptr(scores), L.ptr(work), V, k, L.ptr(vals), L.ptr(inds), st()), "sat_topk")       # row 0 only (model.py:343)
+                    top_scores = vals
+                    top_preds = torch.cat([top_preds, inds.to(torch.int64).unsqueeze(0)], 0)
+                    alphas = torch.cat([alphas, alpha.unsqueeze(0)], 0)
+                else:
+                    L.check(lib.sat_beam_scores(L.ptr(logits), k, V, T, L.ptr(mask_rest), 2, L.ptr(top_scores.contiguous()), L.ptr(scores), st()),
+                            "sat_beam_scores")
+                    L.check(lib.sat_topk(L.ptr(scores), L.ptr(work), k * V, k, L.ptr(vals), L.ptr(inds), st()), "sat_topk")
+                    top_scores = vals
+                    pred = inds.to(torch.int64)
+                    keep = torch.div(pred, V, rounding_mode="floor")
+                    word = torch.remainder(pred, V).unsqueeze(0)
+                    top_preds = torch.cat([top_preds[:, keep], word], 0)
+                    alphas = torch.cat([alphas[:, keep], alpha.unsqueeze(0)[:, keep]], 0)
+                    h, c = h[keep].contiguous(), c[keep].contiguous()
+                complete = top_preds[step + 1] == END
+                done = complete.tolist()
+                if any(done):
+                    for i, flag in enumerate(done):
+                        if flag:
+                            fin_caps.append(top_preds[:, i][1:-1].tolist())
+                            fin_alphas.append(alphas[:, i][1:-1].reshape(-1, Hh, Ww).cpu())
+                            fin_scores.append(float(rescore(top_scores[i], step)))
+                            fin_ppl.append(float(torch.exp(-top_scores[i] / step)))
+                    inc = ~complete
+                    top_preds, alphas, top_scores = top_preds[:, inc], alphas[:, inc], top_scores[inc]
+                    h, c = h[inc].contiguous(), c[inc].contiguous()
+                    k = int(inc.sum())
+                    if k == 0:
+                        break
+                if step >= max_gen_length:
+                    for i in range(top_preds.shape[1]):
+                        fin_caps.append(top_preds[:, i][1:-1].tolist())
+                        fin_alphas.append(alphas[:, i][1:-1].reshape(-1, Hh, Ww).cpu())
+                        fin_scores.append(float(rescore(top_scores[i], step)))
+                        fin_ppl.append(float(torch.exp(-top_scores[i] / step)))
+                    break
+                step += 1
+            if return_all:
+                order = [i for _, i in sorted([[fin_scores[i], i] for i in range(len(fin_scores))], reverse=True)]
+                captions.append([fin_caps[i] for i in order]); cap_alphas.append([fin_alphas[i] for i in order])
+                cap_scores.append([fin_scores[i] for i in order]); cap_ppl.append([fin_ppl[i] for i in order])
+            else:
+                best = fin_scores.index(max(fin_scores))
+                captions.append(fin_caps[best]); cap_alphas.append(fin_alphas[best])
+                cap_scores.append(fin_scores[best]); cap_ppl.append(fin_ppl[best])
+        return captions, cap_scores, cap_alphas, cap_ppl
+
     def train_decode(self, ann_bld, caps, lengths, epsilon=0, draw=None, with_loss=True):
         """Decoder half of train_batch + the loss terms (model.py:487-557, 592-597).
 
@@ -156,8 +274,8 @@ class SAT(SATDecoder, _Base):
     Same constructor kwargs (train.py:264 passes ``**vars(args)``), same sub-module attribute names and
     state-dict keys; ``train_batch`` / ``training_step`` / ``configure_optimizers`` keep their signatures.
     Construction order follows the reference (criterion, encoder, embedding, init_lstm, lstm, attention, beta,
-    output) so that a seed produces the same parameter stream.  Inference (``caption`` / beam search,
-    model.py:214-472) and the nltk metrics (model.py:646-718) are outside this round's scope."""
+    output) so that a seed produces the same parameter stream.  ``caption`` / ``forward`` run the reference's per-image
+    beam search ("beam" sampling) on the HIP step kernels; the nltk metrics (model.py:646-718) are out of scope."""
 
     def __init__(self, **kwargs):
         nn.Module.__init__(self)
@@ -207,6 +325,23 @@ class SAT(SATDecoder, _Base):
         ann = self.encoder(img)                                  # (B, D, h, w), channels-last memory
         B, D, h, w = ann.shape
         return ann.permute(0, 2, 3, 1).reshape(B, h * w, D), (h, w)
+
+    @torch.no_grad()
+    def caption(self, img_tensor, beamk=3, max_gen_length=32, temperature=1.0, sample_method="beam", sample_topk=3,
+                decoder_noise=None, rescore_method=None, rescore_reward=0.5, return_all=False):
+        """model.py:214-235: eval mode, then forward."""
+        self.eval()
+        return self.forward(img_tensor, beamk, max_gen_length, temperature, sample_method, sample_topk, decoder_noise,
+                            rescore_method, rescore_reward, return_all)
+
+    def forward(self, img, beamk=3, max_gen_length=32, temperature=1.0, sample_method="beam", sample_topk=3, decoder_noise=None,
+                rescore_method=None, rescore_reward=0.5, return_all=False):
+        """Inference only (model.py:237-472): encode the batch once, then beam-search every image."""
+        assert sample_method in ["beam", "multinomial", "topk"]
+        with torch.no_grad():
+            ann_bld, hw = self.encode(img)
+            return self.beam_decode(ann_bld.contiguous(), hw, beamk, max_gen_length, temperature, sample_method, sample_topk,
+                                    decoder_noise, rescore_method, rescore_reward, return_all)
 
     def train_batch(self, batch, epsilon=0, draw=None):
         img, encoded_captions, lengths = batch

@@ -161,6 +161,33 @@ def g6():
     save("g6_label_smoothing", **out)
 
 
+# ---------------------------------------------------------------- G7 (beam search, model.py:214-472)
+def g7():
+    hp = small_hp(vocab_size=31)
+    model, sd = build(hp, 70)
+    model.eval()
+    ann = torch.from_numpy(prng.uniform((3, hp.encoder_dim, 2, 3), 701, 0.0, 1.5))
+    arrs = {"sd." + k: v for k, v in sd.items()}
+    arrs["ann"] = ann
+    cases = [(1, None, False, 6), (3, None, False, 6), (5, "LN", False, 7), (3, "WR", True, 5), (4, "BAR", True, 6), (3, "LN", True, 4)]
+    arrs["cases"] = np.array([[c[0], {None: 0, "LN": 1, "WR": 2, "BAR": 3}[c[1]], int(c[2]), c[3]] for c in cases])
+    for ci, (beamk, rm, ra, mgl) in enumerate(cases):
+        caps, scores, alphas, ppl = model.caption(ann, beamk=beamk, max_gen_length=mgl, temperature=1.0, sample_method="beam",
+                                                  rescore_method=rm, rescore_reward=0.5, return_all=ra)
+        for b in range(ann.shape[0]):
+            cl = caps[b] if ra else [caps[b]]
+            sl = scores[b] if ra else [scores[b]]
+            al = alphas[b] if ra else [alphas[b]]
+            pl_ = ppl[b] if ra else [ppl[b]]
+            arrs["c%d_b%d_n" % (ci, b)] = np.int64(len(cl))
+            for j in range(len(cl)):
+                arrs["c%d_b%d_%d_tok" % (ci, b, j)] = np.array(cl[j], np.int64)
+                arrs["c%d_b%d_%d_score" % (ci, b, j)] = np.float64(sl[j])
+                arrs["c%d_b%d_%d_ppl" % (ci, b, j)] = np.float64(pl_[j])
+                arrs["c%d_b%d_%d_alpha" % (ci, b, j)] = al[j].numpy()
+    save("g7_beam", **arrs)
+
+
 # ---------------------------------------------------------------- G8 (C1 decoder shapes)
 def g8():
     hp = O.default_hparams(vocab_size=6400, encoder_dim=256, embed_dim=256, attention_dim=128, decoder_dim=512, input_size=64)
@@ -219,4 +246,4 @@ if __name__ == "__main__":
     g4("layers2", 1.0, 46, decoder_layers=2)
     g4("embnorm", 1.0, 47, embed_norm=0.3)
     g4("gamma", 0.0, 48, att_gamma=0.5, B=4, R=3, T=9, H=3, W=3)
-    g6(); g8(); g_encoder()
+    g6(); g7(); g8(); g_encoder()

@@ -1,0 +1,57 @@
+"""GPU parity of the inference row (BASELINE config C5): SAT.caption / forward beam search on the HIP
+step kernels against the reference fixtures (G7: token ids exact; scores, perplexities, alphas within 1e-4) and,
+for a ResNet-backed model, against the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from test_oracle_golden import _beam_cases, check_beam_against_golden, sd_from  # noqa: E402
+
+
+def test_g7_beam_search_on_hip(golden_dir):
+    import sat_amd  # noqa: F401
+    from sat_amd import model as M
+    from oracle import sat_oracle as O
+    g = np.load(os.path.join(golden_dir, "g7_beam.npz"))
+    sd = sd_from(g)
+    V, m = sd["embedding.weight"].shape
+    hp = O.default_hparams(vocab_size=V, embed_dim=m, decoder_dim=sd["lstm.weight_hh_l0"].shape[1],
+                           encoder_dim=sd["attention.encoder_att.weight"].shape[1], attention_dim=sd["attention.encoder_att.weight"].shape[0])
+    dec = M.SATDecoder(hp).cuda().eval()
+    dec.load_decoder_state(sd)
+    ann = torch.tensor(g["ann"])
+    B, D, Hh, Ww = ann.shape
+    ann_bld = ann.permute(0, 2, 3, 1).reshape(B, Hh * Ww, D).contiguous().cuda()
+    for ci, beamk, rm, ra, mgl in _beam_cases(g):
+        out = dec.beam_decode(ann_bld, (Hh, Ww), beamk=beamk, max_gen_length=mgl, rescore_method=rm, rescore_reward=0.5, return_all=ra)
+        check_beam_against_golden(g, ci, ra, *out, tol=1e-4)
+
+
+def test_caption_end_to_end_matches_oracle():
+    """caption(img): eval-mode encoder (running statistics) + beam search, C5-style (beamk 5) on a small ResNet-18 model."""
+    import sat_amd  # noqa: F401
+    from sat_amd import model as M
+    from oracle import prng, sat_oracle as O
+    over = dict(encoder_arch="resnet18", encoder_dim=32, input_size=64, encoder_size=3, vocab_size=60, embed_dim=24, attention_dim=16,
+                decoder_dim=40, deep_output=True)
+    torch.manual_seed(11)
+    model = M.SAT(**vars(O.default_hparams(**over))).cuda()
+    oracle = O.OracleSAT(O.default_hparams(**over), {k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+    img = torch.from_numpy(prng.uniform((3, 3, 64, 64), 31, 0.0, 1.0))
+    caps, scores, alphas, ppl = model.caption(img.cuda(), beamk=5, max_gen_length=8, rescore_method="LN")
+    assert not model.training
+    oracle.encoder.eval()
+    with torch.no_grad():
+        ann = oracle.encoder(img.clone())
+        ocaps, oscores, oalphas, oppl = O.beam_search(oracle.sd, oracle.hp, ann, beamk=5, max_gen_length=8, rescore_method="LN")
+    assert caps == ocaps
+    for a, b in zip(scores, oscores):
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(b))
+    for a, b in zip(alphas, oalphas):
+        assert a.shape == b.shape and float((a - b).abs().max()) <= 1e-4
+    with pytest.raises(NotImplementedError):
+        model.caption(img.cuda(), sample_method="multinomial")

@@ -194,3 +194,39 @@ def test_encoder_structure(golden_dir):
 def test_fixtures_are_small(golden_dir):
     total = sum(os.path.getsize(p) for p in glob.glob(os.path.join(golden_dir, "*.npz")))
     assert total < 4 << 20
+
+
+def _beam_cases(g):
+    names = {0: None, 1: "LN", 2: "WR", 3: "BAR"}
+    return [(ci, int(c[0]), names[int(c[1])], bool(c[2]), int(c[3])) for ci, c in enumerate(g["cases"])]
+
+
+def check_beam_against_golden(g, ci, return_all, caps, scores, alphas, ppl, tol):
+    B = g["ann"].shape[0]
+    for b in range(B):
+        n = int(g["c%d_b%d_n" % (ci, b)])
+        cl = caps[b] if return_all else [caps[b]]
+        sl = scores[b] if return_all else [scores[b]]
+        al = alphas[b] if return_all else [alphas[b]]
+        pl = ppl[b] if return_all else [ppl[b]]
+        assert len(cl) == n
+        for j in range(n):
+            key = "c%d_b%d_%d_" % (ci, b, j)
+            assert list(cl[j]) == g[key + "tok"].tolist(), (ci, b, j)
+            assert abs(float(sl[j]) - float(g[key + "score"])) <= tol * max(1.0, abs(float(g[key + "score"])))
+            assert abs(float(pl[j]) - float(g[key + "ppl"])) <= tol * max(1.0, abs(float(g[key + "ppl"])))
+            a = np.asarray(al[j].cpu() if torch.is_tensor(al[j]) else al[j], np.float64)
+            assert a.shape == g[key + "alpha"].shape and np.abs(a - g[key + "alpha"]).max() <= tol
+
+
+def test_g7_beam_search(golden_dir):
+    """model.py:214-472 (beam sampling; rescoring None / LN / WR / BAR; return_all both ways)."""
+    g = load(golden_dir, "g7_beam")
+    sd = sd_from(g)
+    hp = O.default_hparams(vocab_size=sd["embedding.weight"].shape[0], deep_output=True)
+    hp.decoder_dim = sd["lstm.weight_hh_l0"].shape[1]
+    ann = torch.tensor(g["ann"])
+    for ci, beamk, rm, ra, mgl in _beam_cases(g):
+        with torch.no_grad():
+            out = O.beam_search(sd, hp, ann, beamk=beamk, max_gen_length=mgl, rescore_method=rm, rescore_reward=0.5, return_all=ra)
+        check_beam_against_golden(g, ci, ra, *out, tol=2e-6)
