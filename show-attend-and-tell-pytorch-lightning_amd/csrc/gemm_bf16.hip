@@ -34,6 +34,7 @@ struct BArgs {
     ConvGeom g;
     int kchunk, nsplit;
     float* slab;
+    int wide_store;       // bf16 output staged through LDS and written 16 bytes per lane
 };
 
 template <typename T> struct VecN { static constexpr int n = 16 / sizeof(T); };
@@ -84,25 +85,44 @@ __device__ __forceinline__ void row_setup(const BArgs& a, int m, RowCtx& c) {
     }
 }
 
+// Decoded k index of one k-tile row, shared through LDS so that the integer divisions are done by 32 lanes per
+// tile instead of by every gathering lane: conv fwd / dgrad: (r, s, channel); wgrad: (image, y0, x0) of the pixel.
+struct KEnt { int e0, e1, e2; };      // e2 < 0 : beyond the end of the reduction
+
+template <int AM, int BMo>
+__device__ __forceinline__ KEnt k_decode(const BArgs& a, int k, int kend) {
+    KEnt t; t.e0 = t.e1 = 0; t.e2 = -1;
+    if (k >= kend) return t;
+    const ConvGeom& g = a.g;
+    if (AM == A_CONV_FWD) { int rs = k / g.C; t.e2 = k - rs * g.C; t.e0 = rs / g.S; t.e1 = rs - t.e0 * g.S; }
+    else if (AM == A_CONV_DGRAD) { int rs = k / g.K; t.e2 = k - rs * g.K; t.e0 = rs / g.S; t.e1 = rs - t.e0 * g.S; }
+    else if (BMo == B_CONV_WGRAD) {
+        int pq = g.P * g.Q; int img = k / pq; int rem = k - img * pq; int p = rem / g.Q, q = rem - p * g.Q;
+        t.e2 = img; t.e0 = p * g.stride - g.pad; t.e1 = q * g.stride - g.pad;
+    }
+    return t;
+}
+
 template <int AM, typename T>
-__device__ __forceinline__ uint4 row_fetch(const BArgs& a, const RowCtx& c, int k, int kend) {
+__device__ __forceinline__ uint4 row_fetch(const BArgs& a, const RowCtx& c, int k, int kend, const KEnt& t) {
     const uint4 z = make_uint4(0, 0, 0, 0);
     if (!c.ok || k >= kend) return z;
     const T* A = reinterpret_cast<const T*>(a.A);
     if (AM == A_ROW) return *reinterpret_cast<const uint4*>(A + c.base + k);
     const ConvGeom& g = a.g;
     if (AM == A_CONV_FWD) {
-        int rs = k / g.C, ch = k - rs * g.C; int r = rs / g.S, s = rs - r * g.S;
-        int y = c.y0 + r, x = c.x0 + s;
+        int y = c.y0 + t.e0, x = c.x0 + t.e1;
         if ((unsigned)y >= (unsigned)g.H || (unsigned)x >= (unsigned)g.W) return z;
-        return *reinterpret_cast<const uint4*>(A + (((long)c.n * g.H + y) * g.W + x) * g.C + ch);
+        return *reinterpret_cast<const uint4*>(A + (((long)c.n * g.H + y) * g.W + x) * g.C + t.e2);
     }
-    int rs = k / g.K, ko = k - rs * g.K; int r = rs / g.S, s = rs - r * g.S;
-    int ty = c.y0 - r, tx = c.x0 - s;
+    int ty = c.y0 - t.e0, tx = c.x0 - t.e1;
     if (ty < 0 || tx < 0) return z;
-    int p = ty / g.stride, q = tx / g.stride;
-    if (p * g.stride != ty || q * g.stride != tx || p >= g.P || q >= g.Q) return z;
-    return *reinterpret_cast<const uint4*>(A + (((long)c.n * g.P + p) * g.Q + q) * g.K + ko);
+    int p, q;
+    if (g.stride == 1) { p = ty; q = tx; }
+    else if (g.stride == 2) { if ((ty | tx) & 1) return z; p = ty >> 1; q = tx >> 1; }
+    else { p = ty / g.stride; q = tx / g.stride; if (p * g.stride != ty || q * g.stride != tx) return z; }
+    if (p >= g.P || q >= g.Q) return z;
+    return *reinterpret_cast<const uint4*>(A + (((long)c.n * g.P + p) * g.Q + q) * g.K + t.e2);
 }
 
 template <typename T>
@@ -120,20 +140,19 @@ __device__ __forceinline__ uint4 kmajor_fetch(const void* base, long ld, int k, 
 struct ColCtx { int r, s, ch; bool ok; };
 
 template <int BMo, typename T>
-__device__ __forceinline__ uint4 bk_fetch(const BArgs& a, const ColCtx& c, int n, int k, int kend) {
+__device__ __forceinline__ uint4 bk_fetch(const BArgs& a, const ColCtx& c, int n, int k, int kend, const KEnt& t) {
     if (BMo == B_KMAJOR) return kmajor_fetch<T>(a.B, a.ldb, k, kend, n, a.N);
     const uint4 z = make_uint4(0, 0, 0, 0);
     if (!c.ok || k >= kend) return z;
     const ConvGeom& g = a.g;
     const T* B = reinterpret_cast<const T*>(a.B);
-    if (BMo == B_CONV_WGRAD) {
-        int pq = g.P * g.Q; int img = k / pq; int rem = k - img * pq; int p = rem / g.Q, q = rem - p * g.Q;
-        int y = p * g.stride - g.pad + c.r, x = q * g.stride - g.pad + c.s;
+    if (BMo == B_CONV_WGRAD) {          // t = (y0, x0, image) of output pixel k
+        int y = t.e0 + c.r, x = t.e1 + c.s;
         if ((unsigned)y >= (unsigned)g.H || (unsigned)x >= (unsigned)g.W) return z;
-        return *reinterpret_cast<const uint4*>(B + (((long)img * g.H + y) * g.W + x) * g.C + c.ch);
+        return *reinterpret_cast<const uint4*>(B + (((long)t.e2 * g.H + y) * g.W + x) * g.C + c.ch);
     }
-    int rs = k / g.K, ko = k - rs * g.K; int r = rs / g.S, s = rs - r * g.S;
-    return *reinterpret_cast<const uint4*>(B + (((long)ko * g.R + r) * g.S + s) * g.C + n);
+    // B_CONV_DGRAD_W: t = (r, s, ko) of reduction index k
+    return *reinterpret_cast<const uint4*>(B + (((long)t.e2 * g.R + t.e0) * g.S + t.e1) * g.C + n);
 }
 
 // raw 16 bytes -> bf16 in LDS.  bf16 source: 8 elements (ds_write_b128); fp32 source: 4 elements (ds_write_b64)
@@ -160,7 +179,9 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(BArgs a) {
     constexpr int VA = VecN<TA>::n, VB = VecN<TB>::n;
     constexpr int NVA = BM * KB / VA / NT, NVB = BN * KB / VB / NT;
     constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr bool CONV = (AM == A_CONV_FWD || AM == A_CONV_DGRAD || BMo == B_CONV_WGRAD);
     __shared__ __attribute__((aligned(16))) __bf16 smem[2 * STAGE];
+    __shared__ KEnt ktab[2][KB];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bm = blockIdx.y * BM, bn = blockIdx.x * BN;
@@ -201,13 +222,17 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(BArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     uint4 ra[NVA], rb[NVB];
-    auto fetch = [&](int k0) {
+    const KEnt none = {0, 0, -1};
+    auto fill_tab = [&](int buf, int k0) { if (CONV && tid < KB) ktab[buf][tid] = k_decode<AM, BMo>(a, k0 + tid, kend); };
+    auto fetch = [&](int k0, int tb) {
 #pragma unroll
         for (int j = 0; j < NVA; ++j)
-            ra[j] = AK ? kmajor_fetch<TA>(a.A, a.lda, k0 + a0[j], kend, bm + a1[j], a.M) : row_fetch<AM, TA>(a, actx[j], k0 + a1[j], kend);
+            ra[j] = AK ? kmajor_fetch<TA>(a.A, a.lda, k0 + a0[j], kend, bm + a1[j], a.M)
+                       : row_fetch<AM, TA>(a, actx[j], k0 + a1[j], kend, (AM == A_ROW) ? none : ktab[tb][a1[j]]);
 #pragma unroll
         for (int j = 0; j < NVB; ++j)
-            rb[j] = BKM ? bk_fetch<BMo, TB>(a, bctx[j], bn + b1[j], k0 + b0[j], kend) : brow_fetch<TB>(a, bn + b0[j], k0 + b1[j], kend);
+            rb[j] = BKM ? bk_fetch<BMo, TB>(a, bctx[j], bn + b1[j], k0 + b0[j], kend, (BMo == B_KMAJOR) ? none : ktab[tb][b0[j]])
+                        : brow_fetch<TB>(a, bn + b0[j], k0 + b1[j], kend);
     };
     auto stash = [&](int buf) {
         __bf16* as = smem + buf * STAGE; __bf16* bs = as + A_EL;
@@ -219,12 +244,13 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(BArgs a) {
 
     int cur = 0;
     if (kbeg < kend) {
-        fetch(kbeg);
+        if (CONV) { fill_tab(0, kbeg); fill_tab(1, kbeg + KB); __syncthreads(); }
+        fetch(kbeg, 0);
         stash(0);
         __syncthreads();
-        for (int k0 = kbeg; k0 < kend; k0 += KB) {
+        for (int k0 = kbeg, it = 0; k0 < kend; k0 += KB, ++it) {
             const bool more = (k0 + KB) < kend;
-            if (more) fetch(k0 + KB);
+            if (more) fetch(k0 + KB, (it + 1) & 1);
             const __bf16* as = smem + cur * STAGE;
             const __bf16* bs = as + A_EL;
 #pragma unroll
@@ -257,11 +283,49 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(BArgs a) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
             }
             if (more) stash(cur ^ 1);
+            fill_tab(it & 1, k0 + 2 * KB);          // tile it+2; tile it's entries were consumed a full iteration ago
             __syncthreads();
             cur ^= 1;
         }
     }
 
+    if (sizeof(TC) == 2 && a.wide_store) {
+        // bf16 result: the MFMA C layout gives each lane one column, i.e. 2-byte stores.  Stage the tile in LDS
+        // (the operand buffers are free now) and write whole 16-byte row segments instead.
+        constexpr int LDC = BN + 8;
+        static_assert(BM * LDC <= 2 * STAGE, "C tile must fit the staging buffers");
+        __bf16* cs = smem;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int lr = wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, lc = wn + j * 32 + li;
+                    float v = acc[i][j][r];
+                    if (bm + lr < a.M && bn + lc < a.N) v = ep_value(a, bm + lr, bn + lc, v);
+                    cs[lr * LDC + lc] = (__bf16)v;
+                }
+        __syncthreads();
+        constexpr int VPR = BN / 8;
+#pragma unroll
+        for (int j = 0; j < BM * VPR / NT; ++j) {
+            int v = tid + j * NT, lr = v / VPR, lc = (v % VPR) * 8;
+            int row = bm + lr, col = bn + lc;
+            if (row < a.M && col < a.N) {
+                bf16x8 o = *reinterpret_cast<const bf16x8*>(cs + lr * LDC + lc);
+                __bf16* dst = reinterpret_cast<__bf16*>(a.C) + (long)row * a.ldc + col;
+                if (a.accumulate) {
+                    bf16x8 old = *reinterpret_cast<const bf16x8*>(dst);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (__bf16)((float)o[e] + (float)old[e]);
+                }
+                *reinterpret_cast<bf16x8*>(dst) = o;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -363,6 +427,8 @@ int launch_gemm_bf16(const GemmArgs& g, hipStream_t st) {
     int ktiles = cdiv(g.K, KB); if (ktiles < 1) ktiles = 1;
     int per = cdiv(ktiles, ns);
     k.kchunk = per * KB; k.nsplit = cdiv(ktiles, per);
+    k.wide_store = (g.c_bf16 && !g.c_rows && k.nsplit == 1 && g.N % 8 == 0 && g.ldc % 8 == 0 && al16(g.C) &&
+                    (g.epi == EPI_NONE || g.epi == EPI_BIAS || g.epi == EPI_BIAS_RELU)) ? 1 : 0;
 
 #define SAT_BCASE(AMV, BMV, TA, TB, TC) return runb_tiles<AMV, BMV, TA, TB, TC>(k, BMt, st);
     const bool ab = g.a_bf16, bb = g.b_bf16, cb = g.c_bf16;
