@@ -11,6 +11,8 @@
 //                                            two ds_read_b64_tr_b16 (hardware transpose), row stride
 //                                            = 64 B mod 256 B => the 4 rows of a block hit disjoint banks
 // Block = 256 threads (2 x 2 waves), tile BM x BN x 32, register-staged double buffer.
+#include <stdlib.h>
+
 #include "gemm.h"
 #include "profile.h"
 
@@ -420,8 +422,14 @@ int launch_gemm_bf16(const GemmArgs& g, hipStream_t st) {
     long blocks = (long)cdiv(g.M, BMt) * cdiv(g.N, BMt);
     int ns = 1;
     if (g.slab && blocks < 256 && g.K >= 16 * KB) {
-        int want = (int)((512 + blocks - 1) / blocks), maxs = g.K / (8 * KB);
-        ns = want < maxs ? want : maxs; if (ns > 64) ns = 64; if (ns < 1) ns = 1;
+        // split-K: enough blocks to keep every CU streaming (~TARGET blocks), but the fp32 partial slabs (written and
+        // re-read: 8 bytes per output element per split) must stay a fraction of the operand bytes
+        static const int target = getenv("SAT_SPLIT_TARGET") ? atoi(getenv("SAT_SPLIT_TARGET")) : 768;
+        static const int frac = getenv("SAT_SPLIT_FRAC") ? atoi(getenv("SAT_SPLIT_FRAC")) : 8;
+        int want = (int)((target + blocks - 1) / blocks), maxs = g.K / (8 * KB);
+        double in_bytes = ((double)g.M + g.N) * g.K * 2.0;
+        int lim = (int)(in_bytes / ((double)frac * g.M * g.N)); if (lim < 4) lim = 4;
+        ns = want < maxs ? want : maxs; if (ns > lim) ns = lim; if (ns > 256) ns = 256; if (ns < 1) ns = 1;
         while (ns > 1 && (long)ns * g.M * g.N > g.slab_elems) --ns;
     }
     int ktiles = cdiv(g.K, KB); if (ktiles < 1) ktiles = 1;
