@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SAT_HIP_ABI_VERSION 2
+#define SAT_HIP_ABI_VERSION 3
 
 int sat_abi_version(void);
 const char* sat_last_error(void);
@@ -81,6 +81,7 @@ typedef struct sat_decoder_dims {
     int32_t deep_output;  /* DeepOutput.deep (model.py:116)                        */
     int32_t padding_idx;  /* <PAD> id (model.py:162)                               */
     int32_t precision;    /* 0: exact fp32 MFMA (parity mode); 1: bf16 MFMA, fp32 accumulate/state */
+    float embed_max_norm; /* nn.Embedding max_norm (model.py:161); <= 0: off.  Renormalises embedding rows IN PLACE */
 } sat_decoder_dims;
 
 /* state-dict tensors of the decoder; used for weights and, with the same

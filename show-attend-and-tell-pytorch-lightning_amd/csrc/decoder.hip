@@ -13,7 +13,7 @@ struct Ws {
     size_t total = 0;
     // saved by forward
     float *U, *mean, *f, *init_img, *H_all, *C_all, *HC, *Z, *XZ, *Y, *GY, *Uact, *Wcat, *bcat;
-    int* Tok;
+    int* Tok; int* flags;
     // backward scratch
     float *dA, *dHout, *dZout, *DZ, *DHC, *dXZ, *dHc, *dCc, *dU, *dwf_part, *dY, *colpart, *dinit_img, *df, *dmean, *slab;
     long slab_elems;
@@ -38,6 +38,7 @@ Ws layout(const sat_decoder_dims& d, char* base) {
     w.Wcat = (float*)take((size_t)HCW * d.n);
     w.bcat = (float*)take((size_t)HCW);
     w.Tok = (int*)take((size_t)T1 * N);
+    w.flags = (int*)take((size_t)d.V);
     w.dA = (float*)take((size_t)(d.P > 0 ? d.P : 1) * d.m);
     w.dHout = (float*)take((size_t)T1 * N * d.n);
     w.dZout = (float*)take((size_t)T1 * N * d.D);
@@ -179,7 +180,16 @@ int decoder_fwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
             hipLaunchKernelGGL(teacher_tokens_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, b.caps, b.lengths, w.Tok + (long)t * N, N, d.T, t);
             SAT_TRY(launch_ok("teacher_tokens"));
         }
+    auto renorm = [&](const int* tok, int count) -> int {
+        if (!(d.embed_max_norm > 0.f)) return SAT_OK;
+        hipLaunchKernelGGL(embedding_mark_kernel, dim3(cdiv(count, 256)), dim3(256), 0, st, tok, count, w.flags, d.V);
+        SAT_TRY(launch_ok("embedding_mark"));
+        hipLaunchKernelGGL(embedding_renorm_kernel, dim3(d.V), dim3(64), 0, st, p.embedding, w.flags, m, d.embed_max_norm);
+        return launch_ok("embedding_renorm");
+    };
+    if (d.embed_max_norm > 0.f) SAT_CHECK_HIP(hipMemsetAsync(w.flags, 0, (size_t)d.V * 4, st));
     if (ts > 0) {
+        SAT_TRY(renorm(w.Tok, ts * N));
         hipLaunchKernelGGL(gather_rows_kernel, dim3(ts * N), dim3(64), 0, st, p.embedding, w.Tok, w.Y, ts * N, m);
         SAT_TRY(launch_ok("embedding gather"));
         SAT_TRY(gemm(st, A_ROW, B_ROW, w.Y, m, p.w_ih, m + D, w.GY, 4 * n, ts * N, 4 * n, m));
@@ -194,6 +204,7 @@ int decoder_fwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
             pending = t;
             hipLaunchKernelGGL(argmax_tokens_kernel, dim3(N), dim3(256), 0, st, logits, b.prow + (long)(t - 1) * N, b.lengths, w.Tok + (long)t * N, d.V, t);
             SAT_TRY(launch_ok("argmax_tokens"));
+            SAT_TRY(renorm(w.Tok + (long)t * N, N));
             hipLaunchKernelGGL(gather_rows_kernel, dim3(N), dim3(64), 0, st, p.embedding, w.Tok + (long)t * N, w.Y + (long)t * N * m, N, m);
             SAT_TRY(launch_ok("embedding gather"));
             SAT_TRY(gemm(st, A_ROW, B_ROW, w.Y + (long)t * N * m, m, p.w_ih, m + D, w.GY + (long)t * N * 4 * n, 4 * n, N, 4 * n, m));
@@ -229,7 +240,6 @@ int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
     SAT_CHECK_HIP(hipMemsetAsync(w.dCc, 0, (size_t)N * n * 4, st));
     SAT_CHECK_HIP(hipMemsetAsync(w.dHout, 0, (size_t)T1 * N * n * 4, st));
     SAT_CHECK_HIP(hipMemsetAsync(w.dZout, 0, (size_t)T1 * N * D * 4, st));
-    SAT_CHECK_HIP(hipMemsetAsync(g.embedding, 0, (size_t)V * m * 4, st));
 
     // ---- output layer, all packed rows at once (DeepOutput backward)
     if (P > 0) {
@@ -290,10 +300,8 @@ int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
     SAT_TRY(wgrad(dG, HCW, w.XZ, D, g.w_ih + m, m + D, 4 * n, D));
     // embedding: dY = dA (deep output) + dG * W_ih[:, :m], scattered into the table (padding row skipped)
     SAT_TRY(gemm(st, A_ROW, B_KMAJOR, dG, HCW, p.w_ih, m + D, w.dY, m, KR, m, 4 * n, 1));
-    if (KR > 0) {
-        hipLaunchKernelGGL(embedding_bwd_kernel, dim3(KR), dim3(64), 0, st, w.dY, w.Tok, g.embedding, KR, m, d.padding_idx);
-        SAT_TRY(launch_ok("embedding_bwd"));
-    }
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(V), dim3(256), 0, st, w.dY, w.Tok, g.embedding, KR, m, d.padding_idx);
+    SAT_TRY(launch_ok("embedding_bwd"));
     // attention parameters and the annotation gradient
     SAT_TRY(colsum(st, w, w.dwf_part, A, d.B, A, g.att_f));
     SAT_TRY(gemm(st, A_KMAJOR, B_KMAJOR, w.dU, A, b.ann, D, g.att_enc, D, A, D, d.B * d.L, 0, EPI_NONE, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, slab, se));

@@ -561,13 +561,65 @@ __global__ void colsum_finish_kernel(const float* __restrict__ part, int nparts,
     out[c] = accumulate ? out[c] + s : s;
 }
 
-// embedding gradient: dE[tok[r], :] += dY[r, :]  (padding row and dead rows skipped).  Float atomics.
-__global__ void embedding_bwd_kernel(const float* __restrict__ dY, const int* __restrict__ tok, float* __restrict__ dE, int rows, int width, int padding_idx) {
-    int r = blockIdx.x;
-    if (r >= rows) return;
-    int t = tok[r];
-    if (t < 0 || t == padding_idx) return;
-    for (int c = threadIdx.x; c < width; c += blockDim.x) atomicAdd(dE + (long)t * width + c, dY[(long)r * width + c]);
+// embedding gradient, deterministic: one block per vocabulary row v collects, in increasing r, the rows with
+// tok[r] == v (ordered compaction by wave ballots) and sums their dY rows in that order.  No atomics: the result
+// does not depend on scheduling.  The padding row and rows without a token (-1) get zeros.
+constexpr int EMB_LIST = 1024;
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* __restrict__ dY, const int* __restrict__ tok, float* __restrict__ dE,
+                                                            int rows, int width, int padding_idx) {
+    __shared__ int s_list[EMB_LIST];
+    __shared__ int s_wcnt[4];
+    __shared__ int s_total;
+    const int v = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* out = dE + (long)v * width;
+    if (v == padding_idx) { for (int c = tid; c < width; c += 256) out[c] = 0.f; return; }
+    for (int c0 = 0; c0 < width; c0 += 256) { if (c0 + tid < width) out[c0 + tid] = 0.f; }
+    if (tid == 0) s_total = 0;
+    __syncthreads();
+    for (int base = 0; base < rows; base += 256) {
+        const int r = base + tid;
+        const bool hit = (r < rows) && (tok[r] == v);
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) s_wcnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = s_total;
+        for (int w = 0; w < wave; ++w) off += s_wcnt[w];
+        const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+        if (hit && pos < EMB_LIST) s_list[pos] = r;
+        __syncthreads();
+        if (tid == 0) s_total += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        __syncthreads();
+        if (s_total >= EMB_LIST || base + 256 >= rows) {           // flush the ordered list
+            const int cnt = min(s_total, EMB_LIST);
+            for (int c = tid; c < width; c += 256) {
+                float acc = out[c];
+                for (int i = 0; i < cnt; ++i) acc += dY[(long)s_list[i] * width + c];
+                out[c] = acc;
+            }
+            __syncthreads();
+            if (tid == 0) s_total = 0;
+            __syncthreads();
+        }
+    }
+}
+
+// nn.Embedding(max_norm=...) (model.py:161): rows that are looked up and whose L2 norm exceeds max_norm are rescaled
+// in place by max_norm / (norm + 1e-7), as torch.embedding_renorm_ does.  flags marks the looked-up rows first so
+// that a row used by several tokens is rescaled exactly once.
+__global__ void embedding_mark_kernel(const int* __restrict__ tok, int n, int* __restrict__ flags, int V) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { int t = tok[i]; if (t >= 0 && t < V) flags[t] = 1; }
+}
+__global__ __launch_bounds__(64) void embedding_renorm_kernel(float* __restrict__ table, int* __restrict__ flags, int width, float max_norm) {
+    const int v = blockIdx.x, lane = threadIdx.x;
+    if (!flags[v]) return;
+    float* row = table + (long)v * width;
+    float s = 0.f;
+    for (int c = lane; c < width; c += 64) s += row[c] * row[c];
+    s = wave_sum(s);
+    const float norm = sqrtf(s);
+    if (norm > max_norm) { const float sc = max_norm / (norm + 1e-7f); for (int c = lane; c < width; c += 64) row[c] *= sc; }
+    if (lane == 0) flags[v] = 0;
 }
 
 // out[i] = a[i] + b[i]

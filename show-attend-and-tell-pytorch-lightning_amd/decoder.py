@@ -70,9 +70,9 @@ class PackPlan:
         return flags
 
 
-def decoder_dims(B, R, T, Lc, D, A, m, n, V, P, deep, padding_idx, precision=0):
+def decoder_dims(B, R, T, Lc, D, A, m, n, V, P, deep, padding_idx, precision=0, embed_max_norm=0.0):
     return L.DecoderDims(B=B, R=R, T=T, L=Lc, D=D, A=A, m=m, n=n, V=V, P=P, deep_output=int(bool(deep)), padding_idx=padding_idx,
-                         precision=int(precision))
+                         precision=int(precision), embed_max_norm=float(embed_max_norm or 0.0))
 
 
 def _params_struct(tensors):
@@ -96,7 +96,7 @@ class DecoderTrainFn(torch.autograd.Function):
     """logits_packed (P,V), alphas (N,T-1,L) = decoder(ann (B,L,D), captions) with BPTT backward."""
 
     @staticmethod
-    def forward(ctx, ann, caps_i32, plan, teacher, deep, padding_idx, R, precision, *params):
+    def forward(ctx, ann, caps_i32, plan, teacher, deep, padding_idx, R, precision, embed_max_norm, *params):
         lib = L.lib()
         L.require_gpu(ann, caps_i32, *[p for p in params if p is not None])
         names = L.PARAM_FIELDS
@@ -114,7 +114,7 @@ class DecoderTrainFn(torch.autograd.Function):
                       beta_b=(D,), out_hidden=(m, n), out_context=(m, D), out_w=(V, m), out_b=(V,))
         for k in names:
             _check_param(k, tens[k], shapes[k])
-        dims = decoder_dims(B, R, T, Lc, D, A, m, n, V, plan.P, deep, padding_idx, precision)
+        dims = decoder_dims(B, R, T, Lc, D, A, m, n, V, plan.P, deep, padding_idx, precision, embed_max_norm)
         ws_bytes = lib.sat_decoder_workspace_bytes(C.byref(dims))
         if ws_bytes == 0:
             raise L.SatHipError("sat_decoder_workspace_bytes: %s" % lib.sat_last_error().decode())
@@ -155,7 +155,7 @@ class DecoderTrainFn(torch.autograd.Function):
         w, g = _params_struct(tens), _params_struct(grads)
         L.check(lib.sat_decoder_train_bwd(C.byref(dims), C.byref(w), C.byref(batch), L.ptr(dlogits), L.ptr(alphas), L.ptr(dalphas),
                                           C.byref(g), L.ptr(dann), L.ptr(ctx.ws), ctx.ws_bytes, L.stream_ptr()), "sat_decoder_train_bwd")
-        return (dann, None, None, None, None, None, None, None, *[grads[k] for k in L.PARAM_FIELDS])
+        return (dann, None, None, None, None, None, None, None, None, *[grads[k] for k in L.PARAM_FIELDS])
 
 
 class LabelSmoothingFn(torch.autograd.Function):

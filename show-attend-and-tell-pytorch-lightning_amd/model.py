@@ -96,14 +96,12 @@ class SATDecoder(nn.Module):
             raise NotImplementedError("HIP decoder: decoder_layers=%d (only 1 layer is built this round)" % hp.decoder_layers)
         if float(hp.dropout) != 0.0 or float(hp.embedding_dropout) != 0.0:
             raise NotImplementedError("HIP decoder: dropout > 0 is not built this round (parity runs use 0, train.py:140-143)")
-        if getattr(hp, "embed_norm", None) is not None:
-            raise NotImplementedError("HIP decoder: embedding max_norm is not built this round")
         assert 0 <= hp.label_smoothing < (hp.vocab_size - 1) / hp.vocab_size
         self.criterion = LabelSmoothing(hp.label_smoothing)
         self.pad_idx = int(hp.vocab_stoi["<PAD>"])
         if encoder_factory is not None:                     # registered here to keep the reference's module order
             self.encoder = encoder_factory(hp)
-        self.embedding = nn.Embedding(hp.vocab_size, hp.embed_dim, max_norm=None, padding_idx=self.pad_idx)
+        self.embedding = nn.Embedding(hp.vocab_size, hp.embed_dim, max_norm=getattr(hp, "embed_norm", None), padding_idx=self.pad_idx)
         self.embedding_dropout = nn.Dropout(p=hp.embedding_dropout)
         self.init_lstm = InitLSTM(hp, bias=True)
         self.lstm = nn.LSTM(input_size=hp.embed_dim + hp.encoder_dim, hidden_size=hp.decoder_dim, num_layers=hp.decoder_layers, bias=True)
@@ -258,7 +256,8 @@ class SATDecoder(nn.Module):
         caps2 = caps.reshape(B * R, T)
         caps_i32 = caps2.to(device=ann_bld.device, dtype=torch.int32).contiguous()
         logits_packed, alphas = Dk.DecoderTrainFn.apply(ann_bld, caps_i32, plan, teacher, bool(self.hp.deep_output), self.pad_idx, R,
-                                                        int(getattr(self, "sat_precision", "fp32") == "bf16"), *self.param_list())
+                                                        int(getattr(self, "sat_precision", "fp32") == "bf16"), getattr(self.hp, "embed_norm", None) or 0.0,
+                                                        *self.param_list())
         targets_packed = plan.pack(caps2[:, 1:].to(ann_bld.device).unsqueeze(-1)).squeeze(-1)
         if not with_loss:
             return dict(logits_packed=logits_packed, targets_packed=targets_packed, alphas=alphas, plan=plan)

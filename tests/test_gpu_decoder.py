@@ -37,10 +37,11 @@ def hp_from_golden(g, sd):
     return O.default_hparams(vocab_size=V, embed_dim=m, decoder_dim=sd["lstm.weight_hh_l0"].shape[1],
                              encoder_dim=sd["attention.encoder_att.weight"].shape[1], attention_dim=sd["attention.encoder_att.weight"].shape[0],
                              deep_output=bool(g["hp_deep_output"]), weight_tying=bool(g["hp_weight_tying"]),
-                             label_smoothing=float(g["hp_label_smoothing"]), att_gamma=float(g["hp_att_gamma"]))
+                             label_smoothing=float(g["hp_label_smoothing"]), att_gamma=float(g["hp_att_gamma"]),
+                             embed_norm=(None if float(g["hp_embed_norm"]) < 0 else float(g["hp_embed_norm"])))
 
 
-GOLDEN_TAGS = ["tf1", "tf0", "tf05", "smooth", "shallow", "tied", "gamma"]   # layers2 / embnorm: not built on the HIP path this round
+GOLDEN_TAGS = ["tf1", "tf0", "tf05", "smooth", "shallow", "tied", "gamma", "embnorm"]   # layers2: not built on the HIP path this round
 
 
 @pytest.mark.parametrize("tag", GOLDEN_TAGS)
@@ -71,6 +72,14 @@ def test_golden_train_batch_and_grads(M, golden_dir, tag):
     for k in g.files:
         if k.startswith("g."):
             close(params[k[2:]].grad, g[k], 2e-4, k)
+    if hp.embed_norm is not None:                # max_norm renormalised the looked-up rows in place, like nn.Embedding
+        from oracle import sat_oracle as O
+        w = torch.from_numpy(g["sd.embedding.weight"].copy())
+        caps2 = torch.from_numpy(g["caps"]).reshape(-1, g["caps"].shape[-1]); lens = torch.from_numpy(g["lengths"]).reshape(-1)
+        fed = torch.cat([caps2[i, :int(lens[i])] for i in range(caps2.shape[0])])       # tokens actually looked up
+        O.embed({"embedding.weight": w}, fed, hp.embed_norm)                            # the oracle renormalises w in place
+        close(dec.embedding.weight, w, 1e-6, "renormalised embedding table")
+        assert float(dec.embedding.weight.detach().cpu().norm(dim=1)[fed.unique()].max()) <= hp.embed_norm * (1 + 1e-5)
     # doubly-stochastic term: report the distance to the reference bit pattern
     bits = np.float32(res["ds"].item()).view(np.uint32)
     print("ds ulps vs reference:", abs(int(bits) - int(g["ds_bits"])))
@@ -130,6 +139,14 @@ def test_c2_shapes_properties(M):
     for k, p in dec.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), k
     assert dec.embedding.weight.grad[0].abs().max().item() == 0.0    # padding_idx row gets no gradient
+    # no atomics anywhere in the step: a second run reproduces every gradient bit for bit
+    g1 = {k: p.grad.clone() for k, p in dec.named_parameters()}
+    dec.zero_grad(set_to_none=True)
+    res_b = dec.train_decode(ann, caps.cuda(), lengths, 1.0)
+    (res_b["ce"] + res_b["ds"]).backward()
+    for k, p in dec.named_parameters():
+        assert torch.equal(p.grad, g1[k]), "gradient of %s is not reproducible" % k
+    assert torch.equal(res_b["logits_packed"], res["logits_packed"])
     # captions of one image are exchangeable: permuting them inside every image permutes the outputs
     perm = torch.tensor([2, 0, 4, 1, 3])
     res2 = dec.train_decode(ann.detach(), caps[:, perm].cuda(), lengths[:, perm], 1.0)
