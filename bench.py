@@ -193,8 +193,14 @@ def main():
         if dom:
             tf = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
             peak = PEAK["bf16"] if "bf16" in dom["name"] else PEAK["f32"]
+            traffic = None      # HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/pmc_aggregate.py), same workload only
+            pmc = os.path.join(ROOT, "profiles", "r01_bf16_bench_c2_pmc_hbm.json")
+            if args.config == "c2" and args.precision == "bf16" and not args.batch and not args.ragged and os.path.exists(pmc):
+                for row in json.load(open(pmc)):
+                    if row["family"] == dom["name"]:
+                        traffic = round(row["hbm_bytes_per_launch"])
             roof = {"bound": "mfma", "kernel": dom["name"], "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(tf / peak, 4), "traffic": None,
+                    "frac": round(tf / peak, 4), "traffic": traffic,
                     "avg_launch_us": round(dom["total_ms"] * 1e3 / dom["launches"], 2), "launches_per_step": dom["launches"] // prof_steps,
                     "flops_per_launch": dom["flops"] / dom["launches"],
                     "measured_on": "%d instrumented steps right after the timed region (events add launch overhead)" % prof_steps,

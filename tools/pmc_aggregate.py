@@ -1,0 +1,41 @@
+"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs, MI355X_MICROARCH.md HBM section) into
+per-kernel HBM bytes per launch.  FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE tallies 64 B per 128-B
+request for wide coalesced streaming reads, so the read side is doubled.
+
+    python tools/pmc_aggregate.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_bf16_bench_c2_pmc_hbm.json
+"""
+import collections, csv, glob, json, re, sys
+
+MODE = {("0", "0"): "nt", ("0", "1"): "nn", ("1", "1"): "tn", ("2", "0"): "conv_fwd", ("3", "3"): "conv_dgrad", ("1", "2"): "conv_wgrad"}
+
+
+def family(name):
+    m = re.search(r"gemm_bf16_kernelILi(\d+)ELi(\d+)ELi(\d)ELi(\d)E(DF16b|f)", name) or \
+        re.search(r"gemm_bf16_kernel<(\d+), (\d+), (\d), (\d), (float|__bf16)", name)
+    if m:
+        return "gemm_bf16_%s_%sx%s_%s" % (MODE.get((m.group(3), m.group(4)), "?"), m.group(1), m.group(2), "b" if m.group(5) in ("DF16b", "__bf16") else "f")
+    m = re.search(r"gemm_f32_kernel<(\d+), (\d+), (\d), (\d)>", name)
+    if m:
+        return "gemm_f32_%s_%sx%s" % (MODE.get((m.group(3), m.group(4)), "?"), m.group(1), m.group(2))
+    return name.split("(")[0][:80]
+
+
+def agg(d):
+    out = collections.defaultdict(lambda: [0, 0.0, 0.0])
+    for r in csv.DictReader(open(glob.glob(d + "/*/*counter_collection.csv")[0])):
+        e = out[family(r["Kernel_Name"])]
+        e[0] += 1; e[1] += float(r["Counter_Value"]); e[2] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    return out
+
+
+if __name__ == "__main__":
+    f, w = agg(sys.argv[1]), agg(sys.argv[2])
+    rows = []
+    for k, (n, fs, t) in f.items():
+        ws = w.get(k, [0, 0.0, 0.0])[1]
+        rows.append(dict(family=k, launches=n, read_bytes_per_launch=2 * fs * 1024 / n, write_bytes_per_launch=ws * 1024 / n,
+                         hbm_bytes_per_launch=(2 * fs + ws) * 1024 / n, avg_us_under_pmc=t / n / 1e3))
+    rows.sort(key=lambda r: -r["avg_us_under_pmc"] * r["launches"])
+    json.dump(rows, open(sys.argv[3], "w"), indent=1)
+    for r in rows[:10]:
+        print("%-40s n=%4d  %8.1f MB/launch  %7.1f us" % (r["family"], r["launches"], r["hbm_bytes_per_launch"] / 1e6, r["avg_us_under_pmc"]))
