@@ -139,6 +139,10 @@ def conv_wgrad(dy, x, w, stride, pad):
     return dw.permute(0, 3, 1, 2)                                             # (K,C,R,S) view, channels_last memory
 
 
+_tracked = []      # num_batches_tracked buffers touched by the running whole-encoder forward (bumped once, together)
+_defer = [False]
+
+
 def bn_fwd(x, bn, residual=None, relu=True, training=True):
     lib = L.lib()
     Cc = x.shape[-1]; rows = x.numel() // Cc
@@ -151,7 +155,10 @@ def bn_fwd(x, bn, residual=None, relu=True, training=True):
         L.check(lib.sat_bn_train_fwd_t(dt, L.ptr(x), rows, Cc, L.ptr(bn.weight), L.ptr(bn.bias), float(bn.eps), mom, L.ptr(bn.running_mean),
                                        L.ptr(bn.running_var), L.ptr(mean), L.ptr(invstd), L.ptr(residual), int(relu), L.ptr(y), L.ptr(scratch),
                                        L.stream_ptr()), "sat_bn_train_fwd")
-        bn.num_batches_tracked += 1
+        if _defer[0]:
+            _tracked.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked += 1
         return y, (mean, invstd)
     L.check(lib.sat_bn_eval_fwd_t(dt, L.ptr(x), rows, Cc, L.ptr(bn.running_mean), L.ptr(bn.running_var), float(bn.eps), L.ptr(bn.weight),
                                   L.ptr(bn.bias), L.ptr(residual), int(relu), L.ptr(y), L.stream_ptr()), "sat_bn_eval_fwd")
@@ -243,12 +250,20 @@ class EncoderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, img, enc, *params):
+        try:
+            return EncoderFn._forward(ctx, img, enc, *params)
+        finally:
+            _defer[0] = False
+
+    @staticmethod
+    def _forward(ctx, img, enc, *params):
         lib = L.lib()
         L.require_gpu(img, *params)
         if img.dim() != 4 or img.shape[1] != 3 or img.dtype != torch.float32:
             raise ValueError("encoder input must be (B,3,H,W) fp32 in [0,1]")
         img = img.contiguous()
         training = enc.training
+        _defer[0] = True; del _tracked[:]
         bf = enc.precision == "bf16"
         adt = BF16 if bf else torch.float32
         N, _, H, W = img.shape
@@ -256,7 +271,7 @@ class EncoderFn(torch.autograd.Function):
         t = {}
         wcopy = {}
 
-        def Wt(p):                       # the tensor the kernels read for filter parameter p
+        def Wt(p):                       # the tensor the kernels read for filter parameter p (bf16 copy in bf16 mode)
             if not bf:
                 return p
             c = wcopy.get(p)
@@ -309,6 +324,10 @@ class EncoderFn(torch.autograd.Function):
             y = torch.empty(Nn, enc.out_size, enc.out_size, Cc, dtype=torch.float32, device=img.device)
             L.check(lib.sat_resize_fwd(L.ptr(x), L.ptr(y), Nn, Hh, Ww, Cc, enc.out_size, enc.out_size, st), "sat_resize_fwd")
             x = y
+        _defer[0] = False
+        if _tracked:
+            torch._foreach_add_(_tracked, 1)
+            del _tracked[:]
         ctx.t, ctx.recs, ctx.enc, ctx.Wt, ctx.bf = t, recs, enc, Wt, bf
         ctx.params = params
         return x.permute(0, 3, 1, 2)            # (B, D, h, w) view over NHWC memory
