@@ -27,18 +27,36 @@ class GradSync:
         self._pending = [0] * len(self.buckets)
         self._inflight = []
         self._handles = []
+        self._early = set()                # buckets already launched from inside the encoder backward this step
         if self.world > 1:
             for bi, bucket in enumerate(self.buckets):
                 for p in bucket:
                     self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
+            enc = getattr(model, "encoder", None)
+            if enc is not None and hasattr(enc, "precision"):          # HipEncoder: stage-by-stage notification
+                enc.grad_ready = self.encoder_stage_ready
 
     def _make_hook(self, bi):
         def hook(param):
             self._pending[bi] += 1
             if self._pending[bi] == len(self.buckets[bi]):
                 self._pending[bi] = 0
-                self._launch(bi)
+                if bi not in self._early:
+                    self._launch(bi)
         return hook
+
+    def encoder_stage_ready(self, grads):
+        """Called from the encoder backward with {parameter: gradient} of everything computed so far: buckets that
+        are complete start their all-reduce now, overlapping the rest of the conv-stack backward."""
+        if self.world == 1:
+            return
+        for bi, bucket in enumerate(self.buckets):
+            if bi in self._early or not bucket or any(p not in grads for p in bucket):
+                continue
+            flat = torch.cat([grads[p].reshape(-1) for p in bucket])
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+            self._inflight.append((work, flat, list(bucket)))
+            self._early.add(bi)
 
     def _launch(self, bi):
         params = [p for p in self.buckets[bi] if p.grad is not None]
@@ -55,7 +73,9 @@ class GradSync:
         for bi, n in enumerate(self._pending):       # buckets whose parameters did not all receive a gradient
             if n:
                 self._pending[bi] = 0
-                self._launch(bi)
+                if bi not in self._early:
+                    self._launch(bi)
+        self._early = set()
         for work, flat, params in self._inflight:
             work.wait()
             flat.div_(self.world)

@@ -41,6 +41,18 @@ def _worker(rank, world, port, out):
         model.zero_grad(set_to_none=True)
         model(idx[sl], x[sl]).backward()
         sync.finish()
+    # early path: the encoder backward announces a finished stage before autograd has accumulated anything
+    ref_grads = {k: p.grad.clone() for k, p in model.named_parameters()}
+    model.zero_grad(set_to_none=True)
+    loss = model(idx[sl], x[sl])
+    stage = sync.buckets[1]                              # the "projection + layer4" bucket
+    sync.encoder_stage_ready(dict(zip(stage, torch.autograd.grad(loss, stage, retain_graph=True))))
+    assert 1 in sync._early
+    loss.backward()
+    sync.finish()
+    for k, p in model.named_parameters():
+        assert torch.allclose(p.grad, ref_grads[k], atol=1e-7, rtol=1e-6), k
+    assert not sync._early and not sync._inflight
     torch.save({k: p.grad.clone() for k, p in model.named_parameters()}, out % rank)
     torch.save({k: p.detach().clone() for k, p in model.named_parameters()}, (out % rank) + ".w")
     dist.destroy_process_group()
