@@ -113,10 +113,10 @@ int launch_attention_fwd(hipStream_t st, const float* ann, const float* U, const
     dim3 grid(B, cdiv(D, dchunk));
     if (vec) {
         SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_fwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(attention_fwd_kernel<4>, grid, dim3(ATT_THREADS), lds, st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, R, L, D, A, dchunk);
+        hipLaunchKernelGGL(attention_fwd_kernel<4>, grid, dim3(ATTF_THREADS), lds, st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, R, L, D, A, dchunk);
     } else {
         SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_fwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(attention_fwd_kernel<1>, grid, dim3(ATT_THREADS), lds, st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, R, L, D, A, dchunk);
+        hipLaunchKernelGGL(attention_fwd_kernel<1>, grid, dim3(ATTF_THREADS), lds, st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, R, L, D, A, dchunk);
     }
     return launch_ok("attention_fwd");
 }

@@ -108,8 +108,10 @@ __global__ void init_expand_bwd_kernel(const float* __restrict__ dh0, const floa
 // grid = (B, D-chunks); block = 256.  Every block recomputes the (cheap) scores + softmax of its image's
 // R caption rows, then accumulates its D-chunk of the context while reading the annotation tile ONCE
 // for all R rows.  dyn LDS: [RMAX*L scores/alpha][RMAX*A q][A w][part: 4*RMAX*chunk]
+constexpr int ATTF_WAVES = 16;                 // forward: 16 waves share the tanh-heavy score phase of one image
+constexpr int ATTF_THREADS = ATTF_WAVES * 64;
 template <int VW>
-__global__ __launch_bounds__(ATT_THREADS) void attention_fwd_kernel(
+__global__ __launch_bounds__(ATTF_THREADS) void attention_fwd_kernel(
     const float* __restrict__ ann, const float* __restrict__ U, const float* __restrict__ hc, int hc_ld,
     const float* __restrict__ wf, const int* __restrict__ lengths, int step,
     float* __restrict__ alphas, int T1, float* __restrict__ Z, float* __restrict__ XZ,
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_fwd_kernel(
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int d0 = blockIdx.y * dchunk, dn = min(dchunk, D - d0);
     const float scale = 1.0f / sqrtf((float)L);
-    for (int k = tid; k < A; k += ATT_THREADS) s_w[k] = wf[k];
+    for (int k = tid; k < A; k += ATTF_THREADS) s_w[k] = wf[k];
 
     for (int r0 = 0; r0 < R; r0 += ATT_RMAX) {
         const int rn = min(ATT_RMAX, R - r0);
@@ -132,10 +134,10 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_fwd_kernel(
         const bool any = lmask != 0;
         __syncthreads();
         if (any) {
-            for (int e = tid; e < rn * A; e += ATT_THREADS) { int r = e / A, k = e - r * A; s_q[r * A + k] = hc[(long)(i0 + r) * hc_ld + k]; }
+            for (int e = tid; e < rn * A; e += ATTF_THREADS) { int r = e / A, k = e - r * A; s_q[r * A + k] = hc[(long)(i0 + r) * hc_ld + k]; }
             __syncthreads();
             // ---- scores: wave per location, lanes over the attention dim
-            for (int l = wave; l < L; l += 4) {
+            for (int l = wave; l < L; l += ATTF_WAVES) {
                 float part[ATT_RMAX];
 #pragma unroll
                 for (int r = 0; r < ATT_RMAX; ++r) part[r] = 0.f;
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_fwd_kernel(
             }
             __syncthreads();
             // ---- softmax over L: wave per row
-            for (int r = wave; r < rn; r += 4) {
+            for (int r = wave; r < rn; r += ATTF_WAVES) {
                 if (!((lmask >> r) & 1u)) continue;       // wave-uniform
                 float mx = -INFINITY;
                 for (int l = lane; l < L; l += 64) mx = fmaxf(mx, s_sc[r * L + l]);
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_fwd_kernel(
         }
         // ---- alphas out (only the first D-chunk block writes); dead rows are written as zeros
         if (blockIdx.y == 0) {
-            for (int e = tid; e < rn * L; e += ATT_THREADS) {
+            for (int e = tid; e < rn * L; e += ATTF_THREADS) {
                 int r = e / L, l = e - r * L;
                 alphas[((long)(i0 + r) * T1 + step) * L + l] = ((lmask >> r) & 1u) ? s_sc[r * L + l] : 0.f;
             }
@@ -174,7 +176,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_fwd_kernel(
         const int nv = dn / VW;                         // vectors in the chunk
         const int groups = max(1, min(4, ATT_THREADS / max(nv, 1)));
         const int gsz = ATT_THREADS / groups;           // threads per group
-        const int g = tid / gsz, tv = tid - g * gsz;
+        const bool ctx_thread = tid < ATT_THREADS;       // the context phase runs on the first 4 waves; all waves do the scores
+        const int g = ctx_thread ? tid / gsz : groups, tv = tid - (ctx_thread ? g : 0) * gsz;
         float acc[ATT_RMAX][VW];
         if (any) {
             for (int v0 = 0; v0 < nv; v0 += gsz) {
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_fwd_kernel(
                 }
             }
         } else {
-            for (int e = tid; e < rn * dn; e += ATT_THREADS) { int r = e / dn, d = d0 + e - r * dn; Z[(long)(i0 + r) * D + d] = 0.f; XZ[(long)(i0 + r) * D + d] = 0.f; }
+            for (int e = tid; e < rn * dn; e += ATTF_THREADS) { int r = e / dn, d = d0 + e - r * dn; Z[(long)(i0 + r) * D + d] = 0.f; XZ[(long)(i0 + r) * D + d] = 0.f; }
         }
     }
 }
