@@ -395,6 +395,23 @@ static int conv_dgrad_any(const void* dy, const void* w, void* dx, const sat_con
     a.accumulate = accumulate; a.C = dx; a.ldc = g.C; a.g = g;
     if (g.R == 1 && g.S == 1 && g.stride == 1 && g.pad == 0) {
         a.M = g.N * g.H * g.W; a.N = g.C; a.K = g.K; a.A = dy; a.lda = g.K; a.amode = A_ROW; a.B = w; a.ldb = g.C; a.bmode = B_KMAJOR;
+    } else if (bf16 && g.stride == 2) {
+        // stride 2: an input pixel only sees the taps whose parity matches its own, so run one implicit GEMM per
+        // (h % 2, w % 2) class over exactly those taps (9 tap-products for a 3x3 instead of 36; 1 instead of 4 for a 1x1)
+        a.A = dy; a.amode = A_CONV_DGRAD; a.B = w; a.bmode = B_CONV_DGRAD_W; a.N = g.C;
+        for (int ph = 0; ph < 2; ++ph)
+            for (int pw = 0; pw < 2; ++pw) {
+                ConvGeom c = g; c.cls = 1; c.ph = ph; c.pw = pw;
+                c.Hc = (g.H - ph + 1) / 2; c.Wc = (g.W - pw + 1) / 2;
+                c.r0 = (ph + g.pad) & 1; c.s0 = (pw + g.pad) & 1;
+                c.rc = c.r0 < g.R ? (g.R - c.r0 + 1) / 2 : 0; c.sc = c.s0 < g.S ? (g.S - c.s0 + 1) / 2 : 0;
+                if (c.Hc <= 0 || c.Wc <= 0) continue;
+                a.g = c; a.M = g.N * c.Hc * c.Wc; a.K = c.rc * c.sc * g.K;
+                if (a.K == 0 && accumulate) continue;                    // nothing to add for this class
+                if (c.sc == 0) a.g.sc = 1;                               // K == 0: the class only receives zeros
+                SAT_TRY(launch_gemm(a, (hipStream_t)stream));
+            }
+        return SAT_OK;
     } else {
         a.M = g.N * g.H * g.W; a.N = g.C; a.K = g.R * g.S * g.K; a.A = dy; a.amode = A_CONV_DGRAD; a.B = w; a.bmode = B_CONV_DGRAD_W;
     }

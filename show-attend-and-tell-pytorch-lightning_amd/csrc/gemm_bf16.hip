@@ -56,9 +56,17 @@ __device__ __forceinline__ float ep_value(const BArgs& a, int row, int col, floa
     return v;
 }
 
+// parity-class data gradient: GEMM row (n, h', w') -> NHWC pixel (n, 2h'+ph, 2w'+pw)
+__device__ __forceinline__ long class_row(const BArgs& a, int row) {
+    const ConvGeom& g = a.g;
+    int hw = g.Hc * g.Wc; int n = row / hw; int r = row - n * hw; int hc = r / g.Wc, wc = r - hc * g.Wc;
+    return ((long)n * g.H + 2 * hc + g.ph) * g.W + 2 * wc + g.pw;
+}
+
 template <typename TC>
 __device__ __forceinline__ void put(const BArgs& a, int row, int col, float v) {
     long orow = row;
+    if (a.g.cls) orow = class_row(a, row);
     if (a.c_rows) { int r = a.c_rows[row]; if (r < 0) return; orow = r; }
     TC* p = reinterpret_cast<TC*>(a.C) + orow * a.ldc + col;
     if (a.accumulate) v += (float)*p;
@@ -82,7 +90,9 @@ __device__ __forceinline__ void row_setup(const BArgs& a, int m, RowCtx& c) {
         c.y0 = p * g.stride - g.pad; c.x0 = q * g.stride - g.pad;
     } else {
         const ConvGeom& g = a.g;
-        int hw = g.H * g.W; c.n = m / hw; int r = m - c.n * hw; int h = r / g.W, w = r - h * g.W;
+        int h, w;
+        if (g.cls) { int hw = g.Hc * g.Wc; c.n = m / hw; int r = m - c.n * hw; int hc = r / g.Wc; h = 2 * hc + g.ph; w = 2 * (r - hc * g.Wc) + g.pw; }
+        else { int hw = g.H * g.W; c.n = m / hw; int r = m - c.n * hw; h = r / g.W; w = r - h * g.W; }
         c.y0 = h + g.pad; c.x0 = w + g.pad;
     }
 }
@@ -97,7 +107,11 @@ __device__ __forceinline__ KEnt k_decode(const BArgs& a, int k, int kend) {
     if (k >= kend) return t;
     const ConvGeom& g = a.g;
     if (AM == A_CONV_FWD) { int rs = k / g.C; t.e2 = k - rs * g.C; t.e0 = rs / g.S; t.e1 = rs - t.e0 * g.S; }
-    else if (AM == A_CONV_DGRAD) { int rs = k / g.K; t.e2 = k - rs * g.K; t.e0 = rs / g.S; t.e1 = rs - t.e0 * g.S; }
+    else if (AM == A_CONV_DGRAD) {
+        int rs = k / g.K; t.e2 = k - rs * g.K;
+        if (g.cls) { int ri = rs / g.sc; t.e0 = g.r0 + 2 * ri; t.e1 = g.s0 + 2 * (rs - ri * g.sc); }     // taps of this parity class only
+        else { t.e0 = rs / g.S; t.e1 = rs - t.e0 * g.S; }
+    }
     else if (BMo == B_CONV_WGRAD) {
         int pq = g.P * g.Q; int img = k / pq; int rem = k - img * pq; int p = rem / g.Q, q = rem - p * g.Q;
         t.e2 = img; t.e0 = p * g.stride - g.pad; t.e1 = q * g.stride - g.pad;
@@ -317,7 +331,8 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(BArgs a) {
             int row = bm + lr, col = bn + lc;
             if (row < a.M && col < a.N) {
                 bf16x8 o = *reinterpret_cast<const bf16x8*>(cs + lr * LDC + lc);
-                __bf16* dst = reinterpret_cast<__bf16*>(a.C) + (long)row * a.ldc + col;
+                const long orow = a.g.cls ? class_row(a, row) : (long)row;
+                __bf16* dst = reinterpret_cast<__bf16*>(a.C) + orow * a.ldc + col;
                 if (a.accumulate) {
                     bf16x8 old = *reinterpret_cast<const bf16x8*>(dst);
 #pragma unroll

@@ -236,8 +236,9 @@ def _block_bwd(r, dout, grads, need_dx, W=None):
         grads[blk.downsample[0].weight] = conv_wgrad(dxd, r.x, blk.downsample[0].weight, blk.stride, 0)
         if not need_dx:
             return None
-        dx = conv_dgrad(dxd, W(blk.downsample[0].weight), r.x.shape, blk.stride, 0)
-        return conv_dgrad(dx1, W(first_w), r.x.shape, first_stride, first_pad, out=dx, accumulate=True)
+        dx = conv_dgrad(dx1, W(first_w), r.x.shape, first_stride, first_pad)
+        # the strided 1x1 shortcut only reaches the even pixels: accumulate it on top (the other parity classes are skipped)
+        return conv_dgrad(dxd, W(blk.downsample[0].weight), r.x.shape, blk.stride, 0, out=dx, accumulate=True)
     if not need_dx:
         return None
     return conv_dgrad(dx1, W(first_w), r.x.shape, first_stride, first_pad, out=g, accumulate=True)   # identity path + conv path
