@@ -312,16 +312,28 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(BArgs a) {
         static_assert(BM * LDC <= 2 * STAGE, "C tile must fit the staging buffers");
         __bf16* cs = smem;
         __syncthreads();
+        // Neighbouring lanes hold neighbouring columns.  Registers r, r+1 are rows R, R+1: the even lane of a pair
+        // collects both columns of row R, the odd lane both columns of row R+1 (one DPP swap), so every lane writes
+        // one packed 4-byte LDS word per register pair instead of two 2-byte ones.
+        const bool odd = lane & 1;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int lr = wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, lc = wn + j * 32 + li;
-                    float v = acc[i][j][r];
-                    if (bm + lr < a.M && bn + lc < a.N) v = ep_value(a, bm + lr, bn + lc, v);
-                    cs[lr * LDC + lc] = (__bf16)v;
+                for (int r = 0; r < 16; r += 2) {
+                    const int lr0 = wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, lc = wn + j * 32 + li;
+                    float v0 = acc[i][j][r], v1 = acc[i][j][r + 1];
+                    if (a.epi != EPI_NONE && bn + lc < a.N) {
+                        if (bm + lr0 < a.M) v0 = ep_value(a, bm + lr0, bn + lc, v0);
+                        if (bm + lr0 + 1 < a.M) v1 = ep_value(a, bm + lr0 + 1, bn + lc, v1);
+                    }
+                    const float give = odd ? v0 : v1;
+                    const float got = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(give), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true));
+                    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                    bf16x2 pk;
+                    if (odd) { pk[0] = (__bf16)got; pk[1] = (__bf16)v1; } else { pk[0] = (__bf16)v0; pk[1] = (__bf16)got; }
+                    *reinterpret_cast<bf16x2*>(cs + (lr0 + (odd ? 1 : 0)) * LDC + (lc & ~1)) = pk;
                 }
         __syncthreads();
         constexpr int VPR = BN / 8;
