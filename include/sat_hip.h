@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SAT_HIP_ABI_VERSION 3
+#define SAT_HIP_ABI_VERSION 4
 
 int sat_abi_version(void);
 const char* sat_last_error(void);
@@ -82,6 +82,9 @@ typedef struct sat_decoder_dims {
     int32_t padding_idx;  /* <PAD> id (model.py:162)                               */
     int32_t precision;    /* 0: exact fp32 MFMA (parity mode); 1: bf16 MFMA, fp32 accumulate/state */
     float embed_max_norm; /* nn.Embedding max_norm (model.py:161); <= 0: off.  Renormalises embedding rows IN PLACE */
+    float dropout;        /* nn.Dropout p of InitLSTM / DeepOutput (model.py:74,117) in training mode; 0: off     */
+    float embedding_dropout; /* p of embedding_dropout (model.py:164); 0: off                                    */
+    uint64_t dropout_seed;   /* masks = counter-based hash of (seed, stream, element): same seed for fwd and bwd */
 } sat_decoder_dims;
 
 /* state-dict tensors of the decoder; used for weights and, with the same

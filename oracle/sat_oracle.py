@@ -186,11 +186,14 @@ def trunk_param_count(arch):
 #        SURVEY 8b).  All tensors fp32 CPU.
 # --------------------------------------------------------------------------
 
-def init_state(sd, ann, layers, n):
+def init_state(sd, ann, layers, n, mean_mask=None):
     """InitLSTM.forward (model.py:76-81).  ann (N,D,h,w) -> h0,c0 (layers,N,n).
     The ``reshape`` is a raw reinterpretation of the (N, 2*layers*n) buffer --
-    no permute -- so rows mix across the batch."""
+    no permute -- so rows mix across the batch.  ``mean_mask`` (N,D) stands
+    for ``self.dropout`` (model.py:78): kept elements carry 1/(1-p)."""
     mean = ann.mean((2, 3))
+    if mean_mask is not None:
+        mean = mean * mean_mask
     v = F.linear(F.linear(mean, sd["init_lstm.factorize.weight"], sd["init_lstm.factorize.bias"]),
                  sd["init_lstm.init.weight"], sd["init_lstm.init.bias"])
     flat = v.reshape(2 * layers, mean.shape[0], n)
@@ -253,13 +256,16 @@ def lstm_step_math(sd, x, h, c, layers):
     return torch.stack(hs), torch.stack(cs)
 
 
-def deep_output(sd, y, h, z, deep=True):
+def deep_output(sd, y, h, z, deep=True, x_mask=None):
     """DeepOutput.forward (model.py:125-131): un-gated context z and the *new*
-    hidden state (F8).  Tied weights simply alias output.output.weight."""
+    hidden state (F8).  Tied weights simply alias output.output.weight.
+    ``x_mask`` stands for ``self.dropout`` (model.py:130)."""
     if deep:
         x = torch.tanh(y + F.linear(h, sd["output.hidden.weight"]) + F.linear(z, sd["output.context.weight"]))
     else:
         x = F.linear(h, sd["output.hidden.weight"])
+    if x_mask is not None:
+        x = x * x_mask
     return F.linear(x, sd["output.output.weight"], sd.get("output.output.bias"))
 
 
@@ -267,7 +273,7 @@ def deep_output(sd, y, h, z, deep=True):
 # a8. train_batch (model.py:474-557)
 # --------------------------------------------------------------------------
 
-def decode_train(sd, hp, ann_img, caps, lengths, epsilon=0, draw=None, lstm_fn=lstm_step):
+def decode_train(sd, hp, ann_img, caps, lengths, epsilon=0, draw=None, lstm_fn=lstm_step, masks=None):
     """Decoder half of train_batch: everything after ``self.encoder(img)``.
 
     ann_img (B,D,h,w); caps (B,R,T) int64; lengths (B,R) int64.
@@ -282,7 +288,9 @@ def decode_train(sd, hp, ann_img, caps, lengths, epsilon=0, draw=None, lstm_fn=l
     _, _, Hh, Ww = ann.shape
     caps = caps.reshape(-1, caps.size(2))
     lens = lengths.reshape(-1)
-    h, c = init_state(sd, ann, layers, n)                     # model.py:498
+    # masks (dropout restated with explicit masks): init (N,D), emb (T-1,N,m), out (T-1,N,m); None = no dropout
+    masks = masks or {}
+    h, c = init_state(sd, ann, layers, n, masks.get("init"))   # model.py:498
     h, c = h.clone(), c.clone()
     N, T = caps.shape
     logits = torch.zeros(N, T - 1, V)
@@ -296,6 +304,8 @@ def decode_train(sd, hp, ann_img, caps, lengths, epsilon=0, draw=None, lstm_fn=l
         else:
             tok = torch.argmax(logits[live, step - 1, :], dim=1)
         y = embed(sd, tok, getattr(hp, "embed_norm", None))
+        if masks.get("emb") is not None:
+            y = y * masks["emb"][step][live]                  # embedding_dropout (model.py:526)
         z, alpha = soft_attention(sd, ann[live], h[-1, live])
         alphas[live, step, :] = alpha.reshape(int(live.sum()), Hh * Ww)
         gate = beta_gate(sd, h[-1, live])
@@ -304,7 +314,8 @@ def decode_train(sd, hp, ann_img, caps, lengths, epsilon=0, draw=None, lstm_fn=l
         h = h.clone(); c = c.clone()
         h[:, live] = hn
         c[:, live] = cn
-        logits[live, step, :] = deep_output(sd, y, h[-1, live], z, hp.deep_output).float()
+        xm = masks["out"][step][live] if masks.get("out") is not None else None
+        logits[live, step, :] = deep_output(sd, y, h[-1, live], z, hp.deep_output, xm).float()
     return dict(logits=logits, alphas=alphas, targets=caps[:, 1:], lengths=lens)
 
 
@@ -334,9 +345,9 @@ def doubly_stochastic(alphas, gamma):
     return gamma * ((1 - alphas.sum(dim=1)) ** 2).mean()
 
 
-def training_loss(sd, hp, ann_img, caps, lengths, epsilon=0, draw=None):
+def training_loss(sd, hp, ann_img, caps, lengths, epsilon=0, draw=None, masks=None):
     """model.py:589-597 without the logging: returns (loss, parts)."""
-    out = decode_train(sd, hp, ann_img, caps, lengths, epsilon, draw)
+    out = decode_train(sd, hp, ann_img, caps, lengths, epsilon, draw, masks=masks)
     lp, bs = pack_time_major(out["logits"], out["lengths"])
     tp, _ = pack_time_major(out["targets"], out["lengths"])
     ce = label_smoothing_ce(lp, tp, hp.label_smoothing)

@@ -24,7 +24,7 @@ class GemmDesc(C.Structure):
 
 class DecoderDims(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("B", "R", "T", "L", "D", "A", "m", "n", "V", "P", "deep_output", "padding_idx", "precision")] + \
-               [("embed_max_norm", C.c_float)]
+               [("embed_max_norm", C.c_float), ("dropout", C.c_float), ("embedding_dropout", C.c_float), ("dropout_seed", C.c_uint64)]
 
 
 PARAM_FIELDS = ("embedding", "init_f_w", "init_f_b", "init_i_w", "init_i_b", "w_ih", "w_hh", "b_ih", "b_hh",
@@ -156,8 +156,8 @@ def lib():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(handle, name)          # AttributeError if the export is missing
             fn.restype, fn.argtypes = res, args
-        if handle.sat_abi_version() != 3:
-            raise SatHipError("libsat_hip.so ABI version %d != 3 (rebuild: make -C csrc)" % handle.sat_abi_version())
+        if handle.sat_abi_version() != 4:
+            raise SatHipError("libsat_hip.so ABI version %d != 4 (rebuild: make -C csrc)" % handle.sat_abi_version())
         _lib = handle
     return _lib
 

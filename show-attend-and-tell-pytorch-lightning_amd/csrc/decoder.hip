@@ -13,6 +13,7 @@ struct Ws {
     size_t total = 0;
     // saved by forward
     float *U, *mean, *f, *init_img, *H_all, *C_all, *HC, *Z, *XZ, *Y, *GY, *Uact, *Wcat, *bcat;
+    float *Udrop, *mean_rows, *f_rows, *init_rows, *df_rows;     // only carved when dropout > 0
     int* Tok; int* flags;
     // backward scratch
     float *dA, *dHout, *dZout, *DZ, *DHC, *dXZ, *dHc, *dCc, *dU, *dwf_part, *dY, *colpart, *dinit_img, *df, *dmean, *slab;
@@ -38,6 +39,11 @@ Ws layout(const sat_decoder_dims& d, char* base) {
     w.Wcat = (float*)take((size_t)HCW * d.n);
     w.bcat = (float*)take((size_t)HCW);
     w.Tok = (int*)take((size_t)T1 * N);
+    w.Udrop = w.mean_rows = w.f_rows = w.init_rows = w.df_rows = nullptr;
+    if (d.dropout > 0.f) {
+        w.Udrop = (float*)take((size_t)(d.P > 0 ? d.P : 1) * d.m); w.mean_rows = (float*)take((size_t)N * d.D); w.f_rows = (float*)take((size_t)N * d.m);
+        w.init_rows = (float*)take((size_t)N * 2 * d.n); w.df_rows = (float*)take((size_t)N * d.m);
+    }
     w.flags = (int*)take((size_t)d.V);
     w.dA = (float*)take((size_t)(d.P > 0 ? d.P : 1) * d.m);
     w.dHout = (float*)take((size_t)T1 * N * d.n);
@@ -67,6 +73,7 @@ int check_dims(const sat_decoder_dims* d) {
     SAT_REQUIRE(d->B > 0 && d->R > 0 && d->T >= 2 && d->L > 0 && d->D > 0 && d->A > 0 && d->m > 0 && d->n > 0 && d->V > 0,
                 "decoder: non-positive dimension (B=%d R=%d T=%d L=%d D=%d A=%d m=%d n=%d V=%d)", d->B, d->R, d->T, d->L, d->D, d->A, d->m, d->n, d->V);
     SAT_REQUIRE(d->P >= 0 && (long)d->P <= (long)d->B * d->R * (d->T - 1), "decoder: packed token count %d out of range", d->P);
+    SAT_REQUIRE(d->dropout >= 0.f && d->dropout < 1.f && d->embedding_dropout >= 0.f && d->embedding_dropout < 1.f, "decoder: dropout must lie in [0,1)");
     return SAT_OK;
 }
 
@@ -136,7 +143,15 @@ static int flush_outputs(hipStream_t st, const sat_decoder_dims& d, const sat_de
     } else {
         SAT_TRY(gemm(st, A_ROW, B_ROW, H1, d.n, p.out_hidden, d.n, u, d.m, rows, d.m, d.n, 0, EPI_NONE, nullptr, rows_map));
     }
-    return gemm(st, A_ROW, B_ROW, u, d.m, p.out_w, d.m, logits + (long)p0 * d.V, d.V, rows, d.V, d.m, 0,
+    const float* uin = u;
+    if (d.dropout > 0.f) {                       // DeepOutput.dropout (model.py:130) on the packed rows
+        float* ud = w.Udrop + (long)p0 * d.m;
+        hipLaunchKernelGGL(dropout_rows_kernel, dim3(cdiv((long)rows * d.m, 256)), dim3(256), 0, st, u, ud, (long)rows * d.m, d.m, d.dropout,
+                           (unsigned long long)d.dropout_seed, 2u, (long)p0);
+        SAT_TRY(launch_ok("output dropout"));
+        uin = ud;
+    }
+    return gemm(st, A_ROW, B_ROW, uin, d.m, p.out_w, d.m, logits + (long)p0 * d.V, d.V, rows, d.V, d.m, 0,
                 p.out_b ? EPI_BIAS : EPI_NONE, p.out_b);
 }
 
@@ -165,10 +180,21 @@ int decoder_fwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
     // InitLSTM (model.py:76-81) on the B images, then the raw reshape over the repeated rows (F3)
     hipLaunchKernelGGL(ann_mean_kernel, dim3(d.B), dim3(256), 0, st, b.ann, w.mean, d.L, D);
     SAT_TRY(launch_ok("ann_mean"));
-    SAT_TRY(gemm(st, A_ROW, B_ROW, w.mean, D, p.init_f_w, D, w.f, m, d.B, m, D, 0, EPI_BIAS, p.init_f_b));
-    SAT_TRY(gemm(st, A_ROW, B_ROW, w.f, m, p.init_i_w, m, w.init_img, 2 * n, d.B, 2 * n, m, 0, EPI_BIAS, p.init_i_b));
-    hipLaunchKernelGGL(init_expand_kernel, dim3(cdiv(2L * N * n, 256)), dim3(256), 0, st, w.init_img, w.H_all, w.C_all, N, d.R, n);
-    SAT_TRY(launch_ok("init_expand"));
+    if (d.dropout > 0.f) {
+        // dropout acts on the mean of the repeated annotations: every caption row has its own mask, so run the
+        // two Linears on N rows; the (N, 2n) result IS the (2, N, n) state buffer (raw reshape, F3)
+        hipLaunchKernelGGL(init_mean_rows_kernel, dim3(cdiv((long)N * D, 256)), dim3(256), 0, st, w.mean, w.mean_rows, N, d.R, D, d.dropout, (unsigned long long)d.dropout_seed);
+        SAT_TRY(launch_ok("init_mean_rows"));
+        SAT_TRY(gemm(st, A_ROW, B_ROW, w.mean_rows, D, p.init_f_w, D, w.f_rows, m, N, m, D, 0, EPI_BIAS, p.init_f_b));
+        SAT_TRY(gemm(st, A_ROW, B_ROW, w.f_rows, m, p.init_i_w, m, w.init_rows, 2 * n, N, 2 * n, m, 0, EPI_BIAS, p.init_i_b));
+        SAT_CHECK_HIP(hipMemcpyAsync(w.H_all, w.init_rows, (size_t)N * n * 4, hipMemcpyDeviceToDevice, st));
+        SAT_CHECK_HIP(hipMemcpyAsync(w.C_all, w.init_rows + (long)N * n, (size_t)N * n * 4, hipMemcpyDeviceToDevice, st));
+    } else {
+        SAT_TRY(gemm(st, A_ROW, B_ROW, w.mean, D, p.init_f_w, D, w.f, m, d.B, m, D, 0, EPI_BIAS, p.init_f_b));
+        SAT_TRY(gemm(st, A_ROW, B_ROW, w.f, m, p.init_i_w, m, w.init_img, 2 * n, d.B, 2 * n, m, 0, EPI_BIAS, p.init_i_b));
+        hipLaunchKernelGGL(init_expand_kernel, dim3(cdiv(2L * N * n, 256)), dim3(256), 0, st, w.init_img, w.H_all, w.C_all, N, d.R, n);
+        SAT_TRY(launch_ok("init_expand"));
+    }
 
     // alphas of steps that never run stay zero (model.py:506)
     if (ts < T1) SAT_CHECK_HIP(hipMemsetAsync(alphas, 0, (size_t)N * T1 * d.L * 4, st));
@@ -190,7 +216,7 @@ int decoder_fwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
     if (d.embed_max_norm > 0.f) SAT_CHECK_HIP(hipMemsetAsync(w.flags, 0, (size_t)d.V * 4, st));
     if (ts > 0) {
         SAT_TRY(renorm(w.Tok, ts * N));
-        hipLaunchKernelGGL(gather_rows_kernel, dim3(ts * N), dim3(64), 0, st, p.embedding, w.Tok, w.Y, ts * N, m);
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(ts * N), dim3(64), 0, st, p.embedding, w.Tok, w.Y, ts * N, m, d.embedding_dropout, (unsigned long long)d.dropout_seed, 0L);
         SAT_TRY(launch_ok("embedding gather"));
         SAT_TRY(gemm(st, A_ROW, B_ROW, w.Y, m, p.w_ih, m + D, w.GY, 4 * n, ts * N, 4 * n, m));
     }
@@ -205,7 +231,7 @@ int decoder_fwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
             hipLaunchKernelGGL(argmax_tokens_kernel, dim3(N), dim3(256), 0, st, logits, b.prow + (long)(t - 1) * N, b.lengths, w.Tok + (long)t * N, d.V, t);
             SAT_TRY(launch_ok("argmax_tokens"));
             SAT_TRY(renorm(w.Tok + (long)t * N, N));
-            hipLaunchKernelGGL(gather_rows_kernel, dim3(N), dim3(64), 0, st, p.embedding, w.Tok + (long)t * N, w.Y + (long)t * N * m, N, m);
+            hipLaunchKernelGGL(gather_rows_kernel, dim3(N), dim3(64), 0, st, p.embedding, w.Tok + (long)t * N, w.Y + (long)t * N * m, N, m, d.embedding_dropout, (unsigned long long)d.dropout_seed, (long)t * N);
             SAT_TRY(launch_ok("embedding gather"));
             SAT_TRY(gemm(st, A_ROW, B_ROW, w.Y + (long)t * N * m, m, p.w_ih, m + D, w.GY + (long)t * N * 4 * n, 4 * n, N, 4 * n, m));
         }
@@ -245,7 +271,12 @@ int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
     if (P > 0) {
         SAT_TRY(gemm(st, A_ROW, B_KMAJOR, dlogits, V, p.out_w, m, w.dA, m, P, m, V, 0, d.deep_output ? EPI_MUL_DTANH : EPI_NONE, nullptr,
                      nullptr, nullptr, w.Uact, m));
-        SAT_TRY(gemm(st, A_KMAJOR, B_KMAJOR, dlogits, V, w.Uact, m, g.out_w, m, V, m, P, 0, EPI_NONE, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, slab, se));
+        if (d.dropout > 0.f) {
+            hipLaunchKernelGGL(dropout_rows_kernel, dim3(cdiv((long)P * m, 256)), dim3(256), 0, st, w.dA, w.dA, (long)P * m, m, d.dropout,
+                               (unsigned long long)d.dropout_seed, 2u, 0L);
+            SAT_TRY(launch_ok("output dropout bwd"));
+        }
+        SAT_TRY(gemm(st, A_KMAJOR, B_KMAJOR, dlogits, V, d.dropout > 0.f ? w.Udrop : w.Uact, m, g.out_w, m, V, m, P, 0, EPI_NONE, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, slab, se));
         if (g.out_b) SAT_TRY(colsum(st, w, dlogits, V, P, V, g.out_b));
         SAT_TRY(gemm(st, A_ROW, B_KMAJOR, w.dA, m, p.out_hidden, n, w.dHout, n, P, n, m, 0, EPI_NONE, nullptr, nullptr, b.src_row));
         if (d.deep_output)
@@ -300,6 +331,11 @@ int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
     SAT_TRY(wgrad(dG, HCW, w.XZ, D, g.w_ih + m, m + D, 4 * n, D));
     // embedding: dY = dA (deep output) + dG * W_ih[:, :m], scattered into the table (padding row skipped)
     SAT_TRY(gemm(st, A_ROW, B_KMAJOR, dG, HCW, p.w_ih, m + D, w.dY, m, KR, m, 4 * n, 1));
+    if (d.embedding_dropout > 0.f && KR > 0) {
+        hipLaunchKernelGGL(dropout_rows_kernel, dim3(cdiv((long)KR * m, 256)), dim3(256), 0, st, w.dY, w.dY, (long)KR * m, m, d.embedding_dropout,
+                           (unsigned long long)d.dropout_seed, 1u, 0L);
+        SAT_TRY(launch_ok("embedding dropout bwd"));
+    }
     hipLaunchKernelGGL(embedding_bwd_kernel, dim3(V), dim3(256), 0, st, w.dY, w.Tok, g.embedding, KR, m, d.padding_idx);
     SAT_TRY(launch_ok("embedding_bwd"));
     // attention parameters and the annotation gradient
@@ -310,6 +346,19 @@ int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
                        d.R, N, T1, d.L, D);
     SAT_TRY(launch_ok("dann_from_context"));
     // InitLSTM backward (the raw reshape is a reinterpretation: gradients of the repeated rows add up per image)
+    if (d.dropout > 0.f) {                 // per-caption-row path (see decoder_fwd)
+        SAT_CHECK_HIP(hipMemcpyAsync(w.init_rows, w.dHc, (size_t)N * n * 4, hipMemcpyDeviceToDevice, st));
+        SAT_CHECK_HIP(hipMemcpyAsync(w.init_rows + (long)N * n, w.dCc, (size_t)N * n * 4, hipMemcpyDeviceToDevice, st));
+        SAT_TRY(gemm(st, A_KMAJOR, B_KMAJOR, w.init_rows, 2 * n, w.f_rows, m, g.init_i_w, m, 2 * n, m, N));
+        SAT_TRY(colsum(st, w, w.init_rows, 2 * n, N, 2 * n, g.init_i_b));
+        SAT_TRY(gemm(st, A_ROW, B_KMAJOR, w.init_rows, 2 * n, p.init_i_w, m, w.df_rows, m, N, m, 2 * n));
+        SAT_TRY(gemm(st, A_KMAJOR, B_KMAJOR, w.df_rows, m, w.mean_rows, D, g.init_f_w, D, m, D, N));
+        SAT_TRY(colsum(st, w, w.df_rows, m, N, m, g.init_f_b));
+        SAT_TRY(gemm(st, A_ROW, B_KMAJOR, w.df_rows, m, p.init_f_w, D, w.mean_rows, D, N, D, m));          // d(mean rows), reuses the buffer
+        hipLaunchKernelGGL(init_mean_rows_bwd_kernel, dim3(cdiv((long)d.B * D, 256)), dim3(256), 0, st, w.mean_rows, w.dmean, d.B, d.R, D, d.dropout,
+                           (unsigned long long)d.dropout_seed);
+        SAT_TRY(launch_ok("init_mean_rows_bwd"));
+    } else {
     hipLaunchKernelGGL(init_expand_bwd_kernel, dim3(cdiv((long)d.B * 2 * n, 256)), dim3(256), 0, st, w.dHc, w.dCc, w.dinit_img, d.B, d.R, n);
     SAT_TRY(launch_ok("init_expand_bwd"));
     SAT_TRY(gemm(st, A_KMAJOR, B_KMAJOR, w.dinit_img, 2 * n, w.f, m, g.init_i_w, m, 2 * n, m, d.B));
@@ -318,6 +367,7 @@ int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
     SAT_TRY(gemm(st, A_KMAJOR, B_KMAJOR, w.df, m, w.mean, D, g.init_f_w, D, m, D, d.B));
     SAT_TRY(colsum(st, w, w.df, m, d.B, m, g.init_f_b));
     SAT_TRY(gemm(st, A_ROW, B_KMAJOR, w.df, m, p.init_f_w, D, w.dmean, D, d.B, D, m));
+    }
     const long tot = (long)d.B * d.L * D;
     hipLaunchKernelGGL(dann_add_mean_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, st, dann, w.dmean, d.L, D, tot);
     return launch_ok("dann_add_mean");
@@ -378,7 +428,7 @@ int decoder_infer_step(const sat_decoder_dims& d, const sat_decoder_params& p, c
     SAT_REQUIRE(ws_bytes >= w.total && K >= 1 && K <= Kmax, "decoder_infer_step: workspace or beam count");
     t_bf16_mfma = d.precision ? 1 : 0;
     const int n = d.n, A = d.A, D = d.D, m = d.m, HCW = A + D + 4 * n;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(K), dim3(64), 0, st, p.embedding, tokens, w.Y, K, m);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(K), dim3(64), 0, st, p.embedding, tokens, w.Y, K, m, 0.f, 0ull, 0L);
     SAT_TRY(launch_ok("embedding gather"));
     SAT_TRY(gemm(st, A_ROW, B_ROW, h, n, w.Wcat, n, w.hc, HCW, K, HCW, n, 0, EPI_BIAS_SIGMOID_RANGE, w.bcat, nullptr, nullptr, nullptr, 0, A, A + D));
     SAT_TRY(launch_attention_fwd(st, ann, w.U, w.hc, HCW, p.att_f, w.ones, 0, alpha, 1, w.Z, w.XZ, 1, K, d.L, D, A));

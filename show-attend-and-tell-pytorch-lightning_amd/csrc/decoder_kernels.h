@@ -29,12 +29,51 @@ __global__ void fill_int_kernel(int* p, long n, int v) {
     if (i < n) p[i] = v;
 }
 
-// dst[r, :] = src[idx(r), :]  (embedding gather; tok < 0 -> zeros)
-__global__ void gather_rows_kernel(const float* __restrict__ table, const int* __restrict__ tok, float* __restrict__ out, int rows, int width) {
+// ---- dropout (nn.Dropout in training mode: model.py:74/78, 117/130, 164/526).  The mask is a counter-based hash of
+// (seed, stream, element index): no state, recomputed wherever it is needed (forward, backward), reproducible.
+// streams: 0 = InitLSTM mean, 1 = embedding, 2 = DeepOutput.  keep-probability 1-p, kept values scaled by 1/(1-p).
+__device__ __forceinline__ float dropout_scale(unsigned long long seed, unsigned stream, unsigned long long idx, float p) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(stream + 1) + idx * 0xD1342543DE82EF95ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const float u = (float)(z >> 40) * (1.0f / 16777216.0f);      // 24 bits -> [0,1)
+    return (u >= p) ? 1.0f / (1.0f - p) : 0.f;
+}
+
+// dst[r, :] = table[tok[r], :] (embedding gather; tok < 0 -> zeros), with embedding_dropout when p > 0
+__global__ void gather_rows_kernel(const float* __restrict__ table, const int* __restrict__ tok, float* __restrict__ out, int rows, int width,
+                                   float p, unsigned long long seed, long row0) {
     int r = blockIdx.x;
     if (r >= rows) return;
     int t = tok[r];
-    for (int c = threadIdx.x; c < width; c += blockDim.x) out[(long)r * width + c] = (t >= 0) ? table[(long)t * width + c] : 0.f;
+    for (int c = threadIdx.x; c < width; c += blockDim.x) {
+        float v = (t >= 0) ? table[(long)t * width + c] : 0.f;
+        if (p > 0.f) v *= dropout_scale(seed, 1, (unsigned long long)(row0 + r) * width + c, p);
+        out[(long)r * width + c] = v;
+    }
+}
+// y[r, c] = x[r, c] * mask(stream, (row0 + r) * width + c)   (in place allowed)
+__global__ void dropout_rows_kernel(const float* __restrict__ x, float* __restrict__ y, long total, int width, float p,
+                                    unsigned long long seed, unsigned stream, long row0) {
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < total) y[e] = x[e] * dropout_scale(seed, stream, (unsigned long long)row0 * width + e, p);
+}
+// InitLSTM with dropout: the mean of the REPEATED annotations is dropped per caption row (model.py:78 after 487)
+__global__ void init_mean_rows_kernel(const float* __restrict__ mean, float* __restrict__ out, int N, int R, int D, float p, unsigned long long seed) {
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)N * D) return;
+    long i = e / D; int d = (int)(e - i * D);
+    out[e] = mean[(i / R) * D + d] * dropout_scale(seed, 0, (unsigned long long)e, p);
+}
+// dmean[b, d] = sum_r dmean_rows[b*R + r, d] * mask
+__global__ void init_mean_rows_bwd_kernel(const float* __restrict__ drows, float* __restrict__ dmean, int B, int R, int D, float p, unsigned long long seed) {
+    long o = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= (long)B * D) return;
+    long b = o / D; int d = (int)(o - b * D);
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) { long e = (b * R + r) * D + d; s += drows[e] * dropout_scale(seed, 0, (unsigned long long)e, p); }
+    dmean[o] = s;
 }
 
 // token ids of step `step` for every caption row (teacher forcing): tok[i] = caps[i*T + step]

@@ -200,8 +200,20 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(BArgs a) {
     __shared__ KEnt ktab[2][KB];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bm = blockIdx.y * BM, bn = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * a.kchunk;
+    // XCD-aware tile order: the dispatcher deals workgroups round-robin over the 8 XCDs (each with its own L2), so
+    // workgroups i and i+8 share an L2.  Give every XCD a contiguous run of logical tiles (x fastest): the column
+    // tiles that re-read the same activation rows then hit one L2 instead of eight.  Bijective for any grid size;
+    // placement only affects speed, never results.
+    int bx, by, bz;
+    {
+        const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+        const unsigned orig = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        const unsigned q = total >> 3, r = total & 7, xcd = orig & 7, idx = orig >> 3;
+        const unsigned lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        bx = lin % gridDim.x; const unsigned t2 = lin / gridDim.x; by = t2 % gridDim.y; bz = t2 / gridDim.y;
+    }
+    const int bm = by * BM, bn = bx * BN;
+    const int kbeg = bz * a.kchunk;
     const int kend = min(a.K, kbeg + a.kchunk);
     const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
     const int li = lane & 31, lh = lane >> 5;
@@ -364,7 +376,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(BArgs a) {
                 int row = bm + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 int col = bn + wn + j * 32 + li;
                 if (row < a.M && col < a.N) {
-                    if (a.nsplit > 1) a.slab[((long)blockIdx.z * a.M + row) * a.N + col] = acc[i][j][r];
+                    if (a.nsplit > 1) a.slab[((long)bz * a.M + row) * a.N + col] = acc[i][j][r];
                     else put<TC>(a, row, col, acc[i][j][r]);
                 }
             }

@@ -70,9 +70,11 @@ class PackPlan:
         return flags
 
 
-def decoder_dims(B, R, T, Lc, D, A, m, n, V, P, deep, padding_idx, precision=0, embed_max_norm=0.0):
+def decoder_dims(B, R, T, Lc, D, A, m, n, V, P, deep, padding_idx, precision=0, embed_max_norm=0.0, dropout=0.0,
+                 embedding_dropout=0.0, dropout_seed=0):
     return L.DecoderDims(B=B, R=R, T=T, L=Lc, D=D, A=A, m=m, n=n, V=V, P=P, deep_output=int(bool(deep)), padding_idx=padding_idx,
-                         precision=int(precision), embed_max_norm=float(embed_max_norm or 0.0))
+                         precision=int(precision), embed_max_norm=float(embed_max_norm or 0.0), dropout=float(dropout),
+                         embedding_dropout=float(embedding_dropout), dropout_seed=int(dropout_seed))
 
 
 def _params_struct(tensors):
@@ -96,7 +98,7 @@ class DecoderTrainFn(torch.autograd.Function):
     """logits_packed (P,V), alphas (N,T-1,L) = decoder(ann (B,L,D), captions) with BPTT backward."""
 
     @staticmethod
-    def forward(ctx, ann, caps_i32, plan, teacher, deep, padding_idx, R, precision, embed_max_norm, *params):
+    def forward(ctx, ann, caps_i32, plan, teacher, deep, padding_idx, R, precision, embed_max_norm, dropout, *params):
         lib = L.lib()
         L.require_gpu(ann, caps_i32, *[p for p in params if p is not None])
         names = L.PARAM_FIELDS
@@ -114,7 +116,7 @@ class DecoderTrainFn(torch.autograd.Function):
                       beta_b=(D,), out_hidden=(m, n), out_context=(m, D), out_w=(V, m), out_b=(V,))
         for k in names:
             _check_param(k, tens[k], shapes[k])
-        dims = decoder_dims(B, R, T, Lc, D, A, m, n, V, plan.P, deep, padding_idx, precision, embed_max_norm)
+        dims = decoder_dims(B, R, T, Lc, D, A, m, n, V, plan.P, deep, padding_idx, precision, embed_max_norm, *dropout)
         ws_bytes = lib.sat_decoder_workspace_bytes(C.byref(dims))
         if ws_bytes == 0:
             raise L.SatHipError("sat_decoder_workspace_bytes: %s" % lib.sat_last_error().decode())
@@ -155,7 +157,7 @@ class DecoderTrainFn(torch.autograd.Function):
         w, g = _params_struct(tens), _params_struct(grads)
         L.check(lib.sat_decoder_train_bwd(C.byref(dims), C.byref(w), C.byref(batch), L.ptr(dlogits), L.ptr(alphas), L.ptr(dalphas),
                                           C.byref(g), L.ptr(dann), L.ptr(ctx.ws), ctx.ws_bytes, L.stream_ptr()), "sat_decoder_train_bwd")
-        return (dann, None, None, None, None, None, None, None, None, *[grads[k] for k in L.PARAM_FIELDS])
+        return (dann, None, None, None, None, None, None, None, None, None, *[grads[k] for k in L.PARAM_FIELDS])
 
 
 class LabelSmoothingFn(torch.autograd.Function):
@@ -219,6 +221,19 @@ class DoublyStochasticFn(torch.autograd.Function):
         L.check(lib.sat_doubly_stochastic_bwd(L.ptr(asum), L.ptr(gs), N, T1, Lc, ctx.gamma, L.ptr(dal), L.stream_ptr()),
                 "sat_doubly_stochastic_bwd")
         return dal, None
+
+
+def dropout_scale_reference(seed, stream, idx, p):
+    """numpy replica of csrc/decoder_kernels.h:dropout_scale (tests rebuild the masks with it on the host)."""
+    M = (1 << 64) - 1
+    idx = np.asarray(idx, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = (np.uint64(seed & M) + np.uint64((0x9E3779B97F4A7C15 * (stream + 1)) & M) + idx * np.uint64(0xD1342543DE82EF95))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z ^= z >> np.uint64(31)
+    u = (z >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return np.where(u >= np.float32(p), np.float32(1.0) / (np.float32(1.0) - np.float32(p)), np.float32(0.0)).astype(np.float32)
 
 
 def gemm(A, B, *, amode=0, bmode=0, M=None, N=None, K=None, out=None, accumulate=False, epi=0, bias=None, e0=None, c0=0, c1=0,

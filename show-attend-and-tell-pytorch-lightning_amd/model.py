@@ -94,8 +94,6 @@ class SATDecoder(nn.Module):
         self.hp = hp
         if hp.decoder_layers != 1:
             raise NotImplementedError("HIP decoder: decoder_layers=%d (only 1 layer is built this round)" % hp.decoder_layers)
-        if float(hp.dropout) != 0.0 or float(hp.embedding_dropout) != 0.0:
-            raise NotImplementedError("HIP decoder: dropout > 0 is not built this round (parity runs use 0, train.py:140-143)")
         assert 0 <= hp.label_smoothing < (hp.vocab_size - 1) / hp.vocab_size
         self.criterion = LabelSmoothing(hp.label_smoothing)
         self.pad_idx = int(hp.vocab_stoi["<PAD>"])
@@ -246,7 +244,20 @@ class SATDecoder(nn.Module):
                 cap_scores.append(fin_scores[best]); cap_ppl.append(fin_ppl[best])
         return captions, cap_scores, cap_alphas, cap_ppl
 
-    def train_decode(self, ann_bld, caps, lengths, epsilon=0, draw=None, with_loss=True):
+    def _dropout_args(self, seed=None):
+        """(p, p_embedding, seed) of this call: nn.Dropout is the identity in eval mode; the seed comes from a generator of
+        its own so that the CPU generator stream of scheduled sampling (F7) stays exactly the reference's."""
+        p, pe = float(self.hp.dropout), float(self.hp.embedding_dropout)
+        if not self.training or (p == 0.0 and pe == 0.0):
+            return (0.0, 0.0, 0)
+        if seed is None:
+            gen = self.__dict__.get("_dropout_gen")
+            if gen is None:
+                gen = self.__dict__["_dropout_gen"] = torch.Generator().manual_seed(torch.initial_seed() & 0x7FFFFFFFFFFFFFFF)
+            seed = int(torch.randint(0, 2 ** 62, (1,), generator=gen))
+        return (p, pe, int(seed))
+
+    def train_decode(self, ann_bld, caps, lengths, epsilon=0, draw=None, with_loss=True, dropout_seed=None):
         """Decoder half of train_batch + the loss terms (model.py:487-557, 592-597).
 
         ann_bld (B, L, D) on the GPU; caps (B, R, T) int64; lengths (B, R) int64 (host or device)."""
@@ -257,7 +268,7 @@ class SATDecoder(nn.Module):
         caps_i32 = caps2.to(device=ann_bld.device, dtype=torch.int32).contiguous()
         logits_packed, alphas = Dk.DecoderTrainFn.apply(ann_bld, caps_i32, plan, teacher, bool(self.hp.deep_output), self.pad_idx, R,
                                                         int(getattr(self, "sat_precision", "fp32") == "bf16"), getattr(self.hp, "embed_norm", None) or 0.0,
-                                                        *self.param_list())
+                                                        self._dropout_args(dropout_seed), *self.param_list())
         targets_packed = plan.pack(caps2[:, 1:].to(ann_bld.device).unsqueeze(-1)).squeeze(-1)
         if not with_loss:
             return dict(logits_packed=logits_packed, targets_packed=targets_packed, alphas=alphas, plan=plan)

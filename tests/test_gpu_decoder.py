@@ -156,3 +156,52 @@ def test_c2_shapes_properties(M):
     res3 = dec.train_decode(ann.detach(), caps[:, perm].cuda(), lengths[:, perm], 1.0)
     assert torch.equal(res2["logits_packed"], res3["logits_packed"]) and torch.equal(res2["alphas"], res3["alphas"])
     assert a1.shape == res2["alphas"].shape
+
+
+def test_dropout_matches_oracle_with_the_same_masks(M):
+    """nn.Dropout in the three places of the decoder (InitLSTM mean, embedding, DeepOutput; model.py:78,526,130).
+    The reference's masks come from the device RNG and cannot be reproduced; the HIP path draws them from a
+    counter-based hash, so the test rebuilds exactly those masks on the host (decoder.dropout_scale_reference) and
+    feeds them to the oracle: logits, loss and every gradient must then agree to the usual 1e-4 / 2e-4."""
+    from oracle import prng, sat_oracle as O
+    from sat_amd import decoder as Dk
+    hp = O.default_hparams(vocab_size=40, encoder_dim=16, embed_dim=12, attention_dim=8, decoder_dim=20, dropout=0.3, embedding_dropout=0.2)
+    sd = {k: torch.from_numpy(v) for k, v in prng.decoder_state(hp, 91).items()}
+    B, R, T, Hh, Ww = 4, 3, 9, 2, 3
+    ann = torch.from_numpy(prng.uniform((B, 16, Hh, Ww), 911))
+    caps, lengths = prng.captions(B, R, T, 40, 912)
+    caps, lengths = torch.from_numpy(caps), torch.from_numpy(lengths)
+    N, T1, m, D, seed = B * R, T - 1, 12, 16, 123456789
+    dec = M.SATDecoder(hp).cuda().train(); dec.load_decoder_state(sd)
+    ann_bld = ann.permute(0, 2, 3, 1).reshape(B, Hh * Ww, D).contiguous().cuda().requires_grad_()
+    res = dec.train_decode(ann_bld, caps.cuda(), lengths, 1.0, dropout_seed=seed)
+    plan = res["plan"]
+    # host replica of the masks
+    init = torch.from_numpy(Dk.dropout_scale_reference(seed, 0, np.arange(N * D), 0.3).reshape(N, D))
+    emb = torch.from_numpy(Dk.dropout_scale_reference(seed, 1, np.arange(T1 * N * m), 0.2).reshape(T1, N, m))
+    packed = Dk.dropout_scale_reference(seed, 2, np.arange(plan.P * m), 0.3).reshape(plan.P, m)
+    out = torch.zeros(T1, N, m)
+    prow = plan.prow.cpu()
+    for t in range(T1):
+        for i in range(N):
+            if prow[t, i] >= 0:
+                out[t, i] = torch.from_numpy(packed[prow[t, i]])
+    assert 0.6 < float((init > 0).float().mean()) < 0.8 and 0.7 < float((emb > 0).float().mean()) < 0.9
+    sdo = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    ann_o = ann.clone().requires_grad_()
+    loss_o, out_o = O.training_loss(sdo, hp, ann_o, caps, lengths, 1.0, masks=dict(init=init, emb=emb, out=out))
+    loss_o.backward()
+    close(res["logits_packed"], out_o["logits_packed"], what="logits under dropout")
+    close(res["alphas"], out_o["alphas"], what="alphas under dropout")
+    loss = res["ce"] + res["ds"]
+    close(loss, loss_o, what="loss under dropout")
+    loss.backward()
+    close(ann_bld.grad.reshape(B, Hh, Ww, D).permute(0, 3, 1, 2), ann_o.grad, 2e-4, "d_ann under dropout")
+    for k, p in dec.named_parameters():
+        close(p.grad, sdo[k].grad, 2e-4, k)
+    # eval mode: dropout is the identity (model.py:231)
+    dec.eval()
+    res_e = dec.train_decode(ann_bld.detach(), caps.cuda(), lengths, 1.0)
+    with torch.no_grad():
+        _, out_e = O.training_loss(sd, hp, ann, caps, lengths, 1.0)
+    close(res_e["logits_packed"], out_e["logits_packed"], what="eval logits")
