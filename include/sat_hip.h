@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SAT_HIP_ABI_VERSION 4
+#define SAT_HIP_ABI_VERSION 5
 
 int sat_abi_version(void);
 const char* sat_last_error(void);
@@ -81,6 +81,7 @@ typedef struct sat_decoder_dims {
     int32_t deep_output;  /* DeepOutput.deep (model.py:116)                        */
     int32_t padding_idx;  /* <PAD> id (model.py:162)                               */
     int32_t precision;    /* 0: exact fp32 MFMA (parity mode); 1: bf16 MFMA, fp32 accumulate/state */
+    int32_t layers;       /* nn.LSTM num_layers (model.py:178), 1..SAT_MAX_LSTM_LAYERS; h/c are (layers, N, n) */
     float embed_max_norm; /* nn.Embedding max_norm (model.py:161); <= 0: off.  Renormalises embedding rows IN PLACE */
     float dropout;        /* nn.Dropout p of InitLSTM / DeepOutput (model.py:74,117) in training mode; 0: off     */
     float embedding_dropout; /* p of embedding_dropout (model.py:164); 0: off                                    */
@@ -89,10 +90,11 @@ typedef struct sat_decoder_dims {
 
 /* state-dict tensors of the decoder; used for weights and, with the same
  * field meaning, for gradient outputs. */
+#define SAT_MAX_LSTM_LAYERS 4
 typedef struct sat_decoder_params {
     float* embedding;                 /* embedding.weight            (V, m)      */
     float* init_f_w; float* init_f_b; /* init_lstm.factorize         (m, D), (m) */
-    float* init_i_w; float* init_i_b; /* init_lstm.init              (2n, m), (2n) */
+    float* init_i_w; float* init_i_b; /* init_lstm.init              (2n*layers, m), (2n*layers) */
     float* w_ih; float* w_hh;         /* lstm.weight_ih_l0 (4n, m+D), lstm.weight_hh_l0 (4n, n) */
     float* b_ih; float* b_hh;         /* lstm.bias_ih_l0, lstm.bias_hh_l0 (4n)   */
     float* att_enc;                   /* attention.encoder_att.weight (A, D)     */
@@ -102,6 +104,9 @@ typedef struct sat_decoder_params {
     float* out_hidden;                /* output.hidden.weight         (m, n)     */
     float* out_context;               /* output.context.weight        (m, D), NULL when shallow */
     float* out_w; float* out_b;       /* output.output (V, m), (V); out_b NULL under weight tying */
+    /* stacked layers l = 1 .. layers-1 at index l-1: lstm.weight_ih_l{l} (4n, n), weight_hh_l{l} (4n, n), bias_ih_l{l}, bias_hh_l{l} (4n) */
+    float* up_w_ih[SAT_MAX_LSTM_LAYERS - 1]; float* up_w_hh[SAT_MAX_LSTM_LAYERS - 1];
+    float* up_b_ih[SAT_MAX_LSTM_LAYERS - 1]; float* up_b_hh[SAT_MAX_LSTM_LAYERS - 1];
 } sat_decoder_params;
 
 typedef struct sat_decoder_batch {
@@ -152,9 +157,11 @@ int sat_doubly_stochastic_bwd(const float* asum, const float* gscale, int32_t N,
  * (model.py:330-351); `sat_topk` = torch.topk on the flattened scores (model.py:343, 359). */
 size_t sat_decoder_infer_workspace_bytes(const sat_decoder_dims* d, int32_t max_beams);
 int sat_decoder_infer_begin(const sat_decoder_dims* d, const sat_decoder_params* w, const float* ann /* (L, D) */, int32_t beams,
-                            int32_t max_beams, float* h /* (beams, n) */, float* c, void* workspace, size_t workspace_bytes, void* stream);
+                            int32_t max_beams, float* h /* (layers, beams, n) */, float* c, void* workspace, size_t workspace_bytes, void* stream);
 int sat_decoder_infer_step(const sat_decoder_dims* d, const sat_decoder_params* w, const float* ann, const int32_t* tokens, int32_t beams,
                            int32_t max_beams, float* h, float* c, float* logits /* (beams, V) */, float* alpha /* (beams, L) */,
+                           const float* h_noise /* (layers, beams, n) or NULL: decoder_noise (model.py:322-324), added to h for the
+                                                   LSTM update only; attention and the beta gate see the clean h[-1] */,
                            void* workspace, size_t workspace_bytes, void* stream);
 int sat_beam_scores(const float* logits, int32_t beams, int32_t V, float temperature, const int32_t* masked_ids /* device */,
                     int32_t n_masked, const float* parent_scores /* (beams) or NULL */, float* scores, void* stream);

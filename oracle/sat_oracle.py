@@ -452,13 +452,17 @@ class OracleSAT:
 
 
 # --------------------------------------------------------------------------
-# a11. Inference: SAT.forward / caption beam search (model.py:237-472), "beam" sampling.
+# a11. Inference: SAT.forward / caption (model.py:237-472): beam search, the two sampled variants, decoder noise.
 # --------------------------------------------------------------------------
 
 def beam_search(sd, hp, ann_img, beamk=3, max_gen_length=32, temperature=1.0, rescore_method=None, rescore_reward=0.5,
-                return_all=False, lstm_fn=lstm_step):
+                return_all=False, lstm_fn=lstm_step, sample_method="beam", sample_topk=3, decoder_noise=None,
+                multinomial=torch.multinomial, randn=torch.randn):
     """Per-image beam search exactly as the reference runs it (one image at a time, the beam is the batch).
-    ann_img (B,D,h,w).  Returns (captions, scores, alphas, perplexities) lists like model.py:472."""
+    ann_img (B,D,h,w).  Returns (captions, scores, alphas, perplexities) lists like model.py:472.
+    sample_method "multinomial" / "topk" follow model.py:360-379 and decoder_noise model.py:322-324; their random draws
+    come from ``multinomial(probs, k)`` / ``randn(shape)`` (the torch samplers unless a test supplies its own)."""
+    assert sample_method in ("beam", "multinomial", "topk")
     stoi = hp.vocab_stoi
     START, PAD, END, UNK = int(stoi["<START>"]), int(stoi["<PAD>"]), int(stoi["<END>"]), int(stoi["<UNK>"])
     V, layers, n = hp.vocab_size, hp.decoder_layers, hp.decoder_dim
@@ -489,6 +493,8 @@ def beam_search(sd, hp, ann_img, beamk=3, max_gen_length=32, temperature=1.0, re
             y = embed(sd, top_preds[step])
             z, alpha = soft_attention(sd, annots, h[-1])
             x = torch.cat([y, beta_gate(sd, h[-1]) * z], dim=1).unsqueeze(0)
+            if decoder_noise is not None and decoder_noise != 0.0:               # model.py:322-324: after attention / gate
+                h = h + randn(h.size()) * decoder_noise / (step + 1)
             h, c = lstm_fn(sd, x, h, c, layers)
             scores = F.log_softmax(deep_output(sd, y, h[-1], z, hp.deep_output) / T, dim=1)
             scores[:, [START, PAD]] = float("-inf")                      # model.py:333
@@ -499,7 +505,15 @@ def beam_search(sd, hp, ann_img, beamk=3, max_gen_length=32, temperature=1.0, re
                 alphas = torch.cat([alphas, alpha.unsqueeze(0)], 0)
             else:
                 seq = scores + top_scores.unsqueeze(1)
-                _, pred_idx = torch.topk(seq.reshape(-1), k, dim=0)      # model.py:359
+                if sample_method == "beam":
+                    _, pred_idx = torch.topk(seq.reshape(-1), k, dim=0)      # model.py:359
+                elif sample_method == "multinomial":                         # model.py:360-364
+                    pred_idx = multinomial(F.softmax(20 * seq / step, dim=1).reshape(-1), k)
+                else:                                                        # model.py:365-379
+                    _, cand = torch.topk(seq, sample_topk, dim=1)
+                    cand = (cand + torch.tensor([i * V for i in range(k)]).unsqueeze(1).to(cand)).reshape(-1)
+                    choice = multinomial(F.softmax(seq.reshape(-1)[cand] / step, dim=0), k)
+                    pred_idx = cand[choice]
                 top_scores = seq.reshape(-1)[pred_idx]
                 keep = torch.div(pred_idx, V, rounding_mode="floor")
                 word = torch.remainder(pred_idx, V).unsqueeze(0)

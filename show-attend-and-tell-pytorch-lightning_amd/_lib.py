@@ -23,7 +23,7 @@ class GemmDesc(C.Structure):
 
 
 class DecoderDims(C.Structure):
-    _fields_ = [(k, C.c_int32) for k in ("B", "R", "T", "L", "D", "A", "m", "n", "V", "P", "deep_output", "padding_idx", "precision")] + \
+    _fields_ = [(k, C.c_int32) for k in ("B", "R", "T", "L", "D", "A", "m", "n", "V", "P", "deep_output", "padding_idx", "precision", "layers")] + \
                [("embed_max_norm", C.c_float), ("dropout", C.c_float), ("embedding_dropout", C.c_float), ("dropout_seed", C.c_uint64)]
 
 
@@ -38,8 +38,27 @@ PARAM_KEYS = dict(embedding="embedding.weight", init_f_w="init_lstm.factorize.we
                   out_context="output.context.weight", out_w="output.output.weight", out_b="output.output.bias")
 
 
+MAX_LSTM_LAYERS = 4
+#: stacked LSTM layers l >= 1 (lstm.weight_ih_l{l}, ...): pointer arrays indexed l-1
+UP_FIELDS = ("up_w_ih", "up_w_hh", "up_b_ih", "up_b_hh")
+UP_KEYS = dict(up_w_ih="lstm.weight_ih_l%d", up_w_hh="lstm.weight_hh_l%d", up_b_ih="lstm.bias_ih_l%d", up_b_hh="lstm.bias_hh_l%d")
+
+
+def param_names(layers=1):
+    """Argument order of the decoder parameter list: the 18 base tensors, then 4 per stacked layer."""
+    return list(PARAM_FIELDS) + ["%s_l%d" % (k[3:], l) for l in range(1, layers) for k in UP_FIELDS]
+
+
+def param_key(name):
+    """decoder parameter name -> reference state-dict key"""
+    if name in PARAM_KEYS:
+        return PARAM_KEYS[name]
+    base, l = name.rsplit("_l", 1)
+    return UP_KEYS["up_" + base] % int(l)
+
+
 class DecoderParams(C.Structure):
-    _fields_ = [(k, C.c_void_p) for k in PARAM_FIELDS]
+    _fields_ = [(k, C.c_void_p) for k in PARAM_FIELDS] + [(k, C.c_void_p * (MAX_LSTM_LAYERS - 1)) for k in UP_FIELDS]
 
 
 class DecoderBatch(C.Structure):
@@ -120,7 +139,7 @@ class ProfileEntry(C.Structure):
 SYMBOLS.update({
     "sat_decoder_infer_workspace_bytes": (C.c_size_t, [C.POINTER(DecoderDims), _i32]),
     "sat_decoder_infer_begin": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), _vp, _i32, _i32, _vp, _vp, _vp, C.c_size_t, _vp]),
-    "sat_decoder_infer_step": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp,
+    "sat_decoder_infer_step": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                                          C.c_size_t, _vp]),
     "sat_beam_scores": (C.c_int, [_vp, _i32, _i32, _f, _vp, _i32, _vp, _vp, _vp]),
     "sat_topk": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
@@ -156,8 +175,8 @@ def lib():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(handle, name)          # AttributeError if the export is missing
             fn.restype, fn.argtypes = res, args
-        if handle.sat_abi_version() != 4:
-            raise SatHipError("libsat_hip.so ABI version %d != 4 (rebuild: make -C csrc)" % handle.sat_abi_version())
+        if handle.sat_abi_version() != 5:
+            raise SatHipError("libsat_hip.so ABI version %d != 5 (rebuild: make -C csrc)" % handle.sat_abi_version())
         _lib = handle
     return _lib
 

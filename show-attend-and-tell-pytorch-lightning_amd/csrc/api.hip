@@ -50,6 +50,9 @@ static int check_params(const sat_decoder_dims* d, const sat_decoder_params* w, 
         !w->att_enc || !w->att_dec || !w->att_f || !w->beta_w || !w->beta_b || !w->out_hidden || !w->out_w)
         return fail(SAT_EINVAL, "%s: null tensor in parameter struct", what);
     if (d->deep_output && !w->out_context) return fail(SAT_EINVAL, "%s: deep output needs output.context.weight", what);
+    for (int l = 1; l < d->layers; ++l)
+        if (!w->up_w_ih[l - 1] || !w->up_w_hh[l - 1] || !w->up_b_ih[l - 1] || !w->up_b_hh[l - 1])
+            return fail(SAT_EINVAL, "%s: null tensor for LSTM layer %d", what, l);
     return SAT_OK;
 }
 static int check_batch(const sat_decoder_batch* b) {
@@ -103,10 +106,11 @@ int sat_decoder_infer_begin(const sat_decoder_dims* d, const sat_decoder_params*
     return decoder_infer_begin(*d, *w, ann, beams, max_beams, h, c, (char*)workspace, workspace_bytes, (hipStream_t)stream);
 }
 int sat_decoder_infer_step(const sat_decoder_dims* d, const sat_decoder_params* w, const float* ann, const int32_t* tokens, int32_t beams,
-                           int32_t max_beams, float* h, float* c, float* logits, float* alpha, void* workspace, size_t workspace_bytes, void* stream) {
+                           int32_t max_beams, float* h, float* c, float* logits, float* alpha, const float* h_noise, void* workspace,
+                           size_t workspace_bytes, void* stream) {
     SAT_TRY(check_dims(d)); SAT_TRY(check_params(d, w, "decoder_infer_step"));
     if (!ann || !tokens || !h || !c || !logits || !alpha || !workspace) return fail(SAT_EINVAL, "decoder_infer_step: null pointer");
-    return decoder_infer_step(*d, *w, ann, tokens, beams, max_beams, h, c, logits, alpha, (char*)workspace, workspace_bytes, (hipStream_t)stream);
+    return decoder_infer_step(*d, *w, ann, tokens, beams, max_beams, h, c, logits, alpha, h_noise, (char*)workspace, workspace_bytes, (hipStream_t)stream);
 }
 int sat_beam_scores(const float* logits, int32_t beams, int32_t V, float temperature, const int32_t* masked_ids, int32_t n_masked,
                     const float* parent_scores, float* scores, void* stream) {

@@ -14,6 +14,7 @@ struct Ws {
     // saved by forward
     float *U, *mean, *f, *init_img, *H_all, *C_all, *HC, *Z, *XZ, *Y, *GY, *Uact, *Wcat, *bcat;
     float *Udrop, *mean_rows, *f_rows, *init_rows, *df_rows;     // only carved when dropout > 0
+    float *GU, *DGU, *bup;                                       // stacked LSTM layers (layers > 1): gates, gate grads, bias sums
     int* Tok; int* flags;
     // backward scratch
     float *dA, *dHout, *dZout, *DZ, *DHC, *dXZ, *dHc, *dCc, *dU, *dwf_part, *dY, *colpart, *dinit_img, *df, *dmean, *slab;
@@ -27,9 +28,16 @@ Ws layout(const sat_decoder_dims& d, char* base) {
     w.U = (float*)take((size_t)d.B * d.L * d.A);
     w.mean = (float*)take((size_t)d.B * d.D);
     w.f = (float*)take((size_t)d.B * d.m);
-    w.init_img = (float*)take((size_t)d.B * 2 * d.n);
-    w.H_all = (float*)take((size_t)(T1 + 1) * N * d.n);
-    w.C_all = (float*)take((size_t)(T1 + 1) * N * d.n);
+    const int NL = d.layers;
+    w.init_img = (float*)take((size_t)d.B * 2 * d.n * NL);
+    // hidden / cell state of every layer and step, one time-major run per layer: [layer][T1 + 1][N][n]
+    w.H_all = (float*)take((size_t)NL * (T1 + 1) * N * d.n);
+    w.C_all = (float*)take((size_t)NL * (T1 + 1) * N * d.n);
+    w.GU = w.DGU = w.bup = nullptr;
+    if (NL > 1) {
+        w.GU = (float*)take((size_t)(NL - 1) * T1 * N * 4 * d.n); w.DGU = (float*)take((size_t)(NL - 1) * T1 * N * 4 * d.n);
+        w.bup = (float*)take((size_t)(NL - 1) * 4 * d.n);
+    }
     w.HC = (float*)take((size_t)T1 * N * HCW);
     w.Z = (float*)take((size_t)T1 * N * d.D);
     w.XZ = (float*)take((size_t)T1 * N * d.D);
@@ -42,7 +50,7 @@ Ws layout(const sat_decoder_dims& d, char* base) {
     w.Udrop = w.mean_rows = w.f_rows = w.init_rows = w.df_rows = nullptr;
     if (d.dropout > 0.f) {
         w.Udrop = (float*)take((size_t)(d.P > 0 ? d.P : 1) * d.m); w.mean_rows = (float*)take((size_t)N * d.D); w.f_rows = (float*)take((size_t)N * d.m);
-        w.init_rows = (float*)take((size_t)N * 2 * d.n); w.df_rows = (float*)take((size_t)N * d.m);
+        w.init_rows = (float*)take((size_t)N * 2 * d.n * NL); w.df_rows = (float*)take((size_t)N * d.m);
     }
     w.flags = (int*)take((size_t)d.V);
     w.dA = (float*)take((size_t)(d.P > 0 ? d.P : 1) * d.m);
@@ -51,15 +59,15 @@ Ws layout(const sat_decoder_dims& d, char* base) {
     w.DZ = (float*)take((size_t)T1 * N * d.D);
     w.DHC = (float*)take((size_t)T1 * N * HCW);
     w.dXZ = (float*)take((size_t)N * d.D);
-    w.dHc = (float*)take((size_t)N * d.n);
-    w.dCc = (float*)take((size_t)N * d.n);
+    w.dHc = (float*)take((size_t)NL * N * d.n);
+    w.dCc = (float*)take((size_t)NL * N * d.n);
     w.dU = (float*)take((size_t)d.B * d.L * d.A);
     w.dwf_part = (float*)take((size_t)d.B * d.A);
     w.dY = (float*)take((size_t)T1 * N * d.m);
     long maxrows = d.P > T1 * N ? d.P : T1 * N; if (maxrows < d.B * (long)d.L) maxrows = d.B * (long)d.L;
     long maxcols = d.V > HCW ? d.V : HCW;
     w.colpart = (float*)take((size_t)cdiv(maxrows, 256) * maxcols);
-    w.dinit_img = (float*)take((size_t)d.B * 2 * d.n);
+    w.dinit_img = (float*)take((size_t)d.B * 2 * d.n * NL);
     w.df = (float*)take((size_t)d.B * d.m);
     w.dmean = (float*)take((size_t)d.B * d.D);
     w.slab_elems = 8L << 20;   // 32 MiB of split-K partials
@@ -73,6 +81,7 @@ int check_dims(const sat_decoder_dims* d) {
     SAT_REQUIRE(d->B > 0 && d->R > 0 && d->T >= 2 && d->L > 0 && d->D > 0 && d->A > 0 && d->m > 0 && d->n > 0 && d->V > 0,
                 "decoder: non-positive dimension (B=%d R=%d T=%d L=%d D=%d A=%d m=%d n=%d V=%d)", d->B, d->R, d->T, d->L, d->D, d->A, d->m, d->n, d->V);
     SAT_REQUIRE(d->P >= 0 && (long)d->P <= (long)d->B * d->R * (d->T - 1), "decoder: packed token count %d out of range", d->P);
+    SAT_REQUIRE(d->layers >= 1 && d->layers <= SAT_MAX_LSTM_LAYERS, "decoder: layers=%d outside 1..%d", d->layers, SAT_MAX_LSTM_LAYERS);
     SAT_REQUIRE(d->dropout >= 0.f && d->dropout < 1.f && d->embedding_dropout >= 0.f && d->embedding_dropout < 1.f, "decoder: dropout must lie in [0,1)");
     return SAT_OK;
 }
@@ -134,7 +143,7 @@ static int flush_outputs(hipStream_t st, const sat_decoder_dims& d, const sat_de
     const int rows = p1 - p0;
     if (rows <= 0) return SAT_OK;
     const long N = (long)d.B * d.R;
-    const float* H1 = w.H_all + N * d.n;                 // hidden state AFTER each step (F8: the new h)
+    const float* H1 = w.H_all + ((long)(d.layers - 1) * d.T + 1) * N * d.n;   // top layer's hidden state AFTER each step (F8: the new h)
     float* u = w.Uact + (long)p0 * d.m;
     const int* rows_map = b.src_row + p0;
     if (d.deep_output) {
@@ -162,6 +171,11 @@ int decoder_fwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
     SAT_REQUIRE(ws_bytes >= w.total, "decoder_fwd: workspace %zu < %zu bytes", ws_bytes, w.total);
     SAT_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, "decoder: workspace must be 256-byte aligned");
     const int N = d.B * d.R, T1 = d.T - 1, HCW = d.A + d.D + 4 * d.n, n = d.n, A = d.A, D = d.D, m = d.m;
+    const int NL = d.layers, top = NL - 1;
+    const long LS = (long)(T1 + 1) * N * n;                                   // layer stride of H_all / C_all
+    auto Hs = [&](int t, int l) { return w.H_all + l * LS + (long)t * N * n; };
+    auto Cs = [&](int t, int l) { return w.C_all + l * LS + (long)t * N * n; };
+    auto GUs = [&](int t, int l) { return w.GU + ((long)(l - 1) * T1 + t) * N * 4 * n; };
     const int ts = live_steps(d, b);
     SAT_REQUIRE(b.step_offsets_host[T1] == d.P, "decoder: step_offsets[T-1]=%d != P=%d", b.step_offsets_host[T1], d.P);
     for (int t = 0; t < ts; ++t) SAT_REQUIRE(b.teacher_host[t] || t > 0, "decoder: step 0 must be teacher forced");
@@ -174,6 +188,10 @@ int decoder_fwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
     SAT_CHECK_HIP(hipMemcpyAsync(w.bcat + A, p.beta_b, (size_t)D * 4, hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(add_kernel, dim3(cdiv(4 * n, 256)), dim3(256), 0, st, w.bcat + A + D, p.b_ih, p.b_hh, (long)4 * n);
     SAT_TRY(launch_ok("bias add"));
+    for (int l = 1; l < NL; ++l) {
+        hipLaunchKernelGGL(add_kernel, dim3(cdiv(4 * n, 256)), dim3(256), 0, st, w.bup + (long)(l - 1) * 4 * n, p.up_b_ih[l - 1], p.up_b_hh[l - 1], (long)4 * n);
+        SAT_TRY(launch_ok("bias add (stacked layer)"));
+    }
 
     // att_enc, hoisted (model.py:100): U = ann * W_e^T once per image
     SAT_TRY(gemm(st, A_ROW, B_ROW, b.ann, D, p.att_enc, D, w.U, A, d.B * d.L, A, D));
@@ -186,13 +204,15 @@ int decoder_fwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
         hipLaunchKernelGGL(init_mean_rows_kernel, dim3(cdiv((long)N * D, 256)), dim3(256), 0, st, w.mean, w.mean_rows, N, d.R, D, d.dropout, (unsigned long long)d.dropout_seed);
         SAT_TRY(launch_ok("init_mean_rows"));
         SAT_TRY(gemm(st, A_ROW, B_ROW, w.mean_rows, D, p.init_f_w, D, w.f_rows, m, N, m, D, 0, EPI_BIAS, p.init_f_b));
-        SAT_TRY(gemm(st, A_ROW, B_ROW, w.f_rows, m, p.init_i_w, m, w.init_rows, 2 * n, N, 2 * n, m, 0, EPI_BIAS, p.init_i_b));
-        SAT_CHECK_HIP(hipMemcpyAsync(w.H_all, w.init_rows, (size_t)N * n * 4, hipMemcpyDeviceToDevice, st));
-        SAT_CHECK_HIP(hipMemcpyAsync(w.C_all, w.init_rows + (long)N * n, (size_t)N * n * 4, hipMemcpyDeviceToDevice, st));
+        SAT_TRY(gemm(st, A_ROW, B_ROW, w.f_rows, m, p.init_i_w, m, w.init_rows, 2 * n * NL, N, 2 * n * NL, m, 0, EPI_BIAS, p.init_i_b));
+        for (int l = 0; l < NL; ++l) {
+            SAT_CHECK_HIP(hipMemcpyAsync(Hs(0, l), w.init_rows + (long)l * N * n, (size_t)N * n * 4, hipMemcpyDeviceToDevice, st));
+            SAT_CHECK_HIP(hipMemcpyAsync(Cs(0, l), w.init_rows + (long)(NL + l) * N * n, (size_t)N * n * 4, hipMemcpyDeviceToDevice, st));
+        }
     } else {
         SAT_TRY(gemm(st, A_ROW, B_ROW, w.mean, D, p.init_f_w, D, w.f, m, d.B, m, D, 0, EPI_BIAS, p.init_f_b));
-        SAT_TRY(gemm(st, A_ROW, B_ROW, w.f, m, p.init_i_w, m, w.init_img, 2 * n, d.B, 2 * n, m, 0, EPI_BIAS, p.init_i_b));
-        hipLaunchKernelGGL(init_expand_kernel, dim3(cdiv(2L * N * n, 256)), dim3(256), 0, st, w.init_img, w.H_all, w.C_all, N, d.R, n);
+        SAT_TRY(gemm(st, A_ROW, B_ROW, w.f, m, p.init_i_w, m, w.init_img, 2 * n * NL, d.B, 2 * n * NL, m, 0, EPI_BIAS, p.init_i_b));
+        hipLaunchKernelGGL(init_expand_kernel, dim3(cdiv(2L * NL * N * n, 256)), dim3(256), 0, st, w.init_img, w.H_all, w.C_all, N, d.R, n, NL, LS);
         SAT_TRY(launch_ok("init_expand"));
     }
 
@@ -235,17 +255,31 @@ int decoder_fwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
             SAT_TRY(launch_ok("embedding gather"));
             SAT_TRY(gemm(st, A_ROW, B_ROW, w.Y + (long)t * N * m, m, p.w_ih, m + D, w.GY + (long)t * N * 4 * n, 4 * n, N, 4 * n, m));
         }
-        // [q | beta | gates_h] = h_{t-1} * Wcat^T + bcat, sigmoid on the beta columns
-        SAT_TRY(gemm(st, A_ROW, B_ROW, w.H_all + (long)t * N * n, n, w.Wcat, n, hc, HCW, N, HCW, n, 0, EPI_BIAS_SIGMOID_RANGE, w.bcat,
-                     nullptr, nullptr, nullptr, 0, A, A + D));
+        // [q | beta | gates_h] = h_{t-1} * Wcat^T + bcat, sigmoid on the beta columns.  Attention and the gate read the TOP
+        // layer's state (h[-1], model.py:533,538); the recurrent term of layer 0 reads layer 0's.
+        if (NL == 1) {
+            SAT_TRY(gemm(st, A_ROW, B_ROW, Hs(t, 0), n, w.Wcat, n, hc, HCW, N, HCW, n, 0, EPI_BIAS_SIGMOID_RANGE, w.bcat,
+                         nullptr, nullptr, nullptr, 0, A, A + D));
+        } else {
+            SAT_TRY(gemm(st, A_ROW, B_ROW, Hs(t, top), n, w.Wcat, n, hc, HCW, N, A + D, n, 0, EPI_BIAS_SIGMOID_RANGE, w.bcat,
+                         nullptr, nullptr, nullptr, 0, A, A + D));
+            SAT_TRY(gemm(st, A_ROW, B_ROW, Hs(t, 0), n, w.Wcat + (long)(A + D) * n, n, hc + A + D, HCW, N, 4 * n, n, 0, EPI_BIAS, w.bcat + A + D));
+        }
         SAT_TRY(launch_attention_fwd(st, b.ann, w.U, hc, HCW, p.att_f, b.lengths, t, alphas, T1, w.Z + (long)t * N * D, w.XZ + (long)t * N * D,
                                      d.B, d.R, d.L, D, A));
         // gates += (beta*z) * W_ih[:, m:]^T
         SAT_TRY(gemm(st, A_ROW, B_ROW, w.XZ + (long)t * N * D, D, p.w_ih + m, m + D, hc + A + D, HCW, N, 4 * n, D, 1));
         hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(cdiv((long)N * n, 256)), dim3(256), 0, st, hc + A + D, HCW, w.GY + (long)t * N * 4 * n,
-                           w.C_all + (long)t * N * n, w.H_all + (long)t * N * n, w.C_all + (long)(t + 1) * N * n, w.H_all + (long)(t + 1) * N * n,
-                           b.lengths, t, N, n);
+                           Cs(t, 0), Hs(t, 0), Cs(t + 1, 0), Hs(t + 1, 0), b.lengths, t, N, n);
         SAT_TRY(launch_ok("lstm_cell_fwd"));
+        for (int l = 1; l < NL; ++l) {          // stacked layers: input = the layer below's new h (nn.LSTM, no inter-layer dropout: model.py:175-180)
+            float* gu = GUs(t, l);
+            SAT_TRY(gemm(st, A_ROW, B_ROW, Hs(t + 1, l - 1), n, p.up_w_ih[l - 1], n, gu, 4 * n, N, 4 * n, n, 0, EPI_BIAS, w.bup + (long)(l - 1) * 4 * n));
+            SAT_TRY(gemm(st, A_ROW, B_ROW, Hs(t, l), n, p.up_w_hh[l - 1], n, gu, 4 * n, N, 4 * n, n, 1));
+            hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(cdiv((long)N * n, 256)), dim3(256), 0, st, gu, 4 * n, (const float*)nullptr,
+                               Cs(t, l), Hs(t, l), Cs(t + 1, l), Hs(t + 1, l), b.lengths, t, N, n);
+            SAT_TRY(launch_ok("lstm_cell_fwd (stacked layer)"));
+        }
     }
     return flush_outputs(st, d, p, b, w, logits, b.step_offsets_host[pending], b.step_offsets_host[ts]);
 }
@@ -258,12 +292,21 @@ int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
     const int N = d.B * d.R, T1 = d.T - 1, HCW = d.A + d.D + 4 * d.n, n = d.n, A = d.A, D = d.D, m = d.m, V = d.V, P = d.P;
     const int ts = live_steps(d, b);
     const int KR = ts * N;                              // rows of the time-major padded buffers that were touched
+    const int NL = d.layers, top = NL - 1;
+    const long LS = (long)(T1 + 1) * N * n;
+    auto Hs = [&](int t, int l) { return w.H_all + l * LS + (long)t * N * n; };
+    auto Cs = [&](int t, int l) { return w.C_all + l * LS + (long)t * N * n; };
+    auto GUs = [&](int t, int l) { return w.GU + ((long)(l - 1) * T1 + t) * N * 4 * n; };
+    auto DGUs = [&](int t, int l) { return w.DGU + ((long)(l - 1) * T1 + t) * N * 4 * n; };
+    auto dHcs = [&](int l) { return w.dHc + (long)l * N * n; };
+    auto dCcs = [&](int l) { return w.dCc + (long)l * N * n; };
     float* const slab = w.slab; const long se = w.slab_elems;
 
     SAT_CHECK_HIP(hipMemsetAsync(w.dU, 0, (size_t)d.B * d.L * A * 4, st));
     SAT_CHECK_HIP(hipMemsetAsync(w.dwf_part, 0, (size_t)d.B * A * 4, st));
-    SAT_CHECK_HIP(hipMemsetAsync(w.dHc, 0, (size_t)N * n * 4, st));
-    SAT_CHECK_HIP(hipMemsetAsync(w.dCc, 0, (size_t)N * n * 4, st));
+    SAT_CHECK_HIP(hipMemsetAsync(w.dHc, 0, (size_t)NL * N * n * 4, st));
+    SAT_CHECK_HIP(hipMemsetAsync(w.dCc, 0, (size_t)NL * N * n * 4, st));
+    if (NL > 1 && KR < T1 * N) SAT_CHECK_HIP(hipMemsetAsync(w.DGU, 0, (size_t)(NL - 1) * T1 * N * 4 * n * 4, st));
     SAT_CHECK_HIP(hipMemsetAsync(w.dHout, 0, (size_t)T1 * N * n * 4, st));
     SAT_CHECK_HIP(hipMemsetAsync(w.dZout, 0, (size_t)T1 * N * D * 4, st));
 
@@ -288,7 +331,7 @@ int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
     // dA in time-major padded rows (zeros for finished captions): operand of the weight-grad GEMMs and of dY
     hipLaunchKernelGGL(scatter_rows_kernel, dim3(T1 * N), dim3(64), 0, st, w.dA, b.prow, w.dY, T1 * N, m);
     SAT_TRY(launch_ok("scatter dA"));
-    const float* H1 = w.H_all + (long)N * n;
+    const float* H1 = Hs(1, top);
     SAT_TRY(gemm(st, A_KMAJOR, B_KMAJOR, w.dY, m, H1, n, g.out_hidden, n, m, n, KR, 0, EPI_NONE, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, slab, se));
     if (d.deep_output)
         SAT_TRY(gemm(st, A_KMAJOR, B_KMAJOR, w.dY, m, w.Z, D, g.out_context, D, m, D, KR, 0, EPI_NONE, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, slab, se));
@@ -302,8 +345,16 @@ int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
     for (int t = ts - 1; t >= 0; --t) {
         const float* hc = w.HC + (long)t * N * HCW;
         float* dhc = w.DHC + (long)t * N * HCW;
-        hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(cdiv((long)N * n, 256)), dim3(256), 0, st, hc + A + D, HCW, w.C_all + (long)t * N * n,
-                           w.C_all + (long)(t + 1) * N * n, w.dHout + (long)t * N * n, w.dHc, w.dCc, dhc + A + D, HCW, b.lengths, t, N, n);
+        for (int l = top; l >= 1; --l) {        // stacked layers, top down: gate grads, then into the layer below and the own past
+            float* dgu = DGUs(t, l);
+            hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(cdiv((long)N * n, 256)), dim3(256), 0, st, GUs(t, l), 4 * n, Cs(t, l), Cs(t + 1, l),
+                               l == top ? w.dHout + (long)t * N * n : (const float*)nullptr, dHcs(l), dCcs(l), dgu, 4 * n, b.lengths, t, N, n);
+            SAT_TRY(launch_ok("lstm_cell_bwd (stacked layer)"));
+            SAT_TRY(gemm(st, A_ROW, B_KMAJOR, dgu, 4 * n, p.up_w_ih[l - 1], n, dHcs(l - 1), n, N, n, 4 * n, 1, EPI_NONE, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, slab, se));
+            SAT_TRY(gemm(st, A_ROW, B_KMAJOR, dgu, 4 * n, p.up_w_hh[l - 1], n, dHcs(l), n, N, n, 4 * n, 1, EPI_NONE, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, slab, se));
+        }
+        hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(cdiv((long)N * n, 256)), dim3(256), 0, st, hc + A + D, HCW, Cs(t, 0),
+                           Cs(t + 1, 0), top == 0 ? w.dHout + (long)t * N * n : (const float*)nullptr, dHcs(0), dCcs(0), dhc + A + D, HCW, b.lengths, t, N, n);
         SAT_TRY(launch_ok("lstm_cell_bwd"));
         // d(beta*z) = dG * W_ih[:, m:]
         SAT_TRY(gemm(st, A_ROW, B_KMAJOR, dhc + A + D, HCW, p.w_ih + m, m + D, w.dXZ, D, N, D, 4 * n, 0, EPI_NONE, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, slab, se));
@@ -312,7 +363,12 @@ int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
                            d.R, d.L, D, A);
         SAT_TRY(launch_ok("attention_bwd"));
         // dh_{t-1} += [dq | dbeta_pre | dG] * Wcat
-        SAT_TRY(gemm(st, A_ROW, B_KMAJOR, dhc, HCW, w.Wcat, n, w.dHc, n, N, n, HCW, 1, EPI_NONE, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, slab, se));
+        if (NL == 1) {
+            SAT_TRY(gemm(st, A_ROW, B_KMAJOR, dhc, HCW, w.Wcat, n, w.dHc, n, N, n, HCW, 1, EPI_NONE, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, slab, se));
+        } else {
+            SAT_TRY(gemm(st, A_ROW, B_KMAJOR, dhc, HCW, w.Wcat, n, dHcs(top), n, N, n, A + D, 1, EPI_NONE, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, slab, se));
+            SAT_TRY(gemm(st, A_ROW, B_KMAJOR, dhc + A + D, HCW, w.Wcat + (long)(A + D) * n, n, dHcs(0), n, N, n, 4 * n, 1, EPI_NONE, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, slab, se));
+        }
     }
     // now dHc = dL/dh0 and dCc = dL/dc0
 
@@ -321,9 +377,16 @@ int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
         return gemm(st, A_KMAJOR, B_KMAJOR, dy, ldy, x, ldx, out, ldo, M, Nn, KR, 0, EPI_NONE, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, slab, se);
     };
     const float* dG = w.DHC + A + D;
-    SAT_TRY(wgrad(w.DHC, HCW, w.H_all, n, g.att_dec, n, A, n));
-    SAT_TRY(wgrad(w.DHC + A, HCW, w.H_all, n, g.beta_w, n, D, n));
-    SAT_TRY(wgrad(dG, HCW, w.H_all, n, g.w_hh, n, 4 * n, n));
+    SAT_TRY(wgrad(w.DHC, HCW, Hs(0, top), n, g.att_dec, n, A, n));
+    SAT_TRY(wgrad(w.DHC + A, HCW, Hs(0, top), n, g.beta_w, n, D, n));
+    SAT_TRY(wgrad(dG, HCW, Hs(0, 0), n, g.w_hh, n, 4 * n, n));
+    for (int l = 1; l < NL; ++l) {
+        const float* dgu = DGUs(0, l);
+        SAT_TRY(wgrad(dgu, 4 * n, Hs(1, l - 1), n, g.up_w_ih[l - 1], n, 4 * n, n));
+        SAT_TRY(wgrad(dgu, 4 * n, Hs(0, l), n, g.up_w_hh[l - 1], n, 4 * n, n));
+        SAT_TRY(colsum(st, w, dgu, 4 * n, KR, 4 * n, g.up_b_ih[l - 1]));
+        SAT_CHECK_HIP(hipMemcpyAsync(g.up_b_hh[l - 1], g.up_b_ih[l - 1], (size_t)4 * n * 4, hipMemcpyDeviceToDevice, st));
+    }
     SAT_TRY(colsum(st, w, w.DHC + A, HCW, KR, D, g.beta_b));
     SAT_TRY(colsum(st, w, dG, HCW, KR, 4 * n, g.b_ih));
     SAT_CHECK_HIP(hipMemcpyAsync(g.b_hh, g.b_ih, (size_t)4 * n * 4, hipMemcpyDeviceToDevice, st));
@@ -347,11 +410,12 @@ int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
     SAT_TRY(launch_ok("dann_from_context"));
     // InitLSTM backward (the raw reshape is a reinterpretation: gradients of the repeated rows add up per image)
     if (d.dropout > 0.f) {                 // per-caption-row path (see decoder_fwd)
-        SAT_CHECK_HIP(hipMemcpyAsync(w.init_rows, w.dHc, (size_t)N * n * 4, hipMemcpyDeviceToDevice, st));
-        SAT_CHECK_HIP(hipMemcpyAsync(w.init_rows + (long)N * n, w.dCc, (size_t)N * n * 4, hipMemcpyDeviceToDevice, st));
-        SAT_TRY(gemm(st, A_KMAJOR, B_KMAJOR, w.init_rows, 2 * n, w.f_rows, m, g.init_i_w, m, 2 * n, m, N));
-        SAT_TRY(colsum(st, w, w.init_rows, 2 * n, N, 2 * n, g.init_i_b));
-        SAT_TRY(gemm(st, A_ROW, B_KMAJOR, w.init_rows, 2 * n, p.init_i_w, m, w.df_rows, m, N, m, 2 * n));
+        const int n2 = 2 * n * NL;
+        SAT_CHECK_HIP(hipMemcpyAsync(w.init_rows, w.dHc, (size_t)NL * N * n * 4, hipMemcpyDeviceToDevice, st));
+        SAT_CHECK_HIP(hipMemcpyAsync(w.init_rows + (long)NL * N * n, w.dCc, (size_t)NL * N * n * 4, hipMemcpyDeviceToDevice, st));
+        SAT_TRY(gemm(st, A_KMAJOR, B_KMAJOR, w.init_rows, n2, w.f_rows, m, g.init_i_w, m, n2, m, N));
+        SAT_TRY(colsum(st, w, w.init_rows, n2, N, n2, g.init_i_b));
+        SAT_TRY(gemm(st, A_ROW, B_KMAJOR, w.init_rows, n2, p.init_i_w, m, w.df_rows, m, N, m, n2));
         SAT_TRY(gemm(st, A_KMAJOR, B_KMAJOR, w.df_rows, m, w.mean_rows, D, g.init_f_w, D, m, D, N));
         SAT_TRY(colsum(st, w, w.df_rows, m, N, m, g.init_f_b));
         SAT_TRY(gemm(st, A_ROW, B_KMAJOR, w.df_rows, m, p.init_f_w, D, w.mean_rows, D, N, D, m));          // d(mean rows), reuses the buffer
@@ -359,11 +423,12 @@ int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
                            (unsigned long long)d.dropout_seed);
         SAT_TRY(launch_ok("init_mean_rows_bwd"));
     } else {
-    hipLaunchKernelGGL(init_expand_bwd_kernel, dim3(cdiv((long)d.B * 2 * n, 256)), dim3(256), 0, st, w.dHc, w.dCc, w.dinit_img, d.B, d.R, n);
+    const int n2 = 2 * n * NL;
+    hipLaunchKernelGGL(init_expand_bwd_kernel, dim3(cdiv((long)d.B * n2, 256)), dim3(256), 0, st, w.dHc, w.dCc, w.dinit_img, d.B, d.R, n * NL);
     SAT_TRY(launch_ok("init_expand_bwd"));
-    SAT_TRY(gemm(st, A_KMAJOR, B_KMAJOR, w.dinit_img, 2 * n, w.f, m, g.init_i_w, m, 2 * n, m, d.B));
-    SAT_TRY(colsum(st, w, w.dinit_img, 2 * n, d.B, 2 * n, g.init_i_b));
-    SAT_TRY(gemm(st, A_ROW, B_KMAJOR, w.dinit_img, 2 * n, p.init_i_w, m, w.df, m, d.B, m, 2 * n));
+    SAT_TRY(gemm(st, A_KMAJOR, B_KMAJOR, w.dinit_img, n2, w.f, m, g.init_i_w, m, n2, m, d.B));
+    SAT_TRY(colsum(st, w, w.dinit_img, n2, d.B, n2, g.init_i_b));
+    SAT_TRY(gemm(st, A_ROW, B_KMAJOR, w.dinit_img, n2, p.init_i_w, m, w.df, m, d.B, m, n2));
     SAT_TRY(gemm(st, A_KMAJOR, B_KMAJOR, w.df, m, w.mean, D, g.init_f_w, D, m, D, d.B));
     SAT_TRY(colsum(st, w, w.df, m, d.B, m, g.init_f_b));
     SAT_TRY(gemm(st, A_ROW, B_KMAJOR, w.df, m, p.init_f_w, D, w.dmean, D, d.B, D, m));
@@ -382,13 +447,14 @@ int colsum_public(const float* x, long ld, long rows, int cols, float* out, floa
 size_t decoder_workspace_bytes(const sat_decoder_dims& d) { return layout(d, nullptr).total; }
 
 // ------------------------------------------------------------------ inference: one image, K live beams
-struct InferWs { size_t total; float *U, *Wcat, *bcat, *mean, *f, *init_img, *hc, *Z, *XZ, *Y, *u; int* ones; };
+struct InferWs { size_t total; float *U, *Wcat, *bcat, *mean, *f, *init_img, *hc, *Z, *XZ, *Y, *u, *gu, *bup; int* ones; };
 static InferWs infer_layout(const sat_decoder_dims& d, int Kmax, char* base) {
     InferWs w; size_t off = 0;
     const long HCW = d.A + d.D + 4L * d.n;
     auto take = [&](size_t elems) { size_t o = off; off += (elems * 4 + 255) & ~(size_t)255; return base ? base + o : (char*)nullptr; };
     w.U = (float*)take((size_t)d.L * d.A); w.Wcat = (float*)take((size_t)HCW * d.n); w.bcat = (float*)take((size_t)HCW);
-    w.mean = (float*)take(d.D); w.f = (float*)take(d.m); w.init_img = (float*)take(2 * (size_t)d.n);
+    w.mean = (float*)take(d.D); w.f = (float*)take(d.m); w.init_img = (float*)take(2 * (size_t)d.n * d.layers);
+    w.gu = (float*)take((size_t)Kmax * 4 * d.n); w.bup = (float*)take((size_t)d.layers * 4 * d.n);
     w.hc = (float*)take((size_t)Kmax * HCW); w.Z = (float*)take((size_t)Kmax * d.D); w.XZ = (float*)take((size_t)Kmax * d.D);
     w.Y = (float*)take((size_t)Kmax * d.m); w.u = (float*)take((size_t)Kmax * d.m); w.ones = (int*)take(Kmax);
     w.total = off;
@@ -410,37 +476,60 @@ int decoder_infer_begin(const sat_decoder_dims& d, const sat_decoder_params& p, 
     SAT_CHECK_HIP(hipMemcpyAsync(w.bcat + A, p.beta_b, (size_t)D * 4, hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(add_kernel, dim3(cdiv(4 * n, 256)), dim3(256), 0, st, w.bcat + A + D, p.b_ih, p.b_hh, (long)4 * n);
     SAT_TRY(launch_ok("bias add"));
+    for (int l = 1; l < d.layers; ++l) {
+        hipLaunchKernelGGL(add_kernel, dim3(cdiv(4 * n, 256)), dim3(256), 0, st, w.bup + (long)(l - 1) * 4 * n, p.up_b_ih[l - 1], p.up_b_hh[l - 1], (long)4 * n);
+        SAT_TRY(launch_ok("bias add (stacked layer)"));
+    }
     hipLaunchKernelGGL(fill_int_kernel, dim3(cdiv(Kmax, 256)), dim3(256), 0, st, w.ones, (long)Kmax, 1);
     SAT_TRY(launch_ok("fill ones"));
     SAT_TRY(gemm(st, A_ROW, B_ROW, ann, D, p.att_enc, D, w.U, A, d.L, A, D));
     hipLaunchKernelGGL(ann_mean_kernel, dim3(1), dim3(256), 0, st, ann, w.mean, d.L, D);
     SAT_TRY(launch_ok("ann_mean"));
     SAT_TRY(gemm(st, A_ROW, B_ROW, w.mean, D, p.init_f_w, D, w.f, m, 1, m, D, 0, EPI_BIAS, p.init_f_b));
-    SAT_TRY(gemm(st, A_ROW, B_ROW, w.f, m, p.init_i_w, m, w.init_img, 2 * n, 1, 2 * n, m, 0, EPI_BIAS, p.init_i_b));
-    hipLaunchKernelGGL(init_expand_kernel, dim3(cdiv(2L * K * n, 256)), dim3(256), 0, st, w.init_img, h, c, K, K, n);   // one image, R = K rows
+    SAT_TRY(gemm(st, A_ROW, B_ROW, w.f, m, p.init_i_w, m, w.init_img, 2 * n * d.layers, 1, 2 * n * d.layers, m, 0, EPI_BIAS, p.init_i_b));
+    hipLaunchKernelGGL(init_expand_kernel, dim3(cdiv(2L * d.layers * K * n, 256)), dim3(256), 0, st, w.init_img, h, c, K, K, n, d.layers,
+                       (long)K * n);   // one image, R = K rows
     return launch_ok("init_expand");
 }
 
 // model.py:298-327: embedding -> attention -> beta gate -> LSTM -> deep output for the K live beams of one image
 int decoder_infer_step(const sat_decoder_dims& d, const sat_decoder_params& p, const float* ann, const int* tokens, int K, int Kmax,
-                       float* h, float* c, float* logits, float* alpha, char* ws, size_t ws_bytes, hipStream_t st) {
+                       float* h, float* c, float* logits, float* alpha, const float* h_noise, char* ws, size_t ws_bytes, hipStream_t st) {
     InferWs w = infer_layout(d, Kmax, ws);
+    const int NL = d.layers; const long KS = (long)K * d.n;       // h, c: (layers, K, n)
+    float* htop = h + (NL - 1) * KS;
     SAT_REQUIRE(ws_bytes >= w.total && K >= 1 && K <= Kmax, "decoder_infer_step: workspace or beam count");
     t_bf16_mfma = d.precision ? 1 : 0;
     const int n = d.n, A = d.A, D = d.D, m = d.m, HCW = A + D + 4 * n;
     hipLaunchKernelGGL(gather_rows_kernel, dim3(K), dim3(64), 0, st, p.embedding, tokens, w.Y, K, m, 0.f, 0ull, 0L);
     SAT_TRY(launch_ok("embedding gather"));
-    SAT_TRY(gemm(st, A_ROW, B_ROW, h, n, w.Wcat, n, w.hc, HCW, K, HCW, n, 0, EPI_BIAS_SIGMOID_RANGE, w.bcat, nullptr, nullptr, nullptr, 0, A, A + D));
+    if (NL == 1) {
+        SAT_TRY(gemm(st, A_ROW, B_ROW, h, n, w.Wcat, n, w.hc, HCW, K, HCW, n, 0, EPI_BIAS_SIGMOID_RANGE, w.bcat, nullptr, nullptr, nullptr, 0, A, A + D));
+    } else {
+        SAT_TRY(gemm(st, A_ROW, B_ROW, htop, n, w.Wcat, n, w.hc, HCW, K, A + D, n, 0, EPI_BIAS_SIGMOID_RANGE, w.bcat, nullptr, nullptr, nullptr, 0, A, A + D));
+        SAT_TRY(gemm(st, A_ROW, B_ROW, h, n, w.Wcat + (long)(A + D) * n, n, w.hc + A + D, HCW, K, 4 * n, n, 0, EPI_BIAS, w.bcat + A + D));
+    }
+    // decoder_noise (model.py:322-324): the noise joins h after attention and the gate were taken from the clean state, so
+    // it reaches the step through the recurrent products only: gates += noise * W_hh^T (the GEMM is linear in h)
+    if (h_noise) SAT_TRY(gemm(st, A_ROW, B_ROW, h_noise, n, w.Wcat + (long)(A + D) * n, n, w.hc + A + D, HCW, K, 4 * n, n, 1));
     SAT_TRY(launch_attention_fwd(st, ann, w.U, w.hc, HCW, p.att_f, w.ones, 0, alpha, 1, w.Z, w.XZ, 1, K, d.L, D, A));
     SAT_TRY(gemm(st, A_ROW, B_ROW, w.Y, m, p.w_ih, m + D, w.hc + A + D, HCW, K, 4 * n, m, 1));
     SAT_TRY(gemm(st, A_ROW, B_ROW, w.XZ, D, p.w_ih + m, m + D, w.hc + A + D, HCW, K, 4 * n, D, 1));
     hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(cdiv((long)K * n, 256)), dim3(256), 0, st, w.hc + A + D, HCW, (const float*)nullptr, c, h, c, h, w.ones, 0, K, n);
     SAT_TRY(launch_ok("lstm_cell_fwd"));
+    for (int l = 1; l < NL; ++l) {
+        float* hl = h + l * KS; float* cl = c + l * KS;
+        SAT_TRY(gemm(st, A_ROW, B_ROW, hl - KS, n, p.up_w_ih[l - 1], n, w.gu, 4 * n, K, 4 * n, n, 0, EPI_BIAS, w.bup + (long)(l - 1) * 4 * n));
+        SAT_TRY(gemm(st, A_ROW, B_ROW, hl, n, p.up_w_hh[l - 1], n, w.gu, 4 * n, K, 4 * n, n, 1));
+        if (h_noise) SAT_TRY(gemm(st, A_ROW, B_ROW, h_noise + l * KS, n, p.up_w_hh[l - 1], n, w.gu, 4 * n, K, 4 * n, n, 1));
+        hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(cdiv((long)K * n, 256)), dim3(256), 0, st, w.gu, 4 * n, (const float*)nullptr, cl, hl, cl, hl, w.ones, 0, K, n);
+        SAT_TRY(launch_ok("lstm_cell_fwd (stacked layer)"));
+    }
     if (d.deep_output) {
-        SAT_TRY(gemm(st, A_ROW, B_ROW, h, n, p.out_hidden, n, w.u, m, K, m, n));
+        SAT_TRY(gemm(st, A_ROW, B_ROW, htop, n, p.out_hidden, n, w.u, m, K, m, n));
         SAT_TRY(gemm(st, A_ROW, B_ROW, w.Z, D, p.out_context, D, w.u, m, K, m, D, 1, EPI_ADD_TANH, nullptr, nullptr, nullptr, w.Y, m));
     } else {
-        SAT_TRY(gemm(st, A_ROW, B_ROW, h, n, p.out_hidden, n, w.u, m, K, m, n));
+        SAT_TRY(gemm(st, A_ROW, B_ROW, htop, n, p.out_hidden, n, w.u, m, K, m, n));
     }
     return gemm(st, A_ROW, B_ROW, w.u, m, p.out_w, m, logits, d.V, K, d.V, m, 0, p.out_b ? EPI_BIAS : EPI_NONE, p.out_b);
 }

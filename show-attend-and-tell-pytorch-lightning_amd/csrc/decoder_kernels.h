@@ -119,15 +119,18 @@ __global__ void ann_mean_kernel(const float* __restrict__ ann, float* __restrict
     }
 }
 
-// InitLSTM raw reshape (model.py:79-80): the (N, 2n) buffer whose row j is init[j / R]
-// is reinterpreted as (2, N, n): hc0[0] = h0, hc0[1] = c0.  flat element e of the buffer -> row e / (2n).
-__global__ void init_expand_kernel(const float* __restrict__ init_img, float* __restrict__ h0, float* __restrict__ c0, int N, int R, int n) {
+// InitLSTM raw reshape (model.py:79-80): the (N, 2*layers*n) buffer whose row j is init[j / R]
+// is reinterpreted as (2*layers, N, n): slabs [0, layers) are h0, the rest c0.  flat element e -> row e / (2*layers*n).
+// Layer slab l of h0 / c0 is written at h0 + l * lstride (the time-major state buffers keep one run per layer).
+__global__ void init_expand_kernel(const float* __restrict__ init_img, float* __restrict__ h0, float* __restrict__ c0, int N, int R, int n,
+                                   int layers, long lstride) {
     long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    long half = (long)N * n;
-    if (e >= 2 * half) return;
-    long row = e / (2 * n), col = e % (2 * n);
-    float v = init_img[(row / R) * (2 * n) + col];
-    if (e < half) h0[e] = v; else c0[e - half] = v;
+    const long slab_sz = (long)N * n, w2 = 2L * layers * n;
+    if (e >= 2 * layers * slab_sz) return;
+    long row = e / w2, col = e % w2;
+    float v = init_img[(row / R) * w2 + col];
+    long slab = e / slab_sz, within = e - slab * slab_sz;
+    if (slab < layers) h0[slab * lstride + within] = v; else c0[(slab - layers) * lstride + within] = v;
 }
 // backward of the above: dinit_img[b, col] = sum_r dflat[(b*R + r), col]
 __global__ void init_expand_bwd_kernel(const float* __restrict__ dh0, const float* __restrict__ dc0, float* __restrict__ dinit_img, int B, int R, int n) {
@@ -311,7 +314,7 @@ __global__ void lstm_cell_bwd_kernel(const float* __restrict__ gates, int g_ld, 
     if (lengths[i] <= step) { dg[j] = 0.f; dg[n + j] = 0.f; dg[2 * n + j] = 0.f; dg[3 * n + j] = 0.f; return; }
     const float* g = gates + (long)i * g_ld;
     float gi = g[j], gf = g[n + j], gg = g[2 * n + j], go = g[3 * n + j];
-    float dh = dh_carry[idx] + dh_out[idx];
+    float dh = dh_carry[idx] + (dh_out ? dh_out[idx] : 0.f);
     float tc = fast_tanh(c_new[idx]);
     float dc = dc_carry[idx] + dh * go * (1.f - tc * tc);
     dg[j] = dc * gg * gi * (1.f - gi);

@@ -71,18 +71,32 @@ class PackPlan:
 
 
 def decoder_dims(B, R, T, Lc, D, A, m, n, V, P, deep, padding_idx, precision=0, embed_max_norm=0.0, dropout=0.0,
-                 embedding_dropout=0.0, dropout_seed=0):
+                 embedding_dropout=0.0, dropout_seed=0, layers=1):
+    if not 1 <= int(layers) <= L.MAX_LSTM_LAYERS:
+        raise ValueError("decoder_layers=%d: the library is built for 1..%d stacked LSTM layers" % (layers, L.MAX_LSTM_LAYERS))
     return L.DecoderDims(B=B, R=R, T=T, L=Lc, D=D, A=A, m=m, n=n, V=V, P=P, deep_output=int(bool(deep)), padding_idx=padding_idx,
-                         precision=int(precision), embed_max_norm=float(embed_max_norm or 0.0), dropout=float(dropout),
+                         precision=int(precision), layers=int(layers), embed_max_norm=float(embed_max_norm or 0.0), dropout=float(dropout),
                          embedding_dropout=float(embedding_dropout), dropout_seed=int(dropout_seed))
 
 
-def _params_struct(tensors):
+def _params_struct(tensors, layers=1):
     s = L.DecoderParams()
     for k in L.PARAM_FIELDS:
         t = tensors.get(k)
         setattr(s, k, None if t is None else t.data_ptr())
+    for k in L.UP_FIELDS:
+        arr = getattr(s, k)
+        for l in range(1, layers):
+            arr[l - 1] = tensors["%s_l%d" % (k[3:], l)].data_ptr()
     return s
+
+
+def layers_of(n_params):
+    """number of LSTM layers implied by the length of a decoder parameter list"""
+    extra = n_params - len(L.PARAM_FIELDS)
+    if extra < 0 or extra % len(L.UP_FIELDS):
+        raise ValueError("decoder parameter list has %d entries; expected 18 + 4 per stacked layer" % n_params)
+    return 1 + extra // len(L.UP_FIELDS)
 
 
 def _check_param(name, t, shape):
@@ -101,7 +115,8 @@ class DecoderTrainFn(torch.autograd.Function):
     def forward(ctx, ann, caps_i32, plan, teacher, deep, padding_idx, R, precision, embed_max_norm, dropout, *params):
         lib = L.lib()
         L.require_gpu(ann, caps_i32, *[p for p in params if p is not None])
-        names = L.PARAM_FIELDS
+        layers = layers_of(len(params))
+        names = L.param_names(layers)
         tens = dict(zip(names, params))
         ann = ann.contiguous()
         B, Lc, D = ann.shape
@@ -111,12 +126,16 @@ class DecoderTrainFn(torch.autograd.Function):
         N, T = caps_i32.shape
         if N != B * R or plan.N != N or plan.T != T:
             raise ValueError("caption batch (%d,%d) does not match B*R=%d / plan (%d,%d)" % (N, T, B * R, plan.N, plan.T))
-        shapes = dict(embedding=(V, m), init_f_w=(m, D), init_f_b=(m,), init_i_w=(2 * n, m), init_i_b=(2 * n,), w_ih=(4 * n, m + D),
+        shapes = dict(embedding=(V, m), init_f_w=(m, D), init_f_b=(m,), init_i_w=(2 * n * layers, m), init_i_b=(2 * n * layers,), w_ih=(4 * n, m + D),
                       w_hh=(4 * n, n), b_ih=(4 * n,), b_hh=(4 * n,), att_enc=(A, D), att_dec=(A, n), att_f=(1, A), beta_w=(D, n),
                       beta_b=(D,), out_hidden=(m, n), out_context=(m, D), out_w=(V, m), out_b=(V,))
+        for l in range(1, layers):
+            shapes.update({"w_ih_l%d" % l: (4 * n, n), "w_hh_l%d" % l: (4 * n, n), "b_ih_l%d" % l: (4 * n,), "b_hh_l%d" % l: (4 * n,)})
         for k in names:
             _check_param(k, tens[k], shapes[k])
-        dims = decoder_dims(B, R, T, Lc, D, A, m, n, V, plan.P, deep, padding_idx, precision, embed_max_norm, *dropout)
+            if tens[k] is None and k not in ("out_context", "out_b"):
+                raise ValueError("decoder parameter %s is missing" % k)
+        dims = decoder_dims(B, R, T, Lc, D, A, m, n, V, plan.P, deep, padding_idx, precision, embed_max_norm, *dropout, layers=layers)
         ws_bytes = lib.sat_decoder_workspace_bytes(C.byref(dims))
         if ws_bytes == 0:
             raise L.SatHipError("sat_decoder_workspace_bytes: %s" % lib.sat_last_error().decode())
@@ -127,11 +146,11 @@ class DecoderTrainFn(torch.autograd.Function):
         batch = L.DecoderBatch(ann=ann.data_ptr(), caps=caps_i32.data_ptr(), lengths=plan.lengths.data_ptr(), prow=plan.prow.data_ptr(),
                                src_row=plan.src_row.data_ptr(), step_offsets_host=plan.offsets_host.ctypes.data,
                                teacher_host=teacher.ctypes.data)
-        w = _params_struct(tens)
+        w = _params_struct(tens, layers)
         L.check(lib.sat_decoder_train_fwd(C.byref(dims), C.byref(w), C.byref(batch), L.ptr(logits), L.ptr(alphas), L.ptr(ws), ws_bytes,
                                           L.stream_ptr()), "sat_decoder_train_fwd")
         ctx.dims, ctx.plan, ctx.teacher, ctx.ws, ctx.ws_bytes = dims, plan, teacher, ws, ws_bytes
-        ctx.caps = caps_i32
+        ctx.caps, ctx.layers = caps_i32, layers
         ctx.save_for_backward(ann, alphas, *[p for p in params if p is not None])
         ctx.present = [p is not None for p in params]
         return logits, alphas
@@ -143,7 +162,8 @@ class DecoderTrainFn(torch.autograd.Function):
         ann, alphas = saved[0], saved[1]
         it = iter(saved[2:])
         params = [next(it) if present else None for present in ctx.present]
-        tens = dict(zip(L.PARAM_FIELDS, params))
+        names = L.param_names(ctx.layers)
+        tens = dict(zip(names, params))
         plan, dims = ctx.plan, ctx.dims
         grads = {k: (None if t is None else torch.empty_like(t)) for k, t in tens.items()}
         dann = torch.empty_like(ann)
@@ -154,10 +174,10 @@ class DecoderTrainFn(torch.autograd.Function):
         batch = L.DecoderBatch(ann=ann.data_ptr(), caps=ctx.caps.data_ptr(), lengths=plan.lengths.data_ptr(), prow=plan.prow.data_ptr(),
                                src_row=plan.src_row.data_ptr(), step_offsets_host=plan.offsets_host.ctypes.data,
                                teacher_host=ctx.teacher.ctypes.data)
-        w, g = _params_struct(tens), _params_struct(grads)
+        w, g = _params_struct(tens, ctx.layers), _params_struct(grads, ctx.layers)
         L.check(lib.sat_decoder_train_bwd(C.byref(dims), C.byref(w), C.byref(batch), L.ptr(dlogits), L.ptr(alphas), L.ptr(dalphas),
                                           C.byref(g), L.ptr(dann), L.ptr(ctx.ws), ctx.ws_bytes, L.stream_ptr()), "sat_decoder_train_bwd")
-        return (dann, None, None, None, None, None, None, None, None, None, *[grads[k] for k in L.PARAM_FIELDS])
+        return (dann, None, None, None, None, None, None, None, None, None, *[grads[k] for k in names])
 
 
 class LabelSmoothingFn(torch.autograd.Function):

@@ -92,8 +92,8 @@ class SATDecoder(nn.Module):
         if isinstance(hp, dict) and not isinstance(hp, _HParams):
             hp = _HParams(hp)
         self.hp = hp
-        if hp.decoder_layers != 1:
-            raise NotImplementedError("HIP decoder: decoder_layers=%d (only 1 layer is built this round)" % hp.decoder_layers)
+        if not 1 <= hp.decoder_layers <= L.MAX_LSTM_LAYERS:
+            raise NotImplementedError("HIP decoder: decoder_layers=%d (the library stacks 1..%d LSTM layers)" % (hp.decoder_layers, L.MAX_LSTM_LAYERS))
         assert 0 <= hp.label_smoothing < (hp.vocab_size - 1) / hp.vocab_size
         self.criterion = LabelSmoothing(hp.label_smoothing)
         self.pad_idx = int(hp.vocab_stoi["<PAD>"])
@@ -111,14 +111,15 @@ class SATDecoder(nn.Module):
         if hp.weight_tying and hp.deep_output:
             self.output.output.weight = self.embedding.weight
 
-    # -- parameters in the order of sat_decoder_params (include/sat_hip.h)
+    # -- parameters in the order of sat_decoder_params (include/sat_hip.h): 18 base tensors, then 4 per stacked LSTM layer
     def param_list(self):
         o = self.output
+        up = [getattr(self.lstm, "%s_l%d" % (k, l)) for l in range(1, self.hp.decoder_layers) for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
         return [self.embedding.weight, self.init_lstm.factorize.weight, self.init_lstm.factorize.bias, self.init_lstm.init.weight,
                 self.init_lstm.init.bias, self.lstm.weight_ih_l0, self.lstm.weight_hh_l0, self.lstm.bias_ih_l0, self.lstm.bias_hh_l0,
                 self.attention.encoder_att.weight, self.attention.decoder_att.weight, self.attention.f_att.weight,
                 self.beta[0].weight, self.beta[0].bias, o.hidden.weight, (o.context.weight if o.deep else None),
-                o.output.weight, o.output.bias]
+                o.output.weight, o.output.bias] + up
 
     def load_decoder_state(self, sd):
         own = self.state_dict()
@@ -128,20 +129,22 @@ class SATDecoder(nn.Module):
 
     # ------------------------------------------------------------------ inference (model.py:214-472)
     def _params_struct(self):
-        tens = dict(zip(L.PARAM_FIELDS, self.param_list()))
-        return Dk._params_struct(tens), tens
+        layers = self.hp.decoder_layers
+        tens = dict(zip(L.param_names(layers), self.param_list()))
+        return Dk._params_struct(tens, layers), tens
 
     @torch.no_grad()
     def beam_decode(self, ann_bld, hw, beamk=3, max_gen_length=32, temperature=1.0, sample_method="beam", sample_topk=3,
-                    decoder_noise=None, rescore_method=None, rescore_reward=0.5, return_all=False):
+                    decoder_noise=None, rescore_method=None, rescore_reward=0.5, return_all=False, multinomial=None, randn=None):
         """SAT.forward's per-image beam search (model.py:260-472) on annotations (B, L, D).  The decode step,
         log-softmax / masking and top-k run in the library; the beam bookkeeping (which hypotheses to keep, finished
-        lists, rescoring) stays on the host like in the reference."""
+        lists, rescoring) stays on the host like in the reference.  ``sample_method`` "multinomial" / "topk"
+        (model.py:360-379) draw the continuing hypotheses with ``multinomial(probs, k)`` and ``decoder_noise``
+        (model.py:322-324) perturbs the recurrent state with ``randn(shape)``: both default to the torch samplers on the
+        annotations' device and can be replaced (tests feed both sides the same draws)."""
         import ctypes as C
-        if sample_method != "beam":
-            raise NotImplementedError("sample_method=%r: only 'beam' is built on the HIP path this round" % (sample_method,))
-        if decoder_noise:
-            raise NotImplementedError("decoder_noise is not built on the HIP path")
+        assert sample_method in ("beam", "multinomial", "topk")
+        multinomial = multinomial or torch.multinomial
         lib = L.lib()
         L.require_gpu(ann_bld)
         hp = self.hp
@@ -154,8 +157,10 @@ class SATDecoder(nn.Module):
         START, PAD = int(hp.vocab_stoi["<START>"]), int(hp.vocab_stoi["<PAD>"])
         END, UNK = int(hp.vocab_stoi["<END>"]), int(hp.vocab_stoi["<UNK>"])
         temps = temperature if isinstance(temperature, list) else [temperature]
+        NL = int(hp.decoder_layers)
+        randn = randn or (lambda shape: torch.randn(shape, device=dev))
         dims = Dk.decoder_dims(1, beamk, 2, Lc, D, A, m, n, V, 0, hp.deep_output, self.pad_idx,
-                               int(getattr(self, "sat_precision", "fp32") == "bf16"))
+                               int(getattr(self, "sat_precision", "fp32") == "bf16"), layers=NL)
         w, _keep = self._params_struct()
         ws_bytes = lib.sat_decoder_infer_workspace_bytes(C.byref(dims), beamk)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
@@ -168,7 +173,7 @@ class SATDecoder(nn.Module):
         for idx in range(B):
             k = beamk
             ann = ann_bld[idx].contiguous()
-            h = torch.empty(k, n, **f32); c = torch.empty(k, n, **f32)
+            h = torch.empty(NL, k, n, **f32); c = torch.empty(NL, k, n, **f32)
             L.check(lib.sat_decoder_infer_begin(C.byref(dims), C.byref(w), L.ptr(ann), k, beamk, L.ptr(h), L.ptr(c), L.ptr(ws), ws_bytes, st()),
                     "sat_decoder_infer_begin")
             top_preds = torch.full((1, k), START, dtype=torch.int64, device=dev)
@@ -190,8 +195,11 @@ class SATDecoder(nn.Module):
                 T = float(temps[step % len(temps)])
                 tok = top_preds[step].to(torch.int32).contiguous()
                 logits = torch.empty(k, V, **f32); alpha = torch.empty(k, Lc, **f32)
+                noise = None
+                if decoder_noise is not None and decoder_noise != 0.0:
+                    noise = (randn((NL, k, n)).to(device=dev, dtype=torch.float32) * (decoder_noise / (step + 1))).contiguous()
                 L.check(lib.sat_decoder_infer_step(C.byref(dims), C.byref(w), L.ptr(ann), L.ptr(tok), k, beamk, L.ptr(h), L.ptr(c), L.ptr(logits),
-                                                   L.ptr(alpha), L.ptr(ws), ws_bytes, st()), "sat_decoder_infer_step")
+                                                   L.ptr(alpha), L.ptr(noise), L.ptr(ws), ws_bytes, st()), "sat_decoder_infer_step")
                 scores = torch.empty(k, V, **f32)
                 vals = torch.empty(k, **f32); inds = torch.empty(k, dtype=torch.int32, device=dev)
                 if step == 0:
@@ -203,14 +211,25 @@ class SATDecoder(nn.Module):
                 else:
                     L.check(lib.sat_beam_scores(L.ptr(logits), k, V, T, L.ptr(mask_rest), 2, L.ptr(top_scores.contiguous()), L.ptr(scores), st()),
                             "sat_beam_scores")
-                    L.check(lib.sat_topk(L.ptr(scores), L.ptr(work), k * V, k, L.ptr(vals), L.ptr(inds), st()), "sat_topk")
-                    top_scores = vals
-                    pred = inds.to(torch.int64)
+                    if sample_method == "beam":
+                        L.check(lib.sat_topk(L.ptr(scores), L.ptr(work), k * V, k, L.ptr(vals), L.ptr(inds), st()), "sat_topk")
+                        top_scores = vals
+                        pred = inds.to(torch.int64)
+                    else:
+                        if sample_method == "multinomial":                                 # model.py:360-364
+                            pred = multinomial(torch.softmax(20 * scores / step, dim=1).reshape(-1), k)
+                        else:                                                              # model.py:365-379
+                            _, cand = torch.topk(scores, sample_topk, dim=1)
+                            cand = (cand + (torch.arange(k, device=dev) * V).unsqueeze(1)).reshape(-1)
+                            choice = multinomial(torch.softmax(scores.reshape(-1)[cand] / step, dim=0), k)
+                            pred = cand[choice.to(cand.device)]
+                        pred = pred.to(device=dev, dtype=torch.int64)
+                        top_scores = scores.reshape(-1)[pred]
                     keep = torch.div(pred, V, rounding_mode="floor")
                     word = torch.remainder(pred, V).unsqueeze(0)
                     top_preds = torch.cat([top_preds[:, keep], word], 0)
                     alphas = torch.cat([alphas[:, keep], alpha.unsqueeze(0)[:, keep]], 0)
-                    h, c = h[keep].contiguous(), c[keep].contiguous()
+                    h, c = h[:, keep].contiguous(), c[:, keep].contiguous()
                 complete = top_preds[step + 1] == END
                 done = complete.tolist()
                 if any(done):
@@ -222,7 +241,7 @@ class SATDecoder(nn.Module):
                             fin_ppl.append(float(torch.exp(-top_scores[i] / step)))
                     inc = ~complete
                     top_preds, alphas, top_scores = top_preds[:, inc], alphas[:, inc], top_scores[inc]
-                    h, c = h[inc].contiguous(), c[inc].contiguous()
+                    h, c = h[:, inc].contiguous(), c[:, inc].contiguous()
                     k = int(inc.sum())
                     if k == 0:
                         break
@@ -285,7 +304,7 @@ class SAT(SATDecoder, _Base):
     state-dict keys; ``train_batch`` / ``training_step`` / ``configure_optimizers`` keep their signatures.
     Construction order follows the reference (criterion, encoder, embedding, init_lstm, lstm, attention, beta,
     output) so that a seed produces the same parameter stream.  ``caption`` / ``forward`` run the reference's per-image
-    beam search ("beam" sampling) on the HIP step kernels; the nltk metrics (model.py:646-718) are out of scope."""
+    beam search (beam / multinomial / topk sampling, decoder noise) on the HIP step kernels; the nltk metrics (model.py:646-718) are out of scope."""
 
     def __init__(self, **kwargs):
         nn.Module.__init__(self)

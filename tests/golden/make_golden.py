@@ -188,6 +188,45 @@ def g7():
     save("g7_beam", **arrs)
 
 
+
+# ---------------------------------------------------------------- G9 (sampled decoding, decoder noise, stacked layers)
+G9_CASES = [  # (layers, sample_method, sample_topk, decoder_noise, beamk, max_gen_length, return_all, seed)
+    (1, "multinomial", 3, None, 3, 6, True, 11), (1, "topk", 2, None, 4, 6, False, 12), (1, "beam", 3, 0.3, 3, 5, True, 13),
+    (2, "beam", 3, None, 3, 6, True, 14), (2, "multinomial", 3, 0.2, 3, 5, True, 15), (2, "topk", 3, 0.1, 2, 6, False, 16)]
+
+
+def g9():
+    """SAT.forward with sample_method multinomial / topk (model.py:360-379), decoder_noise (model.py:322-324) and
+    decoder_layers = 2, run under torch.manual_seed(seed): the draws come from the CPU generator, so a restatement that
+    makes the same calls in the same order under the same seed reproduces them."""
+    arrs = {"cases": np.array([[c[0], ["beam", "multinomial", "topk"].index(c[1]), c[2], c[4], c[5], int(c[6]), c[7]] for c in G9_CASES]),
+            "noise": np.array([0.0 if c[3] is None else c[3] for c in G9_CASES])}
+    ann = torch.from_numpy(prng.uniform((2, 12, 2, 3), 901, 0.0, 1.5))
+    arrs["ann"] = ann
+    models = {}
+    for layers in (1, 2):
+        hp = small_hp(vocab_size=29, decoder_layers=layers)
+        model, sd = build(hp, 90 + layers)
+        model.eval()
+        models[layers] = model
+        arrs.update({"l%d.sd.%s" % (layers, k): v for k, v in sd.items()})
+    for ci, (layers, method, topk, noise, beamk, mgl, ra, seed) in enumerate(G9_CASES):
+        torch.manual_seed(seed)
+        caps, scores, alphas, ppl = models[layers].caption(ann, beamk=beamk, max_gen_length=mgl, temperature=1.0, sample_method=method,
+                                                           sample_topk=topk, decoder_noise=noise, rescore_method="LN", return_all=ra)
+        for b in range(ann.shape[0]):
+            cl = caps[b] if ra else [caps[b]]
+            sl = scores[b] if ra else [scores[b]]
+            al = alphas[b] if ra else [alphas[b]]
+            pl_ = ppl[b] if ra else [ppl[b]]
+            arrs["c%d_b%d_n" % (ci, b)] = np.int64(len(cl))
+            for j in range(len(cl)):
+                arrs["c%d_b%d_%d_tok" % (ci, b, j)] = np.array(cl[j], np.int64)
+                arrs["c%d_b%d_%d_score" % (ci, b, j)] = np.float64(sl[j])
+                arrs["c%d_b%d_%d_ppl" % (ci, b, j)] = np.float64(pl_[j])
+                arrs["c%d_b%d_%d_alpha" % (ci, b, j)] = al[j].numpy()
+    save("g9_sampled", **arrs)
+
 # ---------------------------------------------------------------- G8 (C1 decoder shapes)
 def g8():
     hp = O.default_hparams(vocab_size=6400, encoder_dim=256, embed_dim=256, attention_dim=128, decoder_dim=512, input_size=64)
@@ -246,4 +285,4 @@ if __name__ == "__main__":
     g4("layers2", 1.0, 46, decoder_layers=2)
     g4("embnorm", 1.0, 47, embed_norm=0.3)
     g4("gamma", 0.0, 48, att_gamma=0.5, B=4, R=3, T=9, H=3, W=3)
-    g6(); g7(); g8(); g_encoder()
+    g6(); g7(); g8(); g9(); g_encoder()

@@ -33,7 +33,7 @@ def test_header_symbols_exported(libpath):
     for n in names:
         assert hasattr(lib, n), "libsat_hip.so does not export %s" % n
     lib.sat_abi_version.restype = ctypes.c_int
-    assert lib.sat_abi_version() == 4
+    assert lib.sat_abi_version() == 5
 
 
 def test_binding_covers_header(libpath):
@@ -52,8 +52,13 @@ def test_argument_validation_without_gpu(libpath):
     assert b"null" in lib.sat_last_error()
     d = _lib.DecoderDims(B=0, R=1, T=4, L=1, D=1, A=1, m=1, n=1, V=1, P=0, deep_output=1, padding_idx=0)
     assert lib.sat_decoder_workspace_bytes(ctypes.byref(d)) == 0
-    d = _lib.DecoderDims(B=2, R=5, T=22, L=49, D=256, A=128, m=256, n=512, V=6400, P=210, deep_output=1, padding_idx=0)
-    assert lib.sat_decoder_workspace_bytes(ctypes.byref(d)) > 1 << 20
+    d = _lib.DecoderDims(B=2, R=5, T=22, L=49, D=256, A=128, m=256, n=512, V=6400, P=210, deep_output=1, padding_idx=0, layers=1)
+    one = lib.sat_decoder_workspace_bytes(ctypes.byref(d))
+    assert one > 1 << 20
+    d.layers = 2
+    assert lib.sat_decoder_workspace_bytes(ctypes.byref(d)) > one
+    d.layers = 0            # nn.LSTM needs at least one layer
+    assert lib.sat_decoder_workspace_bytes(ctypes.byref(d)) == 0 and b"layers" in lib.sat_last_error()
 
 
 def test_product_fails_loudly_on_cpu():

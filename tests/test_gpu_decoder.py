@@ -38,10 +38,11 @@ def hp_from_golden(g, sd):
                              encoder_dim=sd["attention.encoder_att.weight"].shape[1], attention_dim=sd["attention.encoder_att.weight"].shape[0],
                              deep_output=bool(g["hp_deep_output"]), weight_tying=bool(g["hp_weight_tying"]),
                              label_smoothing=float(g["hp_label_smoothing"]), att_gamma=float(g["hp_att_gamma"]),
-                             embed_norm=(None if float(g["hp_embed_norm"]) < 0 else float(g["hp_embed_norm"])))
+                             embed_norm=(None if float(g["hp_embed_norm"]) < 0 else float(g["hp_embed_norm"])),
+                             decoder_layers=int(g["hp_layers"]))
 
 
-GOLDEN_TAGS = ["tf1", "tf0", "tf05", "smooth", "shallow", "tied", "gamma", "embnorm"]   # layers2: not built on the HIP path this round
+GOLDEN_TAGS = ["tf1", "tf0", "tf05", "smooth", "shallow", "tied", "gamma", "embnorm", "layers2"]
 
 
 @pytest.mark.parametrize("tag", GOLDEN_TAGS)
@@ -205,3 +206,46 @@ def test_dropout_matches_oracle_with_the_same_masks(M):
     with torch.no_grad():
         _, out_e = O.training_loss(sd, hp, ann, caps, lengths, 1.0)
     close(res_e["logits_packed"], out_e["logits_packed"], what="eval logits")
+
+
+@pytest.mark.parametrize("layers,dropout", [(2, 0.0), (3, 0.0), (2, 0.3)])
+def test_stacked_lstm_layers_against_oracle(M, layers, dropout):
+    """decoder_layers > 1 (nn.LSTM num_layers, model.py:178; F3 reshape over 2*layers slabs), ragged lengths, scheduled sampling,
+    with and without dropout (same masks on both sides)."""
+    from oracle import prng, sat_oracle as O
+    from sat_amd import decoder as Dk
+    hp = O.default_hparams(vocab_size=97, encoder_dim=24, embed_dim=20, attention_dim=12, decoder_dim=16, decoder_layers=layers,
+                           dropout=dropout, embedding_dropout=dropout)
+    sd = {k: torch.from_numpy(v) for k, v in prng.decoder_state(hp, 300 + layers).items()}
+    B, R, T, Hh, Ww = 5, 3, 9, 2, 3
+    ann = torch.from_numpy(prng.uniform((B, 24, Hh, Ww), 311, 0.0, 2.0))
+    caps, lengths = prng.captions(B, R, T, 97, 312, min_len=2)
+    caps, lengths = torch.from_numpy(caps), torch.from_numpy(lengths)
+    draws = [0.9, 0.1, 0.8, 0.2, 0.7, 0.3]
+    dec = M.SATDecoder(hp).cuda(); dec.load_decoder_state(sd)
+    dec.train()
+    ann_bld = ann.permute(0, 2, 3, 1).reshape(B, Hh * Ww, 24).contiguous().cuda().requires_grad_()
+    it = iter(draws)
+    seed = 4242
+    res = dec.train_decode(ann_bld, caps.cuda(), lengths, 0.5, draw=lambda: next(it), dropout_seed=seed)
+    kw = {}
+    if dropout > 0:
+        N, T1, m, plan = B * R, T - 1, 20, res["plan"]
+        sc = lambda stream, count: Dk.dropout_scale_reference(seed, stream, np.arange(count), dropout)
+        packed = sc(2, plan.P * m).reshape(plan.P, m)
+        out = torch.zeros(T1, N, m)
+        prow = plan.prow.cpu()
+        for t in range(T1):
+            for i in range(N):
+                if prow[t, i] >= 0:
+                    out[t, i] = torch.from_numpy(packed[prow[t, i]])
+        kw["masks"] = dict(init=torch.from_numpy(sc(0, N * 24).reshape(N, 24)), emb=torch.from_numpy(sc(1, T1 * N * m).reshape(T1, N, m)), out=out)
+    sdo = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    ann_o = ann.clone().requires_grad_()
+    it2 = iter(draws)
+    loss_o, out_o = O.training_loss(sdo, hp, ann_o, caps, lengths, 0.5, draw=lambda: next(it2), **kw)
+    close(res["logits_packed"], out_o["logits_packed"], what="logits"); close(res["alphas"], out_o["alphas"], what="alphas")
+    (res["ce"] + res["ds"]).backward(); loss_o.backward()
+    close(ann_bld.grad.reshape(B, Hh, Ww, 24).permute(0, 3, 1, 2), ann_o.grad, 2e-4, "d_ann")
+    for k, p in dec.named_parameters():
+        close(p.grad, sdo[k].grad, 2e-4, k)

@@ -230,3 +230,37 @@ def test_g7_beam_search(golden_dir):
         with torch.no_grad():
             out = O.beam_search(sd, hp, ann, beamk=beamk, max_gen_length=mgl, rescore_method=rm, rescore_reward=0.5, return_all=ra)
         check_beam_against_golden(g, ci, ra, *out, tol=2e-6)
+
+
+G9_METHODS = ["beam", "multinomial", "topk"]
+
+
+def g9_cases(g):
+    out = []
+    for ci, c in enumerate(g["cases"]):
+        noise = float(g["noise"][ci])
+        out.append(dict(ci=ci, layers=int(c[0]), method=G9_METHODS[int(c[1])], topk=int(c[2]), beamk=int(c[3]), mgl=int(c[4]),
+                        return_all=bool(c[5]), seed=int(c[6]), noise=(noise if noise != 0.0 else None)))
+    return out
+
+
+def g9_state(g, layers):
+    pre = "l%d.sd." % layers
+    sd = {k[len(pre):]: torch.tensor(g[k]) for k in g.files if k.startswith(pre)}
+    hp = O.default_hparams(vocab_size=sd["embedding.weight"].shape[0], deep_output=True, decoder_layers=layers)
+    hp.decoder_dim = sd["lstm.weight_hh_l0"].shape[1]
+    return sd, hp
+
+
+def test_g9_sampled_decoding_noise_and_stacked_layers(golden_dir):
+    """model.py:360-379 (multinomial / topk sampling), 322-324 (decoder_noise) and decoder_layers=2, against the reference
+    run under torch.manual_seed: the restatement makes the same generator calls in the same order."""
+    g = load(golden_dir, "g9_sampled")
+    ann = torch.tensor(g["ann"])
+    for c in g9_cases(g):
+        sd, hp = g9_state(g, c["layers"])
+        torch.manual_seed(c["seed"])
+        with torch.no_grad():
+            out = O.beam_search(sd, hp, ann, beamk=c["beamk"], max_gen_length=c["mgl"], rescore_method="LN", return_all=c["return_all"],
+                                sample_method=c["method"], sample_topk=c["topk"], decoder_noise=c["noise"])
+        check_beam_against_golden(g, c["ci"], c["return_all"], *out, tol=2e-6)
