@@ -14,64 +14,10 @@
 // transposed-read weight-gradient forms), register-staged double buffer.
 #include <stdlib.h>
 
-#include "gemm.h"
+#include "gemm_bf16_common.h"
 #include "profile.h"
 
 namespace sat {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int NT = 256;
-
-struct BArgs {
-    const void* A; long lda; const int* a_rows;
-    const void* B; long ldb;
-    void* C; long ldc; const int* c_rows;
-    int M, N, K;
-    int accumulate, epi;
-    const float* bias; const float* e0; long lde0; int c0, c1;
-    ConvGeom g;
-    int kchunk, nsplit;
-    float* slab;
-    int wide_store;       // bf16 output staged through LDS and written 16 bytes per lane
-};
-
-template <typename T> struct VecN { static constexpr int n = 16 / sizeof(T); };
-
-__device__ __forceinline__ float ep_value(const BArgs& a, int row, int col, float v) {
-    switch (a.epi) {
-        case EPI_BIAS: v += a.bias[col]; break;
-        case EPI_BIAS_SIGMOID_RANGE:
-            if (a.bias) v += a.bias[col];
-            if (col >= a.c0 && col < a.c1) v = fast_sigmoid(v);
-            break;
-        case EPI_ADD_TANH: { long er = a.a_rows ? (long)a.a_rows[row] : (long)row; v = fast_tanh(v + a.e0[er * a.lde0 + col]); } break;
-        case EPI_MUL_DTANH: { float u = a.e0[(long)row * a.lde0 + col]; v *= (1.0f - u * u); } break;
-        case EPI_BIAS_RELU: v = fmaxf(0.0f, v + a.bias[col]); break;
-        default: break;
-    }
-    return v;
-}
-
-// parity-class data gradient: GEMM row (n, h', w') -> NHWC pixel (n, 2h'+ph, 2w'+pw)
-__device__ __forceinline__ long class_row(const BArgs& a, int row) {
-    const ConvGeom& g = a.g;
-    int hw = g.Hc * g.Wc; int n = row / hw; int r = row - n * hw; int hc = r / g.Wc, wc = r - hc * g.Wc;
-    return ((long)n * g.H + 2 * hc + g.ph) * g.W + 2 * wc + g.pw;
-}
-
-template <typename TC>
-__device__ __forceinline__ void put(const BArgs& a, int row, int col, float v) {
-    long orow = row;
-    if (a.g.cls) orow = class_row(a, row);
-    if (a.c_rows) { int r = a.c_rows[row]; if (r < 0) return; orow = r; }
-    TC* p = reinterpret_cast<TC*>(a.C) + orow * a.ldc + col;
-    if (a.accumulate) v += (float)*p;
-    *p = (TC)ep_value(a, row, col, v);
-}
 
 // ---- 16-byte gathers (raw bits; zero when out of range) ---------------------------------------
 struct RowCtx { long base; int n, y0, x0; bool ok; };
@@ -200,18 +146,8 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(BArgs a) {
     __shared__ KEnt ktab[2][KB];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // XCD-aware tile order: the dispatcher deals workgroups round-robin over the 8 XCDs (each with its own L2), so
-    // workgroups i and i+8 share an L2.  Give every XCD a contiguous run of logical tiles (x fastest): the column
-    // tiles that re-read the same activation rows then hit one L2 instead of eight.  Bijective for any grid size;
-    // placement only affects speed, never results.
     int bx, by, bz;
-    {
-        const unsigned total = gridDim.x * gridDim.y * gridDim.z;
-        const unsigned orig = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        const unsigned q = total >> 3, r = total & 7, xcd = orig & 7, idx = orig >> 3;
-        const unsigned lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        bx = lin % gridDim.x; const unsigned t2 = lin / gridDim.x; by = t2 % gridDim.y; bz = t2 / gridDim.y;
-    }
+    xcd_tile(bx, by, bz);
     const int bm = by * BM, bn = bx * BN;
     const int kbeg = bz * a.kchunk;
     const int kend = min(a.K, kbeg + a.kchunk);
@@ -317,79 +253,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(BArgs a) {
         }
     }
 
-    if (sizeof(TC) == 2 && a.wide_store) {
-        // bf16 result: the MFMA C layout gives each lane one column, i.e. 2-byte stores.  Stage the tile in LDS
-        // (the operand buffers are free now) and write whole 16-byte row segments instead.
-        constexpr int LDC = BN + 8;
-        static_assert(BM * LDC <= 2 * STAGE, "C tile must fit the staging buffers");
-        __bf16* cs = smem;
-        __syncthreads();
-        // Neighbouring lanes hold neighbouring columns.  Registers r, r+1 are rows R, R+1: the even lane of a pair
-        // collects both columns of row R, the odd lane both columns of row R+1 (one DPP swap), so every lane writes
-        // one packed 4-byte LDS word per register pair instead of two 2-byte ones.
-        const bool odd = lane & 1;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const int lr0 = wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, lc = wn + j * 32 + li;
-                    float v0 = acc[i][j][r], v1 = acc[i][j][r + 1];
-                    if (a.epi != EPI_NONE && bn + lc < a.N) {
-                        if (bm + lr0 < a.M) v0 = ep_value(a, bm + lr0, bn + lc, v0);
-                        if (bm + lr0 + 1 < a.M) v1 = ep_value(a, bm + lr0 + 1, bn + lc, v1);
-                    }
-                    const float give = odd ? v0 : v1;
-                    const float got = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(give), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true));
-                    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-                    bf16x2 pk;
-                    if (odd) { pk[0] = (__bf16)got; pk[1] = (__bf16)v1; } else { pk[0] = (__bf16)v0; pk[1] = (__bf16)got; }
-                    *reinterpret_cast<bf16x2*>(cs + (lr0 + (odd ? 1 : 0)) * LDC + (lc & ~1)) = pk;
-                }
-        __syncthreads();
-        constexpr int VPR = BN / 8;
-#pragma unroll
-        for (int j = 0; j < BM * VPR / NT; ++j) {
-            int v = tid + j * NT, lr = v / VPR, lc = (v % VPR) * 8;
-            int row = bm + lr, col = bn + lc;
-            if (row < a.M && col < a.N) {
-                bf16x8 o = *reinterpret_cast<const bf16x8*>(cs + lr * LDC + lc);
-                const long orow = a.g.cls ? class_row(a, row) : (long)row;
-                __bf16* dst = reinterpret_cast<__bf16*>(a.C) + orow * a.ldc + col;
-                if (a.accumulate) {
-                    bf16x8 old = *reinterpret_cast<const bf16x8*>(dst);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (__bf16)((float)o[e] + (float)old[e]);
-                }
-                *reinterpret_cast<bf16x8*>(dst) = o;
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int row = bm + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                int col = bn + wn + j * 32 + li;
-                if (row < a.M && col < a.N) {
-                    if (a.nsplit > 1) a.slab[((long)bz * a.M + row) * a.N + col] = acc[i][j][r];
-                    else put<TC>(a, row, col, acc[i][j][r]);
-                }
-            }
-}
-
-template <typename TC>
-__global__ void splitk_reduce_b_kernel(BArgs a) {
-    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    long total = (long)a.M * a.N;
-    if (idx >= total) return;
-    float v = 0.f;
-    for (int z = 0; z < a.nsplit; ++z) v += a.slab[(long)z * total + idx];
-    put<TC>(a, (int)(idx / a.N), (int)(idx % a.N), v);
+    store_tile<BM, BN, TC, 2 * STAGE>(a, acc, smem, bm, bn, bz, wm, wn, tid, lane);
 }
 
 static const char* mname(int am, int bm) {
@@ -407,8 +271,12 @@ template <int BM, int BN, int AM, int BMo, typename TA, typename TB, typename TC
 static int runb(const BArgs& k, hipStream_t st) {
     constexpr int KB = KTile<AM>::v;
     dim3 grid(cdiv(k.N, BN), cdiv(k.M, BM), k.nsplit);
-    char pname[96];
-    if (profile_enabled()) snprintf(pname, sizeof pname, "gemm_bf16_%s_%dx%d_%s", mname(AM, BMo), BM, BN, sizeof(TA) == 2 ? "b" : "f");
+    char pname[128];
+    if (profile_enabled()) {
+        static const bool shapes = getenv("SAT_PROFILE_SHAPES") != nullptr;      // dev: one profile line per problem shape
+        if (shapes) snprintf(pname, sizeof pname, "gemm_bf16_%s_%dx%d_%s M%d N%d K%d z%d", mname(AM, BMo), BM, BN, sizeof(TA) == 2 ? "b" : "f", k.M, k.N, k.K, k.nsplit);
+        else snprintf(pname, sizeof pname, "gemm_bf16_%s_%dx%d_%s", mname(AM, BMo), BM, BN, sizeof(TA) == 2 ? "b" : "f");
+    }
     ProfScope prof(pname, 2.0 * k.M * k.N * k.K, (double)sizeof(TA) * k.M * k.K + (double)sizeof(TB) * k.N * k.K + (double)sizeof(TC) * k.M * k.N, st);
     hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, KB, AM, BMo, TA, TB, TC>), grid, dim3(NT), 0, st, k);
     SAT_TRY(launch_ok("gemm_bf16_kernel"));
@@ -469,7 +337,9 @@ int launch_gemm_bf16(const GemmArgs& g, hipStream_t st) {
         // re-read: 8 bytes per output element per split) must stay a fraction of the operand bytes
         static const int target = getenv("SAT_SPLIT_TARGET") ? atoi(getenv("SAT_SPLIT_TARGET")) : 768;
         static const int frac = getenv("SAT_SPLIT_FRAC") ? atoi(getenv("SAT_SPLIT_FRAC")) : 8;
-        int want = (int)((target + blocks - 1) / blocks), maxs = g.K / (8 * KB);
+        static const int target128 = getenv("SAT_SPLIT_TARGET128") ? atoi(getenv("SAT_SPLIT_TARGET128")) : 384;
+        const int tgt = (BMt == 128) ? target128 : target;      // measured on the C2 step: 128-wide tiles want ~1.5 workgroups per CU, 64-wide ~3
+        int want = (int)((tgt + blocks - 1) / blocks), maxs = g.K / (8 * KB);
         double in_bytes = ((double)g.M + g.N) * g.K * 2.0;
         int lim = (int)(in_bytes / ((double)frac * g.M * g.N)); if (lim < 4) lim = 4;
         ns = want < maxs ? want : maxs; if (ns > lim) ns = lim; if (ns > 256) ns = 256; if (ns < 1) ns = 1;
@@ -481,8 +351,15 @@ int launch_gemm_bf16(const GemmArgs& g, hipStream_t st) {
     k.wide_store = (g.c_bf16 && !g.c_rows && k.nsplit == 1 && g.N % 8 == 0 && g.ldc % 8 == 0 && al16(g.C) &&
                     (g.epi == EPI_NONE || g.epi == EPI_BIAS || g.epi == EPI_BIAS_RELU)) ? 1 : 0;
 
+    static const bool log_shapes = getenv("SAT_LOG_GEMM") != nullptr;     // dev: one stderr line per launch, in launch order
+    if (log_shapes) fprintf(stderr, "GEMMLOG am=%d bm=%d M=%d N=%d K=%d ns=%d acc=%d types=%d%d%d epi=%d\n", g.amode, g.bmode, g.M, g.N, g.K, k.nsplit,
+                            g.accumulate, g.a_bf16, g.b_bf16, g.c_bf16, g.epi);
 #define SAT_BCASE(AMV, BMV, TA, TB, TC) return runb_tiles<AMV, BMV, TA, TB, TC>(k, BMt, st);
     const bool ab = g.a_bf16, bb = g.b_bf16, cb = g.c_bf16;
+    if (ab && bb) {         // bf16 operands in HBM: direct-to-LDS staging where the form allows it
+        const int r = launch_gemm_glds(k, g.amode, g.bmode, cb, BMt, st);
+        if (r != -1) return r;
+    }
     if (ab && bb) {         // encoder: bf16 activations / filters
         if (g.amode == A_CONV_FWD && g.bmode == B_ROW && cb) SAT_BCASE(A_CONV_FWD, B_ROW, __bf16, __bf16, __bf16)
         if (g.amode == A_ROW && g.bmode == B_ROW && cb) SAT_BCASE(A_ROW, B_ROW, __bf16, __bf16, __bf16)

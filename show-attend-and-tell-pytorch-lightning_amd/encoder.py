@@ -131,7 +131,7 @@ def conv_wgrad(dy, x, w, stride, pad):
     K, _, R, S = w.shape
     g = _geom(N, H, W, Cc, K, R, S, stride, pad)
     lib = L.lib()
-    nbytes = max(lib.sat_conv2d_wgrad_slab_bytes(C.byref(g)), 16 << 20)
+    nbytes = max(lib.sat_conv2d_wgrad_slab_bytes(C.byref(g)), 128 << 20)
     slab = _slab(x.device, nbytes)
     dw = torch.empty(K, R, S, Cc, dtype=torch.float32, device=x.device)       # KRSC
     fn = lib.sat_conv2d_wgrad_bf16 if _is_bf(x) else lib.sat_conv2d_wgrad
@@ -353,7 +353,7 @@ class EncoderFn(torch.autograd.Function):
                 D = enc.proj.out_channels; Cc = t["trunk"].shape[-1]
                 db = cast_bf16(d.reshape(-1, D))
                 dw = torch.empty(D, Cc, dtype=torch.float32, device=d.device)
-                gemm(db, t["trunk"].view(-1, Cc), amode=1, bmode=1, out=dw, slab=_slab(d.device, 16 << 20), bf16_mfma=True)
+                gemm(db, t["trunk"].view(-1, Cc), amode=1, bmode=1, out=dw, slab=_slab(d.device, 128 << 20), bf16_mfma=True)
                 grads[enc.proj.weight] = dw.view(D, Cc, 1, 1)
                 if enc.trunk_trainable:
                     dtr = torch.empty(t["trunk"].shape, dtype=BF16, device=d.device)

@@ -215,7 +215,11 @@ def test_whole_encoder_against_oracle(E, arch, es, px):
 
 # ----------------------------------------------------------------------------- bf16 storage convolutions
 BCONVS = [(2, 9, 9, 8, 16, 3, 1, 1), (2, 10, 11, 16, 24, 3, 2, 1), (3, 8, 8, 16, 8, 1, 1, 0), (2, 9, 9, 8, 16, 1, 2, 0),
-          (2, 20, 20, 8, 16, 7, 2, 3), (1, 16, 16, 64, 64, 3, 1, 1), (4, 14, 14, 32, 128, 3, 2, 1), (8, 16, 16, 64, 256, 1, 1, 0)]
+          (2, 20, 20, 8, 16, 7, 2, 3), (1, 16, 16, 64, 64, 3, 1, 1), (4, 14, 14, 32, 128, 3, 2, 1), (8, 16, 16, 64, 256, 1, 1, 0),
+          # channel counts that are multiples of 64 take the direct-to-LDS kernel (csrc/gemm_glds.hip): several k-tiles per
+          # tap, stride-2 parity classes, ragged pixel counts and filter counts, split-K weight gradients on 128-wide tiles
+          (2, 12, 12, 128, 64, 3, 1, 1), (2, 13, 11, 64, 128, 3, 2, 1), (3, 9, 9, 192, 64, 1, 1, 0), (2, 8, 8, 64, 72, 3, 1, 1),
+          (8, 32, 32, 128, 128, 3, 1, 1), (5, 14, 14, 256, 512, 1, 2, 0), (4, 16, 16, 128, 256, 3, 1, 1)]
 
 
 @pytest.mark.parametrize("N,H,W,C,K,R,stride,pad", BCONVS)
