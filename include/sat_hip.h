@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SAT_HIP_ABI_VERSION 5
+#define SAT_HIP_ABI_VERSION 6
 
 int sat_abi_version(void);
 const char* sat_last_error(void);
@@ -220,12 +220,16 @@ int sat_bn_train_bwd(const float* dy, const float* x, const float* y, int64_t ro
  * gradients stay fp32, reductions accumulate in double) */
 int sat_bn_train_fwd_t(int32_t dtype, const void* x, int64_t rows, int32_t C, const float* gamma, const float* beta, float eps, float momentum,
                        float* running_mean, float* running_var, float* save_mean, float* save_invstd,
-                       const void* residual, int32_t relu, void* y, float* scratch, void* stream);
+                       const void* residual, int32_t relu, void* y,
+                       uint8_t* relu_mask /* or NULL; rows*C/8 bytes, C % 8 == 0: bit i of byte b = (element 8b+i of y > 0) */,
+                       float* scratch, void* stream);
 int sat_bn_eval_fwd_t(int32_t dtype, const void* x, int64_t rows, int32_t C, const float* running_mean, const float* running_var, float eps,
                       const float* gamma, const float* beta, const void* residual, int32_t relu, void* y, void* stream);
 int sat_bn_train_bwd_t(int32_t dtype, const void* dy, const void* x, const void* y, int64_t rows, int32_t C, const float* save_mean,
                        const float* save_invstd, const float* gamma, int32_t relu, void* dx, float* dgamma, float* dbeta,
-                       void* dres, int32_t dres_accumulate, float* scratch, void* stream);
+                       void* dres, int32_t dres_accumulate,
+                       const uint8_t* relu_mask /* or NULL: the forward's sign mask, read instead of y (which may then be NULL) */,
+                       float* scratch, void* stream);
 int sat_maxpool3x3s2_fwd_t(int32_t dtype, const void* x, void* y, uint8_t* argmax, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
 int sat_maxpool3x3s2_bwd_t(int32_t dtype, const void* dy, const uint8_t* argmax, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
 /* bf16 plumbing: fp32 -> bf16 copies of filters/gradients (n % 4 == 0); Normalize fused with NCHW -> NHWC and

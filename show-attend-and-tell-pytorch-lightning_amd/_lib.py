@@ -116,9 +116,9 @@ SYMBOLS.update({
     "sat_bn_eval_fwd": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _f, _vp, _vp, _vp, _i32, _vp, _vp]),
     "sat_colsum": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp]),
     "sat_bn_train_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
-    "sat_bn_train_fwd_t": (C.c_int, [_i32, _vp, _i64, _i32, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "sat_bn_train_fwd_t": (C.c_int, [_i32, _vp, _i64, _i32, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "sat_bn_eval_fwd_t": (C.c_int, [_i32, _vp, _i64, _i32, _vp, _vp, _f, _vp, _vp, _vp, _i32, _vp, _vp]),
-    "sat_bn_train_bwd_t": (C.c_int, [_i32, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "sat_bn_train_bwd_t": (C.c_int, [_i32, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "sat_maxpool3x3s2_fwd_t": (C.c_int, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "sat_maxpool3x3s2_bwd_t": (C.c_int, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "sat_cast_f32_to_bf16": (C.c_int, [_vp, _vp, _i64, _vp]),
@@ -175,8 +175,8 @@ def lib():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(handle, name)          # AttributeError if the export is missing
             fn.restype, fn.argtypes = res, args
-        if handle.sat_abi_version() != 5:
-            raise SatHipError("libsat_hip.so ABI version %d != 5 (rebuild: make -C csrc)" % handle.sat_abi_version())
+        if handle.sat_abi_version() != 6:
+            raise SatHipError("libsat_hip.so ABI version %d != 6 (rebuild: make -C csrc)" % handle.sat_abi_version())
         _lib = handle
     return _lib
 

@@ -3,6 +3,7 @@
 // gradient, weight gradient); this file adds the memory-bound layers around them: input
 // normalisation (model.py:59), train-mode BatchNorm (+ReLU, +residual) forward/backward,
 // 3x3/2 max-pool, adaptive average pool / bilinear resize of the `encoder_size` option (readme.md:118-121).
+#include <stdlib.h>
 #include "../../include/sat_hip.h"
 #include "common.h"
 #include "gemm.h"
@@ -95,8 +96,27 @@ template <> __device__ __forceinline__ void ldv<__bf16, 8>(const __bf16* p, long
     for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
 }
 
+// 16 packed bytes -> N floats (fp32: 4, bf16: 8)
+template <typename T, int N> __device__ __forceinline__ void unpack(const uint4& r, float (&o)[N]);
+template <> __device__ __forceinline__ void unpack<float, 4>(const uint4& r, float (&o)[4]) {
+    o[0] = __uint_as_float(r.x); o[1] = __uint_as_float(r.y); o[2] = __uint_as_float(r.z); o[3] = __uint_as_float(r.w);
+}
+template <> __device__ __forceinline__ void unpack<__bf16, 8>(const uint4& r, float (&o)[8]) {
+    o[0] = __uint_as_float(r.x << 16); o[1] = __uint_as_float(r.x & 0xFFFF0000u); o[2] = __uint_as_float(r.y << 16); o[3] = __uint_as_float(r.y & 0xFFFF0000u);
+    o[4] = __uint_as_float(r.z << 16); o[5] = __uint_as_float(r.z & 0xFFFF0000u); o[6] = __uint_as_float(r.w << 16); o[7] = __uint_as_float(r.w & 0xFFFF0000u);
+}
+// ReLU sign mask written by the forward BatchNorm+ReLU: bit i of byte b <-> element 8b + i of the (rows x C) activation.
+// The backward passes read it instead of the bf16 / fp32 output tensor (1/16 .. 1/32 of the bytes).  N = elements per vector.
+template <int N>
+__device__ __forceinline__ void mask_to_floats(const unsigned char* __restrict__ m, long iv, float (&o)[N]) {
+    const unsigned b = (N == 8) ? m[iv] : (unsigned)(m[iv >> 1] >> ((iv & 1) * 4));
+#pragma unroll
+    for (int i = 0; i < N; ++i) o[i] = (b >> i) & 1u ? 1.f : 0.f;
+}
+
 template <int MODE, typename T>
 __global__ __launch_bounds__(256) void bn_colstats_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
+                                                          const unsigned char* __restrict__ rmask,
                                                           const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
                                                           long rows, int C, int CV, long rows_per, double* __restrict__ part0, double* __restrict__ part1) {
     constexpr int E = EPT<T>::n;
@@ -116,25 +136,53 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const T* __restrict__ 
         } else ldv<T, E>(x, cv, mu);                 // shift = row 0
         long r0 = (long)blockIdx.y * rows_per, r1 = r0 + rows_per; if (r1 > rows) r1 = rows;
         long r = r0 + tr;
-        for (; r + 3L * RL < r1; r += 4L * RL) {     // 4 independent 16-byte loads in flight per operand
-            float xv[4][E], gv[4][E], yv[4][E];
+        for (; r + 3L * RL < r1; r += 4L * RL) {     // 4 independent 16-byte loads in flight per operand, kept packed until used
+            uint4 xr[4], gr[4], yr[4]; unsigned mb[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                ldv<T, E>(x, (r + (long)u * RL) * CVT + cv, xv[u]);
-                if (MODE == 1) { ldv<T, E>(dy, (r + (long)u * RL) * CVT + cv, gv[u]); if (relu) ldv<T, E>(y, (r + (long)u * RL) * CVT + cv, yv[u]); }
+                const long iv = (r + (long)u * RL) * CVT + cv;
+                xr[u] = reinterpret_cast<const uint4*>(x)[iv];
+                if (MODE == 1) {
+                    gr[u] = reinterpret_cast<const uint4*>(dy)[iv];
+                    if (relu) {
+                        if (rmask) mb[u] = (E == 8) ? rmask[iv] : (unsigned)(rmask[iv >> 1] >> ((iv & 1) * 4));
+                        else yr[u] = reinterpret_cast<const uint4*>(y)[iv];
+                    }
+                }
             }
+            // the four rows of a group are summed in fp32 (4 terms: ~1 ulp), the groups in double
+            float s0[E], s1[E];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int i = 0; i < E; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float xv[E], gv[E], yv[E];
+                unpack<T, E>(xr[u], xv);
+                if (MODE == 1) {
+                    unpack<T, E>(gr[u], gv);
+                    if (relu) {
+                        if (rmask) {
+#pragma unroll
+                            for (int i = 0; i < E; ++i) yv[i] = (mb[u] >> i) & 1u ? 1.f : 0.f;
+                        } else unpack<T, E>(yr[u], yv);
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < E; ++i) {
-                    if (MODE == 0) { float d = xv[u][i] - mu[i]; a0[i] += d; a1[i] += (double)d * d; }
-                    else { float g = (relu && !(yv[u][i] > 0.f)) ? 0.f : gv[u][i]; a0[i] += g; a1[i] += (double)g * ((xv[u][i] - mu[i]) * is[i]); }
+                    if (MODE == 0) { float d = xv[i] - mu[i]; s0[i] += d; s1[i] = fmaf(d, d, s1[i]); }
+                    else { float g = (relu && !(yv[i] > 0.f)) ? 0.f : gv[i]; s0[i] += g; s1[i] = fmaf(g, (xv[i] - mu[i]) * is[i], s1[i]); }
                 }
+            }
+#pragma unroll
+            for (int i = 0; i < E; ++i) { a0[i] += (double)s0[i]; a1[i] += (double)s1[i]; }
         }
         for (; r < r1; r += RL) {
             float xv[E], gv[E], yv[E];
             ldv<T, E>(x, r * CVT + cv, xv);
-            if (MODE == 1) { ldv<T, E>(dy, r * CVT + cv, gv); if (relu) ldv<T, E>(y, r * CVT + cv, yv); }
+            if (MODE == 1) {
+                ldv<T, E>(dy, r * CVT + cv, gv);
+                if (relu) { if (rmask) mask_to_floats<E>(rmask, r * CVT + cv, yv); else ldv<T, E>(y, r * CVT + cv, yv); }
+            }
 #pragma unroll
             for (int i = 0; i < E; ++i) {
                 if (MODE == 0) { float d = xv[i] - mu[i]; a0[i] += d; a1[i] += (double)d * d; }
@@ -200,52 +248,83 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part0, const d
     if (lane == 0) { dbeta[c] = (float)s; dgamma[c] = (float)q; }
 }
 
-// y = (x - mean) * invstd * gamma + beta (+ residual) (ReLU).  eval mode (var_eps >= 0) passes the running
-// variance in `invstd` and the kernel takes 1/sqrt(var + eps) itself.
-template <typename T>
+// y = (x - mean) * invstd * gamma + beta (+ residual) (ReLU), 16 bytes per lane (E = 4 fp32 / 8 bf16 elements).
+// eval mode (var_eps >= 0) passes the running variance in `invstd` and the kernel takes 1/sqrt(var + eps) itself.
+template <typename T, int N> __device__ __forceinline__ uint4 pack(const float (&v)[N]);
+template <> __device__ __forceinline__ uint4 pack<float, 4>(const float (&v)[4]) {
+    return make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+}
+template <> __device__ __forceinline__ uint4 pack<__bf16, 8>(const float (&v)[8]) {
+    typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+    b8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (__bf16)v[i];
+    return *reinterpret_cast<uint4*>(&o);
+}
+template <typename T, bool EVAL>
 __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
                                 const float* __restrict__ gamma, const float* __restrict__ beta, const T* __restrict__ res, int relu,
-                                T* __restrict__ y, long total4, int C4, float var_eps) {
+                                T* __restrict__ y, unsigned char* __restrict__ rmask, long totalv, int CV, float var_eps) {
+    constexpr int E = EPT<T>::n;
     long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total4) return;
-    int c4 = (int)(e % C4);
-    float4 xv = ld4<T>(x, e);
-    float4 mu = reinterpret_cast<const float4*>(mean)[c4], is = reinterpret_cast<const float4*>(invstd)[c4];
-    if (var_eps >= 0.f) { is.x = 1.f / sqrtf(is.x + var_eps); is.y = 1.f / sqrtf(is.y + var_eps); is.z = 1.f / sqrtf(is.z + var_eps); is.w = 1.f / sqrtf(is.w + var_eps); }
-    float4 g = reinterpret_cast<const float4*>(gamma)[c4], b = reinterpret_cast<const float4*>(beta)[c4];
-    float4 o;
-    o.x = (xv.x - mu.x) * is.x * g.x + b.x; o.y = (xv.y - mu.y) * is.y * g.y + b.y;
-    o.z = (xv.z - mu.z) * is.z * g.z + b.z; o.w = (xv.w - mu.w) * is.w * g.w + b.w;
-    if (res) { float4 r = ld4<T>(res, e); o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
-    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-    st4<T>(y, e, o);
+    if (e >= totalv) return;
+    const int c0 = (int)(e % CV) * E;
+    float xv[E], rv[E], o[E];
+    unpack<T, E>(reinterpret_cast<const uint4*>(x)[e], xv);
+    if (res) unpack<T, E>(reinterpret_cast<const uint4*>(res)[e], rv);
+    unsigned bits = 0;
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        float is = invstd[c0 + i];
+        if (EVAL) is = 1.f / sqrtf(is + var_eps);      // eval mode only: the training pass gets invstd from the finalize kernel
+        float v = (xv[i] - mean[c0 + i]) * is * gamma[c0 + i] + beta[c0 + i];
+        if (res) v += rv[i];
+        bits |= (v > 0.f ? 1u : 0u) << i;
+        o[i] = relu ? fmaxf(v, 0.f) : v;
+    }
+    if (rmask) {
+        if (E == 8) rmask[e] = (unsigned char)bits;
+        else {               // fp32: two lanes make a byte (totalv is even: the mask needs C % 8 == 0)
+            const unsigned other = __shfl_xor(bits, 1, 64);
+            if (!(threadIdx.x & 1)) rmask[e >> 1] = (unsigned char)(bits | (other << 4));
+        }
+    }
+    reinterpret_cast<uint4*>(y)[e] = pack<T, E>(o);
 }
 
 // dx = gamma * invstd * (g - dbeta/M - xhat * dgamma/M);  dres (optional) receives g (the masked upstream gradient)
 template <typename T>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
-                                    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                    const float* __restrict__ dbeta, const float* __restrict__ dgamma, int relu, float inv_rows,
-                                    T* __restrict__ dx, T* __restrict__ dres, int dres_accumulate, long total4, int C4) {
+                                    const unsigned char* __restrict__ rmask, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const float* __restrict__ gamma, const float* __restrict__ dbeta, const float* __restrict__ dgamma, int relu,
+                                    float inv_rows, T* __restrict__ dx, T* __restrict__ dres, int dres_accumulate, long totalv, int CV) {
+    constexpr int E = EPT<T>::n;
     long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total4) return;
-    int c4 = (int)(e % C4);
-    float4 xv = ld4<T>(x, e);
-    float4 g = ld4<T>(dy, e);
-    if (relu) { float4 yv = ld4<T>(y, e);
-        g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f; }
-    float4 mu = reinterpret_cast<const float4*>(mean)[c4], is = reinterpret_cast<const float4*>(invstd)[c4];
-    float4 ga = reinterpret_cast<const float4*>(gamma)[c4];
-    float4 db = reinterpret_cast<const float4*>(dbeta)[c4], dg = reinterpret_cast<const float4*>(dgamma)[c4];
-    float4 o;
-    o.x = ga.x * is.x * (g.x - db.x * inv_rows - (xv.x - mu.x) * is.x * dg.x * inv_rows);
-    o.y = ga.y * is.y * (g.y - db.y * inv_rows - (xv.y - mu.y) * is.y * dg.y * inv_rows);
-    o.z = ga.z * is.z * (g.z - db.z * inv_rows - (xv.z - mu.z) * is.z * dg.z * inv_rows);
-    o.w = ga.w * is.w * (g.w - db.w * inv_rows - (xv.w - mu.w) * is.w * dg.w * inv_rows);
-    st4<T>(dx, e, o);
+    if (e >= totalv) return;
+    const int c0 = (int)(e % CV) * E;
+    float xv[E], g[E], yv[E], o[E];
+    unpack<T, E>(reinterpret_cast<const uint4*>(x)[e], xv);
+    unpack<T, E>(reinterpret_cast<const uint4*>(dy)[e], g);
+    if (relu) {
+        if (rmask) mask_to_floats<E>(rmask, e, yv);
+        else unpack<T, E>(reinterpret_cast<const uint4*>(y)[e], yv);
+#pragma unroll
+        for (int i = 0; i < E; ++i) g[i] = yv[i] > 0.f ? g[i] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        const float is = invstd[c0 + i];
+        o[i] = gamma[c0 + i] * is * (g[i] - dbeta[c0 + i] * inv_rows - (xv[i] - mean[c0 + i]) * is * dgamma[c0 + i] * inv_rows);
+    }
+    reinterpret_cast<uint4*>(dx)[e] = pack<T, E>(o);
     if (dres) {
-        if (dres_accumulate) { float4 r = ld4<T>(dres, e); g.x += r.x; g.y += r.y; g.z += r.z; g.w += r.w; }
-        st4<T>(dres, e, g);
+        if (dres_accumulate) {
+            float r[E];
+            unpack<T, E>(reinterpret_cast<const uint4*>(dres)[e], r);
+#pragma unroll
+            for (int i = 0; i < E; ++i) g[i] += r[i];
+        }
+        reinterpret_cast<uint4*>(dres)[e] = pack<T, E>(g);
     }
 }
 
@@ -469,7 +548,8 @@ static void bn_grid(long rows, int C, int E, int& CV, long& rows_per, int& npart
     while (256 % CV) --CV;                      // CV must divide 256
     int RL = 256 / CV;
     int colblocks = cdiv(CVT, CV);
-    long want = 2048 / colblocks; if (want < 1) want = 1;         // ~8 blocks per CU
+    static const long target = getenv("SAT_BN_BLOCKS") ? atol(getenv("SAT_BN_BLOCKS")) : 512;
+    long want = target / colblocks; if (want < 1) want = 1;         // ~2 blocks per CU: measured best on the C2 step (fewer, longer blocks; fewer partials to finalise)
     rows_per = cdiv(rows, want);
     long minrows = (long)RL * 8; if (rows_per < minrows) rows_per = minrows;
     nparts = cdiv(rows, rows_per);
@@ -487,20 +567,21 @@ extern "C" size_t sat_bn_scratch_bytes(int64_t rows, int32_t C) {
 template <typename T>
 static int bn_train_fwd_t(const T* x, int64_t rows, int32_t C, const float* gamma, const float* beta, float eps, float momentum,
                           float* running_mean, float* running_var, float* save_mean, float* save_invstd, const T* residual, int32_t relu,
-                          T* y, float* scratch, hipStream_t st) {
+                          T* y, uint8_t* relu_mask, float* scratch, hipStream_t st) {
     if (!x || !gamma || !beta || !save_mean || !save_invstd || !y || !scratch) return fail(SAT_EINVAL, "bn_train_fwd: null pointer");
     SAT_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, "bn_train_fwd: rows=%ld C=%d (C must be a multiple of 4)", (long)rows, C);
     constexpr int E = EPT<T>::n;
     SAT_REQUIRE(C % E == 0, "bn_train_fwd: C=%d must be a multiple of %d for this storage type", C, E);
+    SAT_REQUIRE(!relu_mask || (relu && C % 8 == 0), "bn_train_fwd: the ReLU sign mask needs relu and C %% 8 == 0 (C=%d)", C);
     int CV, nparts; long rp; bn_grid(rows, C, E, CV, rp, nparts);
     double* p0 = reinterpret_cast<double*>(scratch); double* p1 = p0 + (long)nparts * C;
     hipLaunchKernelGGL((bn_colstats_kernel<0, T>), dim3(cdiv(C / E, CV), nparts), dim3(256), 0, st, x, (const T*)nullptr, (const T*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, 0, (long)rows, C, CV, rp, p0, p1);
+                       (const unsigned char*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, (long)rows, C, CV, rp, p0, p1);
     SAT_TRY(launch_ok("bn_colstats<0>"));
     hipLaunchKernelGGL(bn_fwd_finalize_kernel<T>, dim3(cdiv(C, 4)), dim3(256), 0, st, p0, p1, x, nparts, C, (long)rows, eps, momentum, save_mean, save_invstd, running_mean, running_var);
     SAT_TRY(launch_ok("bn_fwd_finalize"));
-    long total4 = rows * (C / 4);
-    hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(cdiv(total4, 256)), dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta, residual, relu, y, total4, C / 4, -1.0f);
+    long totalv = rows * (C / E);
+    hipLaunchKernelGGL((bn_apply_kernel<T, false>), dim3(cdiv(totalv, 256)), dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta, residual, relu, y, relu_mask, totalv, C / E, -1.0f);
     return launch_ok("bn_apply");
 }
 
@@ -509,29 +590,32 @@ static int bn_eval_fwd_t(const T* x, int64_t rows, int32_t C, const float* runni
                          const float* gamma, const float* beta, const T* residual, int32_t relu, T* y, hipStream_t st) {
     if (!x || !running_mean || !running_var || !gamma || !beta || !y) return fail(SAT_EINVAL, "bn_eval_fwd: null pointer");
     SAT_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && eps >= 0.f, "bn_eval_fwd: bad shape");
-    long total4 = rows * (C / 4);
-    hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(cdiv(total4, 256)), dim3(256), 0, st, x, running_mean, running_var, gamma, beta, residual, relu, y, total4, C / 4, eps);
+    constexpr int E = EPT<T>::n;
+    SAT_REQUIRE(C % E == 0, "bn_eval_fwd: C=%d must be a multiple of %d for this storage type", C, E);
+    long totalv = rows * (C / E);
+    hipLaunchKernelGGL((bn_apply_kernel<T, true>), dim3(cdiv(totalv, 256)), dim3(256), 0, st, x, running_mean, running_var, gamma, beta, residual, relu, y, (unsigned char*)nullptr, totalv, C / E, eps);
     return launch_ok("bn_apply(eval)");
 }
 
 template <typename T>
 static int bn_train_bwd_t(const T* dy, const T* x, const T* y, int64_t rows, int32_t C, const float* save_mean, const float* save_invstd,
                           const float* gamma, int32_t relu, T* dx, float* dgamma, float* dbeta, T* dres, int32_t dres_accumulate,
-                          float* scratch, hipStream_t st) {
+                          const uint8_t* relu_mask, float* scratch, hipStream_t st) {
     if (!dy || !x || !save_mean || !save_invstd || !gamma || !dx || !dgamma || !dbeta || !scratch) return fail(SAT_EINVAL, "bn_train_bwd: null pointer");
-    if (relu && !y) return fail(SAT_EINVAL, "bn_train_bwd: relu mask needs the forward output");
+    if (relu && !y && !relu_mask) return fail(SAT_EINVAL, "bn_train_bwd: relu needs the forward output or its sign mask");
+    SAT_REQUIRE(!relu_mask || C % 8 == 0, "bn_train_bwd: the ReLU sign mask needs C %% 8 == 0 (C=%d)", C);
     SAT_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, "bn_train_bwd: bad shape");
     constexpr int E = EPT<T>::n;
     SAT_REQUIRE(C % E == 0, "bn_train_bwd: C=%d must be a multiple of %d for this storage type", C, E);
     int CV, nparts; long rp; bn_grid(rows, C, E, CV, rp, nparts);
     double* p0 = reinterpret_cast<double*>(scratch); double* p1 = p0 + (long)nparts * C;
-    hipLaunchKernelGGL((bn_colstats_kernel<1, T>), dim3(cdiv(C / E, CV), nparts), dim3(256), 0, st, x, dy, y, save_mean, save_invstd, relu, (long)rows, C, CV, rp, p0, p1);
+    hipLaunchKernelGGL((bn_colstats_kernel<1, T>), dim3(cdiv(C / E, CV), nparts), dim3(256), 0, st, x, dy, y, relu_mask, save_mean, save_invstd, relu, (long)rows, C, CV, rp, p0, p1);
     SAT_TRY(launch_ok("bn_colstats<1>"));
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, p0, p1, nparts, C, dbeta, dgamma);
     SAT_TRY(launch_ok("bn_bwd_finalize"));
-    long total4 = rows * (C / 4);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(cdiv(total4, 256)), dim3(256), 0, st, x, dy, y, save_mean, save_invstd, gamma, dbeta, dgamma, relu,
-                       1.0f / (float)rows, dx, dres, dres_accumulate, total4, C / 4);
+    long totalv = rows * (C / E);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(cdiv(totalv, 256)), dim3(256), 0, st, x, dy, y, relu_mask, save_mean, save_invstd, gamma, dbeta, dgamma, relu,
+                       1.0f / (float)rows, dx, dres, dres_accumulate, totalv, C / E);
     return launch_ok("bn_bwd_apply");
 }
 
@@ -566,15 +650,15 @@ typedef __bf16 bf;
 
 int sat_bn_train_fwd_t(int32_t dtype, const void* x, int64_t rows, int32_t C, const float* gamma, const float* beta, float eps, float momentum,
                        float* running_mean, float* running_var, float* save_mean, float* save_invstd, const void* residual, int32_t relu,
-                       void* y, float* scratch, void* stream) {
+                       void* y, uint8_t* relu_mask, float* scratch, void* stream) {
     SAT_BY_DTYPE(dtype,
-        bn_train_fwd_t<float>((const float*)x, rows, C, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, (const float*)residual, relu, (float*)y, scratch, (hipStream_t)stream),
-        bn_train_fwd_t<bf>((const bf*)x, rows, C, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, (const bf*)residual, relu, (bf*)y, scratch, (hipStream_t)stream));
+        bn_train_fwd_t<float>((const float*)x, rows, C, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, (const float*)residual, relu, (float*)y, relu_mask, scratch, (hipStream_t)stream),
+        bn_train_fwd_t<bf>((const bf*)x, rows, C, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, (const bf*)residual, relu, (bf*)y, relu_mask, scratch, (hipStream_t)stream));
 }
 int sat_bn_train_fwd(const float* x, int64_t rows, int32_t C, const float* gamma, const float* beta, float eps, float momentum,
                      float* running_mean, float* running_var, float* save_mean, float* save_invstd, const float* residual, int32_t relu,
                      float* y, float* scratch, void* stream) {
-    return sat_bn_train_fwd_t(0, x, rows, C, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, residual, relu, y, scratch, stream);
+    return sat_bn_train_fwd_t(0, x, rows, C, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, residual, relu, y, nullptr, scratch, stream);
 }
 int sat_bn_eval_fwd_t(int32_t dtype, const void* x, int64_t rows, int32_t C, const float* running_mean, const float* running_var, float eps,
                       const float* gamma, const float* beta, const void* residual, int32_t relu, void* y, void* stream) {
@@ -588,15 +672,15 @@ int sat_bn_eval_fwd(const float* x, int64_t rows, int32_t C, const float* runnin
 }
 int sat_bn_train_bwd_t(int32_t dtype, const void* dy, const void* x, const void* y, int64_t rows, int32_t C, const float* save_mean,
                        const float* save_invstd, const float* gamma, int32_t relu, void* dx, float* dgamma, float* dbeta, void* dres,
-                       int32_t dres_accumulate, float* scratch, void* stream) {
+                       int32_t dres_accumulate, const uint8_t* relu_mask, float* scratch, void* stream) {
     SAT_BY_DTYPE(dtype,
-        bn_train_bwd_t<float>((const float*)dy, (const float*)x, (const float*)y, rows, C, save_mean, save_invstd, gamma, relu, (float*)dx, dgamma, dbeta, (float*)dres, dres_accumulate, scratch, (hipStream_t)stream),
-        bn_train_bwd_t<bf>((const bf*)dy, (const bf*)x, (const bf*)y, rows, C, save_mean, save_invstd, gamma, relu, (bf*)dx, dgamma, dbeta, (bf*)dres, dres_accumulate, scratch, (hipStream_t)stream));
+        bn_train_bwd_t<float>((const float*)dy, (const float*)x, (const float*)y, rows, C, save_mean, save_invstd, gamma, relu, (float*)dx, dgamma, dbeta, (float*)dres, dres_accumulate, relu_mask, scratch, (hipStream_t)stream),
+        bn_train_bwd_t<bf>((const bf*)dy, (const bf*)x, (const bf*)y, rows, C, save_mean, save_invstd, gamma, relu, (bf*)dx, dgamma, dbeta, (bf*)dres, dres_accumulate, relu_mask, scratch, (hipStream_t)stream));
 }
 int sat_bn_train_bwd(const float* dy, const float* x, const float* y, int64_t rows, int32_t C, const float* save_mean, const float* save_invstd,
                      const float* gamma, int32_t relu, float* dx, float* dgamma, float* dbeta, float* dres, int32_t dres_accumulate,
                      float* scratch, void* stream) {
-    return sat_bn_train_bwd_t(0, dy, x, y, rows, C, save_mean, save_invstd, gamma, relu, dx, dgamma, dbeta, dres, dres_accumulate, scratch, stream);
+    return sat_bn_train_bwd_t(0, dy, x, y, rows, C, save_mean, save_invstd, gamma, relu, dx, dgamma, dbeta, dres, dres_accumulate, nullptr, scratch, stream);
 }
 int sat_maxpool3x3s2_fwd_t(int32_t dtype, const void* x, void* y, uint8_t* argmax, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
     SAT_BY_DTYPE(dtype, maxpool_fwd_t<float>((const float*)x, (float*)y, argmax, N, H, W, C, (hipStream_t)stream),

@@ -143,23 +143,27 @@ _tracked = []      # num_batches_tracked buffers touched by the running whole-en
 _defer = [False]
 
 
-def bn_fwd(x, bn, residual=None, relu=True, training=True):
+def bn_fwd(x, bn, residual=None, relu=True, training=True, want_mask=False):
+    """BatchNorm (+ residual) (+ ReLU) of a (..., C) NHWC tensor.  Returns (y, stats); in training mode stats =
+    (mean, invstd[, relu_mask]) -- with ``want_mask`` the sign mask of the output (1 bit per element) that ``bn_bwd``
+    reads instead of y."""
     lib = L.lib()
     Cc = x.shape[-1]; rows = x.numel() // Cc
     y = torch.empty_like(x)
     dt = int(_is_bf(x))
     if training:
+        mask = torch.empty(x.numel() // 8, dtype=torch.uint8, device=x.device) if (want_mask and relu and Cc % 8 == 0) else None
         mean = torch.empty(Cc, dtype=torch.float32, device=x.device); invstd = torch.empty_like(mean)
         scratch = torch.empty(lib.sat_bn_scratch_bytes(rows, Cc) // 8 + 1, dtype=torch.float64, device=x.device)
         mom = 0.1 if bn.momentum is None else float(bn.momentum)
         L.check(lib.sat_bn_train_fwd_t(dt, L.ptr(x), rows, Cc, L.ptr(bn.weight), L.ptr(bn.bias), float(bn.eps), mom, L.ptr(bn.running_mean),
-                                       L.ptr(bn.running_var), L.ptr(mean), L.ptr(invstd), L.ptr(residual), int(relu), L.ptr(y), L.ptr(scratch),
+                                       L.ptr(bn.running_var), L.ptr(mean), L.ptr(invstd), L.ptr(residual), int(relu), L.ptr(y), L.ptr(mask), L.ptr(scratch),
                                        L.stream_ptr()), "sat_bn_train_fwd")
         if _defer[0]:
             _tracked.append(bn.num_batches_tracked)
         else:
             bn.num_batches_tracked += 1
-        return y, (mean, invstd)
+        return y, ((mean, invstd) if mask is None else (mean, invstd, mask))
     L.check(lib.sat_bn_eval_fwd_t(dt, L.ptr(x), rows, Cc, L.ptr(bn.running_mean), L.ptr(bn.running_var), float(bn.eps), L.ptr(bn.weight),
                                   L.ptr(bn.bias), L.ptr(residual), int(relu), L.ptr(y), L.stream_ptr()), "sat_bn_eval_fwd")
     return y, None
@@ -172,8 +176,8 @@ def bn_bwd(dy, x, y, stats, bn, relu, dres=None, dres_accumulate=False):
     dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device); dbeta = torch.empty_like(dgamma)
     scratch = torch.empty(lib.sat_bn_scratch_bytes(rows, Cc) // 8 + 1, dtype=torch.float64, device=x.device)
     L.check(lib.sat_bn_train_bwd_t(int(_is_bf(x)), L.ptr(dy), L.ptr(x), L.ptr(y), rows, Cc, L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(bn.weight),
-                                   int(relu), L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dres), int(dres_accumulate), L.ptr(scratch),
-                                   L.stream_ptr()), "sat_bn_train_bwd")
+                                   int(relu), L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dres), int(dres_accumulate),
+                                   L.ptr(stats[2] if len(stats) > 2 else None), L.ptr(scratch), L.stream_ptr()), "sat_bn_train_bwd")
     return dx, dgamma, dbeta
 
 
@@ -201,14 +205,14 @@ def _block_fwd(blk, x, training, W=None):
     else:
         r.idn = x
     if blk.kind == "basic":
-        r.c1 = conv_fwd(x, W(blk.conv1.weight), blk.stride, 1); r.a1, r.s1 = bn_fwd(r.c1, blk.bn1, None, True, training)
+        r.c1 = conv_fwd(x, W(blk.conv1.weight), blk.stride, 1); r.a1, r.s1 = bn_fwd(r.c1, blk.bn1, None, True, training, want_mask=True)
         r.c2 = conv_fwd(r.a1, W(blk.conv2.weight), 1, 1)
-        r.out, r.s2 = bn_fwd(r.c2, blk.bn2, r.idn, True, training)
+        r.out, r.s2 = bn_fwd(r.c2, blk.bn2, r.idn, True, training, want_mask=True)
     else:
-        r.c1 = conv_fwd(x, W(blk.conv1.weight), 1, 0); r.a1, r.s1 = bn_fwd(r.c1, blk.bn1, None, True, training)
-        r.c2 = conv_fwd(r.a1, W(blk.conv2.weight), blk.stride, 1); r.a2, r.s2 = bn_fwd(r.c2, blk.bn2, None, True, training)
+        r.c1 = conv_fwd(x, W(blk.conv1.weight), 1, 0); r.a1, r.s1 = bn_fwd(r.c1, blk.bn1, None, True, training, want_mask=True)
+        r.c2 = conv_fwd(r.a1, W(blk.conv2.weight), blk.stride, 1); r.a2, r.s2 = bn_fwd(r.c2, blk.bn2, None, True, training, want_mask=True)
         r.c3 = conv_fwd(r.a2, W(blk.conv3.weight), 1, 0)
-        r.out, r.s3 = bn_fwd(r.c3, blk.bn3, r.idn, True, training)
+        r.out, r.s3 = bn_fwd(r.c3, blk.bn3, r.idn, True, training, want_mask=True)
     return r
 
 
@@ -294,7 +298,7 @@ class EncoderFn(torch.autograd.Function):
             L.check(lib.sat_pad_channels_3to4(L.ptr(w3), L.ptr(wp), conv1.out_channels * 49, 0, st), "sat_pad_channels_3to4")
         t["x0"], t["wp"] = x0, wp
         t["c0"] = conv_fwd(x0, wp, 2, 3)
-        t["a0"], t["s0"] = bn_fwd(t["c0"], enc[2], None, True, training)
+        t["a0"], t["s0"] = bn_fwd(t["c0"], enc[2], None, True, training, want_mask=True)
         Nn, Hh, Ww, Cc = t["a0"].shape
         P, Q = (Hh + 2 - 3) // 2 + 1, (Ww + 2 - 3) // 2 + 1
         t["p0"] = torch.empty(Nn, P, Q, Cc, dtype=adt, device=img.device)

@@ -66,9 +66,11 @@ def test_conv_bias(E):
     close(nchw(E.conv_fwd(nhwc(x).cuda(), w.cuda(), 1, 0, b.cuda())), F.conv2d(x, w, b), 2e-5, "1x1 conv + bias")
 
 
+@pytest.mark.parametrize("mask", [False, True])
 @pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False)])
 @pytest.mark.parametrize("N,H,W,C", [(4, 5, 5, 8), (2, 16, 16, 64), (3, 7, 7, 12), (8, 8, 8, 128), (8, 16, 16, 64), (8, 4, 4, 256), (8, 2, 2, 512)])
-def test_batchnorm_train_fwd_bwd(E, N, H, W, C, relu, res):
+def test_batchnorm_train_fwd_bwd(E, N, H, W, C, relu, res, mask):
+    """mask=True: the forward writes the 1-bit ReLU sign mask and the backward reads it instead of the output tensor."""
     g = torch.Generator().manual_seed(C + N)
     bn = torch.nn.BatchNorm2d(C)
     with torch.no_grad():
@@ -84,12 +86,20 @@ def test_batchnorm_train_fwd_bwd(E, N, H, W, C, relu, res):
     with torch.no_grad():
         bnd.weight.copy_(bn.weight); bnd.bias.copy_(bn.bias)
     xd = nhwc(x.detach()).cuda(); rd = nhwc(r.detach()).cuda() if res else None
-    yd, stats = E.bn_fwd(xd, bnd, rd, relu, True)
+    yd, stats = E.bn_fwd(xd, bnd, rd, relu, True, want_mask=mask)
     close(nchw(yd), y, 1e-5, "bn fwd")
+    y_for_bwd = yd
+    if mask and relu and C % 8 == 0:
+        assert len(stats) == 3
+        bits = np.unpackbits(stats[2].cpu().numpy(), bitorder="little").astype(bool)
+        assert np.array_equal(bits, (yd.cpu().numpy().reshape(-1) > 0))
+        y_for_bwd = None                      # the backward must not need the output tensor any more
+    else:
+        assert len(stats) == 2
     close(bnd.running_mean, bn.running_mean, 1e-5, "running_mean"); close(bnd.running_var, bn.running_var, 1e-5, "running_var")
     assert int(bnd.num_batches_tracked) == 1
     dres = torch.empty_like(xd) if res else None
-    dx, dgam, dbet = E.bn_bwd(nhwc(dy).cuda(), xd, yd, stats, bnd, relu, dres=dres)
+    dx, dgam, dbet = E.bn_bwd(nhwc(dy).cuda(), xd, y_for_bwd, stats, bnd, relu, dres=dres)
     close(nchw(dx), x.grad, 2e-5, "bn dx"); close(dgam, bn.weight.grad, 2e-5, "bn dgamma"); close(dbet, bn.bias.grad, 2e-5, "bn dbeta")
     if res:
         close(nchw(dres), r.grad, 1e-6, "residual grad")
