@@ -337,9 +337,11 @@ int launch_gemm_bf16(const GemmArgs& g, hipStream_t st) {
         // re-read: 8 bytes per output element per split) must stay a fraction of the operand bytes
         static const int target = getenv("SAT_SPLIT_TARGET") ? atoi(getenv("SAT_SPLIT_TARGET")) : 768;
         static const int frac = getenv("SAT_SPLIT_FRAC") ? atoi(getenv("SAT_SPLIT_FRAC")) : 8;
-        static const int target128 = getenv("SAT_SPLIT_TARGET128") ? atoi(getenv("SAT_SPLIT_TARGET128")) : 384;
-        const int tgt = (BMt == 128) ? target128 : target;      // measured on the C2 step: 128-wide tiles want ~1.5 workgroups per CU, 64-wide ~3
-        int want = (int)((tgt + blocks - 1) / blocks), maxs = g.K / (8 * KB);
+        static const int target128 = getenv("SAT_SPLIT_TARGET128") ? atoi(getenv("SAT_SPLIT_TARGET128")) : 512;
+        const int tgt = (BMt == 128) ? target128 : target;      // resident workgroups: 2 per CU with 128-wide tiles, ~3 with 64-wide; rounding DOWN keeps the grid inside one residency round
+        static const int floor_mode = getenv("SAT_SPLIT_FLOOR") ? atoi(getenv("SAT_SPLIT_FLOOR")) : 1;
+        int want = floor_mode ? (int)(tgt / blocks) : (int)((tgt + blocks - 1) / blocks), maxs = g.K / (8 * KB);
+        if (want < 1) want = 1;
         double in_bytes = ((double)g.M + g.N) * g.K * 2.0;
         int lim = (int)(in_bytes / ((double)frac * g.M * g.N)); if (lim < 4) lim = 4;
         ns = want < maxs ? want : maxs; if (ns > lim) ns = lim; if (ns > 256) ns = 256; if (ns < 1) ns = 1;
