@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SAT_HIP_ABI_VERSION 6
+#define SAT_HIP_ABI_VERSION 7
 
 int sat_abi_version(void);
 const char* sat_last_error(void);
@@ -245,6 +245,38 @@ int sat_maxpool3x3s2_bwd(const float* dy, const uint8_t* argmax, float* dx, int3
 /* encoder_size option (readme.md:118-121): AdaptiveAvgPool2d when P <= H, bilinear Upsample(align_corners=False) otherwise */
 int sat_resize_fwd(const float* x, float* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t P, int32_t Q, void* stream);
 int sat_resize_bwd(const float* dy, float* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t P, int32_t Q, void* stream);
+
+/* ------------------------------------------------------------------ optimizer (SAT.configure_optimizers, model.py:723-757;
+ * gradient clipping train.py:93-96,273-274): every parameter tensor updated by one launch.
+ * `tensors` and `chunks` are DEVICE arrays built by the caller: one sat_opt_tensor per parameter (its gradient pointer
+ * changes per step), one sat_opt_chunk per sat_optimizer_chunk_elems() elements of a tensor. */
+#define SAT_OPT_SGD 0
+#define SAT_OPT_ADAM 1
+#define SAT_OPT_ADAMW 2
+typedef struct sat_opt_tensor {
+    float* p; const float* g;
+    float* m;             /* Adam exp_avg / SGD momentum_buffer (NULL when unused) */
+    float* v;             /* Adam exp_avg_sq                                       */
+    int64_t n;
+    float lr, weight_decay;    /* of the parameter's group                        */
+} sat_opt_tensor;
+typedef struct sat_opt_chunk { int32_t tensor; int32_t reserved; int64_t start; } sat_opt_chunk;
+typedef struct sat_opt_hyper {
+    int32_t kind;              /* SAT_OPT_*                                            */
+    int32_t nesterov, first_step;   /* SGD: nesterov momentum; first step (momentum buffer = gradient) */
+    float beta1, beta2, eps;
+    float bias_correction1;         /* 1 - beta1^step                                  */
+    float bias_correction2_sqrt;    /* sqrt(1 - beta2^step)                            */
+    float momentum;
+    float clip_value;               /* > 0: clamp every gradient element to [-v, v] (clip_grad_value_) */
+} sat_opt_hyper;
+int32_t sat_optimizer_chunk_elems(void);
+/* coef[0] = min(1, max_norm / (||g||_2 + 1e-6)) over ALL tensors (clip_grad_norm_), coef[1] = the norm; fixed-order reduction */
+int sat_grad_clip_coef(const sat_opt_tensor* tensors, const sat_opt_chunk* chunks, int32_t n_chunks, float max_norm, double* scratch,
+                       float* coef, void* stream);
+/* p, m, v updated in place from g * clip_coef[0] (clip_coef NULL = 1) */
+int sat_optimizer_step(const sat_opt_tensor* tensors, const sat_opt_chunk* chunks, int32_t n_chunks, const sat_opt_hyper* hyper,
+                       const float* clip_coef, void* stream);
 
 #ifdef __cplusplus
 }

@@ -61,6 +61,17 @@ class DecoderParams(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in PARAM_FIELDS] + [(k, C.c_void_p * (MAX_LSTM_LAYERS - 1)) for k in UP_FIELDS]
 
 
+class OptTensor(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_int64), ("lr", C.c_float),
+                ("weight_decay", C.c_float)]
+
+
+class OptHyper(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("nesterov", C.c_int32), ("first_step", C.c_int32), ("beta1", C.c_float), ("beta2", C.c_float),
+                ("eps", C.c_float), ("bias_correction1", C.c_float), ("bias_correction2_sqrt", C.c_float), ("momentum", C.c_float),
+                ("clip_value", C.c_float)]
+
+
 class DecoderBatch(C.Structure):
     _fields_ = [("ann", C.c_void_p), ("caps", C.c_void_p), ("lengths", C.c_void_p), ("prow", C.c_void_p), ("src_row", C.c_void_p),
                 ("step_offsets_host", C.c_void_p), ("teacher_host", C.c_void_p)]
@@ -144,6 +155,9 @@ SYMBOLS.update({
     "sat_beam_scores": (C.c_int, [_vp, _i32, _i32, _f, _vp, _i32, _vp, _vp, _vp]),
     "sat_topk": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
 })
+SYMBOLS.update({"sat_optimizer_chunk_elems": (C.c_int32, []),
+                "sat_grad_clip_coef": (C.c_int, [_vp, _vp, _i32, _f, _vp, _vp, _vp]),
+                "sat_optimizer_step": (C.c_int, [_vp, _vp, _i32, C.POINTER(OptHyper), _vp, _vp])})
 SYMBOLS.update({"sat_profile_start": (C.c_int, []),
                 "sat_profile_stop": (C.c_int, [C.POINTER(ProfileEntry), _i32, C.POINTER(C.c_int32)])})
 
@@ -175,8 +189,8 @@ def lib():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(handle, name)          # AttributeError if the export is missing
             fn.restype, fn.argtypes = res, args
-        if handle.sat_abi_version() != 6:
-            raise SatHipError("libsat_hip.so ABI version %d != 6 (rebuild: make -C csrc)" % handle.sat_abi_version())
+        if handle.sat_abi_version() != 7:
+            raise SatHipError("libsat_hip.so ABI version %d != 7 (rebuild: make -C csrc)" % handle.sat_abi_version())
         _lib = handle
     return _lib
 

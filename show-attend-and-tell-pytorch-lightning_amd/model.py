@@ -27,7 +27,12 @@ except Exception:                        # pragma: no cover - exercised where Li
 
 
 class _HParams(dict):
-    __getattr__ = dict.__getitem__
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k) from None
+
     __setattr__ = dict.__setitem__
 
 
@@ -434,14 +439,19 @@ class SAT(SATDecoder, _Base):
             params += [{"params": self.embedding.parameters(), "lr": hp.embedding_lr, "weight_decay": 0.0}]
         if hp.encoder_finetune_after > 0 and hp.encoder_lr > 0:          # F10: mirrored as written
             params += groups([self.encoder], hp.weight_decay, hp.encoder_lr)
-        if hp.opt == "sgd":
+        if hp.opt not in ("sgd", "adam", "adamw"):
+            raise ValueError("opt=%r" % (hp.opt,))
+        if getattr(hp, "fused_optimizer", True):
+            # one launch over every parameter tensor (csrc/optimizer.hip), gradient clipping of train.py:93-96 folded in
+            from .optim import FusedOptimizer
+            opt = FusedOptimizer(params, kind=hp.opt, lr=hp.decoder_lr, betas=(hp.adam_b1, hp.adam_b2), momentum=hp.momentum, nesterov=hp.nesterov,
+                                 grad_clip=getattr(hp, "grad_clip", None), clip_value=getattr(hp, "clip_value", 0.0))
+        elif hp.opt == "sgd":
             opt = torch.optim.SGD(params, lr=hp.decoder_lr, momentum=hp.momentum, nesterov=hp.nesterov)
         elif hp.opt == "adam":
             opt = torch.optim.Adam(params, lr=hp.decoder_lr, betas=(hp.adam_b1, hp.adam_b2))
-        elif hp.opt == "adamw":
-            opt = torch.optim.AdamW(params, lr=hp.decoder_lr, betas=(hp.adam_b1, hp.adam_b2))
         else:
-            raise ValueError("opt=%r" % (hp.opt,))
+            opt = torch.optim.AdamW(params, lr=hp.decoder_lr, betas=(hp.adam_b1, hp.adam_b2))
         self.opt_init_lr = [pg["lr"] for pg in opt.param_groups]
         sched = getattr(hp, "scheduler", None)
         if sched == "step":

@@ -1,0 +1,113 @@
+"""Multi-tensor optimizer step on the HIP library: the optimizers ``SAT.configure_optimizers`` builds
+(reference model.py:723-757: SGD / Adam / AdamW over per-module parameter groups) and Lightning's gradient clipping
+(train.py:93-96, 273-274: ``clip_grad_value_`` / ``clip_grad_norm_``) in one launch over every parameter tensor.
+
+``FusedOptimizer`` is a ``torch.optim.Optimizer``: ``param_groups`` (so the reference's LR schedulers drive it unchanged)
+and the per-parameter ``state`` keys of torch's own optimizers (``step``, ``exp_avg``, ``exp_avg_sq`` /
+``momentum_buffer``), so optimizer checkpoints stay interchangeable."""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+KINDS = {"sgd": 0, "adam": 1, "adamw": 2}
+
+
+class FusedOptimizer(torch.optim.Optimizer):
+    def __init__(self, params, kind="adam", lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, momentum=0.0, nesterov=False,
+                 grad_clip=None, clip_value=0.0):
+        if kind not in KINDS:
+            raise ValueError("kind=%r (sgd / adam / adamw)" % (kind,))
+        if kind == "adamw" and weight_decay == 0.0:
+            weight_decay = 1e-2                        # torch.optim.AdamW's default for groups that do not set it
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, momentum=momentum, nesterov=nesterov))
+        self.kind = kind
+        self.set_clipping(grad_clip, clip_value)
+        self._chunks = None
+        self._sig = None
+        self.last_grad_norm = None                     # device scalar after a step with norm clipping
+
+    def set_clipping(self, algorithm, value):
+        """train.py:93-96: ``--grad_clip value|norm`` with ``--clip_value`` (0 = off)."""
+        if algorithm not in (None, "value", "norm"):
+            raise ValueError("grad_clip=%r" % (algorithm,))
+        self.grad_clip, self.clip_value = (algorithm, float(value)) if value and value > 0 else (None, 0.0)
+
+    def _tables(self, entries, dev):
+        sig = tuple((p.data_ptr(), p.numel()) for p, _ in entries)
+        if sig != self._sig:
+            ce = L.lib().sat_optimizer_chunk_elems()
+            rows = [(ti, 0, s) for ti, (p, _) in enumerate(entries) for s in range(0, p.numel(), ce)]
+            arr = np.array(rows, dtype=[("tensor", np.int32), ("reserved", np.int32), ("start", np.int64)])
+            self._chunks = torch.from_numpy(arr.view(np.uint8).copy()).to(dev)
+            self._n_chunks = len(rows)
+            self._host = torch.empty(len(entries) * C.sizeof(L.OptTensor), dtype=torch.uint8).pin_memory()
+            self._dev = torch.empty_like(self._host, device=dev)
+            self._scratch = torch.empty(self._n_chunks, dtype=torch.float64, device=dev)
+            self._coef = torch.ones(2, dtype=torch.float32, device=dev)
+            self._sig = sig
+        return self._chunks
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = L.lib()
+        entries = []
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is not None:
+                    entries.append((p, group))
+        if not entries:
+            return loss
+        L.require_gpu(*[p for p, _ in entries])
+        dev = entries[0][0].device
+        g0 = self.param_groups[0]
+        beta1, beta2 = g0["betas"]
+        for g in self.param_groups:
+            if tuple(g["betas"]) != (beta1, beta2) or g["eps"] != g0["eps"] or g["momentum"] != g0["momentum"] or g["nesterov"] != g0["nesterov"]:
+                raise ValueError("FusedOptimizer: betas / eps / momentum / nesterov must be the same in every group (lr and weight_decay may differ)")
+        chunks = self._tables(entries, dev)
+        table = (L.OptTensor * len(entries)).from_buffer(self._host.numpy())
+        steps = set()
+        for i, (p, group) in enumerate(entries):
+            dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))      # KRSC filters
+            if p.dtype != torch.float32 or not dense:
+                raise ValueError("FusedOptimizer: parameters must be dense fp32 (contiguous or channels_last)")
+            st = self.state[p]
+            if not st:
+                st["step"] = torch.tensor(0.0)
+                if self.kind == "sgd":
+                    st["momentum_buffer"] = torch.zeros_like(p) if group["momentum"] != 0 else None
+                else:
+                    st["exp_avg"] = torch.zeros_like(p); st["exp_avg_sq"] = torch.zeros_like(p)
+            st["step"] += 1
+            steps.add(float(st["step"]))
+            grad = p.grad if p.grad.stride() == p.stride() else torch.empty_like(p).copy_(p.grad)     # element i of g <-> element i of p
+            m = st.get("momentum_buffer") if self.kind == "sgd" else st["exp_avg"]
+            v = None if self.kind == "sgd" else st["exp_avg_sq"]
+            t = table[i]
+            t.p = p.data_ptr(); t.g = grad.data_ptr(); t.m = 0 if m is None else m.data_ptr(); t.v = 0 if v is None else v.data_ptr()
+            t.n = p.numel(); t.lr = float(group["lr"]); t.weight_decay = float(group["weight_decay"])
+            entries[i] = (p, group, grad)              # keep a re-laid-out gradient alive until the launch
+        if len(steps) != 1:
+            raise ValueError("FusedOptimizer: parameters are at different step counts %s" % sorted(steps))
+        step = steps.pop()
+        self._dev.copy_(self._host, non_blocking=True)
+        coef = None
+        if self.grad_clip == "norm":
+            L.check(lib.sat_grad_clip_coef(L.ptr(self._dev), L.ptr(chunks), self._n_chunks, self.clip_value, L.ptr(self._scratch),
+                                           L.ptr(self._coef), L.stream_ptr()), "sat_grad_clip_coef")
+            coef = self._coef
+            self.last_grad_norm = self._coef[1]
+        hyper = L.OptHyper(kind=KINDS[self.kind], nesterov=int(bool(g0["nesterov"])), first_step=int(step == 1), beta1=beta1, beta2=beta2,
+                           eps=g0["eps"], bias_correction1=1.0 - beta1 ** step, bias_correction2_sqrt=math.sqrt(1.0 - beta2 ** step),
+                           momentum=float(g0["momentum"]), clip_value=self.clip_value if self.grad_clip == "value" else 0.0)
+        L.check(lib.sat_optimizer_step(L.ptr(self._dev), L.ptr(chunks), self._n_chunks, C.byref(hyper), L.ptr(coef), L.stream_ptr()),
+                "sat_optimizer_step")
+        return loss

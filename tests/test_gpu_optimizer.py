@@ -1,0 +1,73 @@
+"""GPU parity of the multi-tensor optimizer step (csrc/optimizer.hip) against torch.optim run on the CPU
+with the same parameter groups, gradients and clipping (train.py:93-96, 273-274; model.py:723-757)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _groups(ps):
+    return [{"params": ps[:2], "lr": 1e-2, "weight_decay": 0.0}, {"params": ps[2:4], "lr": 3e-3, "weight_decay": 0.05},
+            {"params": ps[4:], "lr": 1e-3, "weight_decay": 0.0}]
+
+
+@pytest.mark.parametrize("kind,clip", [("adam", None), ("adam", ("norm", 0.5)), ("adamw", ("value", 0.02)), ("sgd", None), ("sgd", ("norm", 1.0))])
+def test_fused_optimizer_matches_torch(kind, clip):
+    import sat_amd  # noqa: F401
+    from sat_amd.optim import FusedOptimizer
+    g = torch.Generator().manual_seed(7)
+    shapes = [(5,), (70001,), (33, 17), (200, 300), (64, 3, 3, 8), (1,), (131073,)]          # chunk boundaries at 65536 elements
+    ref = [torch.randn(s, generator=g).requires_grad_() for s in shapes]
+    dev = [p.detach().clone().cuda().requires_grad_() for p in ref]
+    if kind == "sgd":
+        topt = torch.optim.SGD(_groups(ref), lr=1e-2, momentum=0.9, nesterov=True)
+    elif kind == "adam":
+        topt = torch.optim.Adam(_groups(ref), lr=1e-2, betas=(0.8, 0.95))
+    else:
+        topt = torch.optim.AdamW(_groups(ref), lr=1e-2, betas=(0.8, 0.95))
+    fopt = FusedOptimizer(_groups(dev), kind=kind, lr=1e-2, betas=(0.8, 0.95), momentum=0.9 if kind == "sgd" else 0.0, nesterov=kind == "sgd",
+                          grad_clip=clip[0] if clip else None, clip_value=clip[1] if clip else 0.0)
+    sched_t = torch.optim.lr_scheduler.ExponentialLR(topt, gamma=0.7)            # the reference's schedulers drive param_groups
+    sched_f = torch.optim.lr_scheduler.ExponentialLR(fopt, gamma=0.7)
+    for step in range(4):
+        for p, q in zip(ref, dev):
+            gr = torch.randn(p.shape, generator=g) * (0.1 if step % 2 else 1.0)
+            p.grad = gr.clone(); q.grad = gr.cuda()
+        if clip and clip[0] == "norm":
+            norm = torch.nn.utils.clip_grad_norm_(ref, clip[1])
+        elif clip:
+            torch.nn.utils.clip_grad_value_(ref, clip[1])
+        topt.step(); fopt.step()
+        if clip and clip[0] == "norm":
+            assert abs(float(fopt.last_grad_norm) - float(norm)) <= 1e-5 * float(norm)
+        sched_t.step(); sched_f.step()
+        for i, (p, q) in enumerate(zip(ref, dev)):
+            err = float((q.detach().cpu() - p.detach()).abs().max())
+            assert err <= 2e-6 * max(1.0, float(p.detach().abs().max())), (kind, clip, step, i, err)
+    # state keys are torch's: checkpoints stay interchangeable
+    st = fopt.state[dev[1]]
+    assert set(st) == ({"step", "momentum_buffer"} if kind == "sgd" else {"step", "exp_avg", "exp_avg_sq"})
+    tst = topt.state[ref[1]]
+    key = "momentum_buffer" if kind == "sgd" else "exp_avg"
+    assert float((st[key].cpu() - tst[key]).abs().max()) <= 1e-6 and float(st["step"]) == 4
+
+
+def test_fused_optimizer_is_bitwise_reproducible_and_rejects_cpu():
+    import sat_amd  # noqa: F401
+    from sat_amd import _lib
+    from sat_amd.optim import FusedOptimizer
+    outs = []
+    for _ in range(2):
+        g = torch.Generator().manual_seed(3)
+        ps = [torch.randn(100000, generator=g).cuda().requires_grad_(), torch.randn(257, 129, generator=g).cuda().requires_grad_()]
+        opt = FusedOptimizer(ps, kind="adam", lr=1e-3, grad_clip="norm", clip_value=0.3)
+        for _ in range(3):
+            for p in ps:
+                p.grad = torch.randn(p.shape, generator=g).cuda()
+            opt.step()
+        outs.append([p.detach().clone() for p in ps])
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    cpu = [torch.zeros(4, requires_grad=True)]
+    cpu[0].grad = torch.ones(4)
+    with pytest.raises(_lib.SatHipError):
+        FusedOptimizer(cpu, kind="adam").step()
