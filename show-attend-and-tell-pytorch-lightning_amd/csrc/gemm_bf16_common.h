@@ -24,7 +24,7 @@ struct BArgs {
     float* slab;
     int wide_store;       // bf16 output staged through LDS and written 16 bytes per lane
     int nstage = 2;       // gemm_glds.hip: LDS ring depth
-    int rotate = 1;       // gemm_glds.hip: per-workgroup rotation of the k-tile sequence
+    int rotate = 1 << 20; // gemm_glds.hip: per-workgroup rotation of the k-tile sequence, window in k-tiles (0 = off)
 };
 
 template <typename T> struct VecN { static constexpr int n = 16 / sizeof(T); };

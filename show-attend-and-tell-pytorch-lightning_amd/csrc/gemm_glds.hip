@@ -191,7 +191,7 @@ __global__ __launch_bounds__(NT) void gemm_glds_kernel(BArgs a) {
     // an 87 % hit rate).  Each workgroup therefore starts its k loop at its own rotation of the tile sequence and wraps
     // around: same tiles, same result up to the (fixed) summation order, requests spread over the whole k window.
     const int T = (kend - kbeg + KB - 1) / KB;
-    int tcur = (T > 0 && a.rotate) ? (int)((unsigned)(bx * 5 + by * 3 + bz) % (unsigned)T) : 0;
+    int tcur = (T > 0 && a.rotate) ? (int)((unsigned)(bx * 5 + by * 3 + bz) % (unsigned)(T < a.rotate ? T : a.rotate)) : 0;
     const int rot = tcur;
     auto seek = [&](int tile) {          // wave-uniform state for k-tile `tile` of this workgroup's chunk
         const int k0 = kbeg + tile * KB;
@@ -402,7 +402,7 @@ int launch_gemm_glds(const BArgs& k0, int amode, int bmode, int c_bf16, int BMt,
     static const int off = getenv("SAT_NO_GLDS") ? atoi(getenv("SAT_NO_GLDS")) : 0;
     static const int force_stages = getenv("SAT_GLDS_STAGES") ? atoi(getenv("SAT_GLDS_STAGES")) : 0;
     static const int deep_from = getenv("SAT_GLDS_DEEP_FROM") ? atoi(getenv("SAT_GLDS_DEEP_FROM")) : 1 << 30;
-    static const int rotate = getenv("SAT_GLDS_ROT") ? atoi(getenv("SAT_GLDS_ROT")) : 1;
+    static const int rotate = getenv("SAT_GLDS_ROT") ? atoi(getenv("SAT_GLDS_ROT")) : 1 << 20;     // 0: off; n: rotation window in k-tiles
     if (off) return -1;
     BArgs k = k0;
     // ring depth: short reductions keep two stages (two workgroups per CU overlap each other); from `deep_from` k-tiles

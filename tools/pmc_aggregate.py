@@ -10,8 +10,11 @@ MODE = {("0", "0"): "nt", ("0", "1"): "nn", ("1", "1"): "tn", ("2", "0"): "conv_
 
 
 def family(name):
-    m = re.search(r"gemm_bf16_kernelILi(\d+)ELi(\d+)ELi(\d)ELi(\d)E(DF16b|f)", name) or \
-        re.search(r"gemm_bf16_kernel<(\d+), (\d+), (\d), (\d), (float|__bf16)", name)
+    m = re.search(r"gemm_glds_kernelILi(\d+)ELi(\d+)ELi(\d)ELi(\d)E", name) or re.search(r"gemm_glds_kernel<(\d+), (\d+), (\d), (\d),", name)
+    if m:      # direct-to-LDS kernel: bf16 operands in HBM
+        return "gemm_glds_%s_%sx%s" % (MODE.get((m.group(3), m.group(4)), "?"), m.group(1), m.group(2))
+    m = re.search(r"gemm_bf16_kernelILi(\d+)ELi(\d+)ELi\d+ELi(\d)ELi(\d)E(DF16b|f)", name) or \
+        re.search(r"gemm_bf16_kernel<(\d+), (\d+), \d+, (\d), (\d), (float|__bf16)", name)
     if m:
         return "gemm_bf16_%s_%sx%s_%s" % (MODE.get((m.group(3), m.group(4)), "?"), m.group(1), m.group(2), "b" if m.group(5) in ("DF16b", "__bf16") else "f")
     m = re.search(r"gemm_f32_kernel<(\d+), (\d+), (\d), (\d)>", name)
@@ -22,7 +25,7 @@ def family(name):
 
 def agg(d):
     out = collections.defaultdict(lambda: [0, 0.0, 0.0])
-    for r in csv.DictReader(open(glob.glob(d + "/*/*counter_collection.csv")[0])):
+    for r in csv.DictReader(open((glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"))[0])):
         e = out[family(r["Kernel_Name"])]
         e[0] += 1; e[1] += float(r["Counter_Value"]); e[2] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     return out
