@@ -405,8 +405,21 @@ int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
     SAT_TRY(colsum(st, w, w.dwf_part, A, d.B, A, g.att_f));
     SAT_TRY(gemm(st, A_KMAJOR, B_KMAJOR, w.dU, A, b.ann, D, g.att_enc, D, A, D, d.B * d.L, 0, EPI_NONE, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, slab, se));
     SAT_TRY(gemm(st, A_ROW, B_KMAJOR, w.dU, A, p.att_enc, D, dann, D, d.B * d.L, D, A));
-    hipLaunchKernelGGL(dann_from_context_kernel, dim3(d.B, cdiv(D, 256)), dim3(256), 16 * sizeof(float), st, alphas, w.DZ, b.lengths, dann, 1,
-                       d.R, N, T1, d.L, D);
+    {
+        // location slab = NQ float4 per LDS row: 13 covers L <= 52 (7x7 maps) in one pass, 16 the 8x8 / 14x14 maps
+        const int lq4 = (d.L + 3) / 4;
+        const int NQ = (lq4 <= 13) ? 13 : 16;
+        const int Lq = (lq4 + NQ - 1) / NQ * NQ;
+        const size_t lds_dann = (size_t)d.R * T1 * Lq * 16;
+        SAT_REQUIRE(lds_dann <= 160 * 1024, "dann_from_context: R*(T-1)*L = %d floats of alphas do not fit the LDS", d.R * T1 * d.L);
+        if (NQ == 13) {
+            SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dann_from_context_kernel<13>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dann));
+            hipLaunchKernelGGL(dann_from_context_kernel<13>, dim3(d.B, cdiv(D, 256)), dim3(256), lds_dann, st, alphas, w.DZ, b.lengths, dann, 1, d.R, N, T1, d.L, D);
+        } else {
+            SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dann_from_context_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dann));
+            hipLaunchKernelGGL(dann_from_context_kernel<16>, dim3(d.B, cdiv(D, 256)), dim3(256), lds_dann, st, alphas, w.DZ, b.lengths, dann, 1, d.R, N, T1, d.L, D);
+        }
+    }
     SAT_TRY(launch_ok("dann_from_context"));
     // InitLSTM backward (the raw reshape is a reinterpretation: gradients of the repeated rows add up per image)
     if (d.dropout > 0.f) {                 // per-caption-row path (see decoder_fwd)
