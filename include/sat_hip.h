@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SAT_HIP_ABI_VERSION 7
+#define SAT_HIP_ABI_VERSION 8
 
 int sat_abi_version(void);
 const char* sat_last_error(void);
@@ -196,6 +196,15 @@ size_t sat_conv2d_wgrad_slab_bytes(const sat_conv_geom* g);
 /* bf16 storage variants (activations and filters bf16 in HBM, C % 8 == 0 and K % 8 == 0): bf16 MFMA, fp32
  * accumulation; the weight gradient is produced in fp32 (master weights stay fp32). */
 int sat_conv2d_fwd_bf16(const void* x, const void* w, const float* bias, void* y, const sat_conv_geom* g, void* stream);
+/* forward that also leaves BatchNorm statistics of its (bf16-rounded) output: per row tile of *tile_rows output pixels and per
+ * filter the fp32 (sum, sum of squares) -> tile_stats[tile][K][2] (sat_conv2d_fwd_stats_bytes).  *tile_rows = 0 when the launch
+ * went to a kernel without that epilogue (the caller then takes sat_bn_train_fwd_t).  sat_bn_train_fwd_tiles_bf16 is
+ * sat_bn_train_fwd_t(dtype = bf16) without the statistics pass over x. */
+size_t sat_conv2d_fwd_stats_bytes(const sat_conv_geom* g);
+int sat_conv2d_fwd_bf16_stats(const void* x, const void* w, void* y, const sat_conv_geom* g, float* tile_stats, int32_t* tile_rows, void* stream);
+int sat_bn_train_fwd_tiles_bf16(const void* x, int64_t rows, int32_t C, const float* tile_stats, int32_t tile_rows, const float* gamma,
+                                const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* save_mean,
+                                float* save_invstd, const void* residual, int32_t relu, void* y, uint8_t* relu_mask, float* scratch, void* stream);
 int sat_conv2d_dgrad_bf16(const void* dy, const void* w, void* dx, const sat_conv_geom* g, int32_t accumulate, void* stream);
 int sat_conv2d_wgrad_bf16(const void* dy, const void* x, float* dw, const sat_conv_geom* g, float* slab, int64_t slab_elems, void* stream);
 /* torchvision Normalize(mean, std) (model.py:59) fused with NCHW -> NHWC and 3 -> 4 channel padding */

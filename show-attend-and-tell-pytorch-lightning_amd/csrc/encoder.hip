@@ -209,6 +209,27 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const T* __restrict__ 
     }
 }
 
+// Column statistics that the convolution epilogue left per row tile (gemm_bf16_common.h: fp32 sum and sum of squares of the
+// stored values per tile and channel) -> the partial layout of bn_colstats_kernel<0>: part0/part1 [nparts][C] in double,
+// unshifted.  Block = 32 channels x 8 tile lanes, tiles of a part in a fixed order.
+__global__ __launch_bounds__(256) void bn_tile_reduce_kernel(const float* __restrict__ tiles, int ntiles, int C, int tiles_per, double* __restrict__ part0,
+                                                             double* __restrict__ part1) {
+    __shared__ double sh[2][8][32];
+    const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
+    const int t0 = blockIdx.y * tiles_per, t1 = min(ntiles, t0 + tiles_per);
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int t = t0 + pl; t < t1; t += 8) { const float2 v = reinterpret_cast<const float2*>(tiles)[(long)t * C + c]; s += (double)v.x; q += (double)v.y; }
+    sh[0][pl][cl] = s; sh[1][pl][cl] = q;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+        double ss = 0.0, qq = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { ss += sh[0][k][cl]; qq += sh[1][k][cl]; }
+        part0[(long)blockIdx.y * C + c] = ss; part1[(long)blockIdx.y * C + c] = qq;
+    }
+}
+
 // Finalise: one 64-lane wave per channel sums the partials (lane-strided, then a fixed xor tree).
 // forward : mean / biased variance -> invstd, running stats (momentum, unbiased variance) as nn.BatchNorm2d
 __device__ __forceinline__ double wave_sum_d(double v) {
@@ -226,7 +247,7 @@ __global__ void bn_fwd_finalize_kernel(const double* __restrict__ part0, const d
     for (int p = lane; p < nparts; p += 64) { s += part0[(long)p * C + c]; q += part1[(long)p * C + c]; }
     s = wave_sum_d(s); q = wave_sum_d(q);
     if (lane == 0) {
-        const double n = (double)rows, shift = (double)(float)x[c];
+        const double n = (double)rows, shift = x ? (double)(float)x[c] : 0.0;      // x == NULL: unshifted sums (conv-epilogue statistics)
         double var = (q - s * s / n) / n; if (var < 0.0) var = 0.0;
         const double mu = shift + s / n;
         mean[c] = (float)mu;
@@ -449,7 +470,8 @@ static int conv_geom(const sat_conv_geom* g, ConvGeom& o, int vec = 4) {
 
 extern "C" {
 
-static int conv_fwd_any(const void* x, const void* w, const float* bias, void* y, const sat_conv_geom* geom, int bf16, void* stream) {
+static int conv_fwd_any(const void* x, const void* w, const float* bias, void* y, const sat_conv_geom* geom, int bf16, void* stream,
+                        float* tile_stats = nullptr, int* tile_rows = nullptr) {
     ConvGeom g; SAT_TRY(conv_geom(geom, g, bf16 ? 8 : 4));
     if (!x || !w || !y) return fail(SAT_EINVAL, "conv2d_fwd: null pointer");
     GemmArgs a; a.a_bf16 = a.b_bf16 = a.c_bf16 = a.bf16_mfma = bf16;
@@ -458,6 +480,7 @@ static int conv_fwd_any(const void* x, const void* w, const float* bias, void* y
     if (g.R == 1 && g.S == 1 && g.stride == 1 && g.pad == 0) { a.A = x; a.lda = g.C; a.amode = A_ROW; }   // 1x1: a plain GEMM over pixels
     else { a.A = x; a.amode = A_CONV_FWD; }
     if (bias) { a.epi = EPI_BIAS; a.bias = bias; }
+    a.tile_stats = tile_stats; a.tile_rows = tile_rows;
     return launch_gemm(a, (hipStream_t)stream);
 }
 int sat_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, const sat_conv_geom* geom, void* stream) {
@@ -465,6 +488,17 @@ int sat_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
 }
 int sat_conv2d_fwd_bf16(const void* x, const void* w, const float* bias, void* y, const sat_conv_geom* geom, void* stream) {
     return conv_fwd_any(x, w, bias, y, geom, 1, stream);
+}
+size_t sat_conv2d_fwd_stats_bytes(const sat_conv_geom* geom) {
+    ConvGeom g; if (conv_geom(geom, g, 8) != SAT_OK) return 0;
+    return (size_t)cdiv((long)g.N * g.P * g.Q, 64L) * g.K * 2 * sizeof(float);
+}
+int sat_conv2d_fwd_bf16_stats(const void* x, const void* w, void* y, const sat_conv_geom* geom, float* tile_stats, int32_t* tile_rows, void* stream) {
+    if (!tile_stats || !tile_rows) return fail(SAT_EINVAL, "conv2d_fwd_bf16_stats: null statistics buffer");
+    int tr = 0;
+    SAT_TRY(conv_fwd_any(x, w, nullptr, y, geom, 1, stream, tile_stats, &tr));
+    *tile_rows = tr;
+    return SAT_OK;
 }
 
 static int conv_dgrad_any(const void* dy, const void* w, void* dx, const sat_conv_geom* geom, int accumulate, int bf16, void* stream) {
@@ -567,7 +601,7 @@ extern "C" size_t sat_bn_scratch_bytes(int64_t rows, int32_t C) {
 template <typename T>
 static int bn_train_fwd_t(const T* x, int64_t rows, int32_t C, const float* gamma, const float* beta, float eps, float momentum,
                           float* running_mean, float* running_var, float* save_mean, float* save_invstd, const T* residual, int32_t relu,
-                          T* y, uint8_t* relu_mask, float* scratch, hipStream_t st) {
+                          T* y, uint8_t* relu_mask, float* scratch, hipStream_t st, const float* tile_stats = nullptr, int tile_rows = 0) {
     if (!x || !gamma || !beta || !save_mean || !save_invstd || !y || !scratch) return fail(SAT_EINVAL, "bn_train_fwd: null pointer");
     SAT_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, "bn_train_fwd: rows=%ld C=%d (C must be a multiple of 4)", (long)rows, C);
     constexpr int E = EPT<T>::n;
@@ -575,10 +609,22 @@ static int bn_train_fwd_t(const T* x, int64_t rows, int32_t C, const float* gamm
     SAT_REQUIRE(!relu_mask || (relu && C % 8 == 0), "bn_train_fwd: the ReLU sign mask needs relu and C %% 8 == 0 (C=%d)", C);
     int CV, nparts; long rp; bn_grid(rows, C, E, CV, rp, nparts);
     double* p0 = reinterpret_cast<double*>(scratch); double* p1 = p0 + (long)nparts * C;
-    hipLaunchKernelGGL((bn_colstats_kernel<0, T>), dim3(cdiv(C / E, CV), nparts), dim3(256), 0, st, x, (const T*)nullptr, (const T*)nullptr,
-                       (const unsigned char*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, (long)rows, C, CV, rp, p0, p1);
-    SAT_TRY(launch_ok("bn_colstats<0>"));
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel<T>, dim3(cdiv(C, 4)), dim3(256), 0, st, p0, p1, x, nparts, C, (long)rows, eps, momentum, save_mean, save_invstd, running_mean, running_var);
+    const T* shift_src = x;
+    if (tile_stats) {        // statistics came out of the convolution's epilogue: combine the row tiles, no pass over x
+        SAT_REQUIRE(tile_rows > 0, "bn_train_fwd: tile_rows=%d", tile_rows);
+        const int ntiles = (int)cdiv(rows, (long)tile_rows);
+        int np = cdiv(ntiles, 64); if (np > nparts) np = nparts; if (np < 1) np = 1;          // partials fit the scratch sized for nparts
+        const int per = cdiv(ntiles, np); np = cdiv(ntiles, per);
+        p1 = p0 + (long)np * C;
+        hipLaunchKernelGGL(bn_tile_reduce_kernel, dim3(cdiv(C, 32), np), dim3(256), 0, st, tile_stats, ntiles, C, per, p0, p1);
+        SAT_TRY(launch_ok("bn_tile_reduce"));
+        nparts = np; shift_src = nullptr;
+    } else {
+        hipLaunchKernelGGL((bn_colstats_kernel<0, T>), dim3(cdiv(C / E, CV), nparts), dim3(256), 0, st, x, (const T*)nullptr, (const T*)nullptr,
+                           (const unsigned char*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, (long)rows, C, CV, rp, p0, p1);
+        SAT_TRY(launch_ok("bn_colstats<0>"));
+    }
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel<T>, dim3(cdiv(C, 4)), dim3(256), 0, st, p0, p1, shift_src, nparts, C, (long)rows, eps, momentum, save_mean, save_invstd, running_mean, running_var);
     SAT_TRY(launch_ok("bn_fwd_finalize"));
     long totalv = rows * (C / E);
     hipLaunchKernelGGL((bn_apply_kernel<T, false>), dim3(cdiv(totalv, 256)), dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta, residual, relu, y, relu_mask, totalv, C / E, -1.0f);
@@ -654,6 +700,13 @@ int sat_bn_train_fwd_t(int32_t dtype, const void* x, int64_t rows, int32_t C, co
     SAT_BY_DTYPE(dtype,
         bn_train_fwd_t<float>((const float*)x, rows, C, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, (const float*)residual, relu, (float*)y, relu_mask, scratch, (hipStream_t)stream),
         bn_train_fwd_t<bf>((const bf*)x, rows, C, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, (const bf*)residual, relu, (bf*)y, relu_mask, scratch, (hipStream_t)stream));
+}
+int sat_bn_train_fwd_tiles_bf16(const void* x, int64_t rows, int32_t C, const float* tile_stats, int32_t tile_rows, const float* gamma, const float* beta,
+                                float eps, float momentum, float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                                const void* residual, int32_t relu, void* y, uint8_t* relu_mask, float* scratch, void* stream) {
+    if (!tile_stats) return fail(SAT_EINVAL, "bn_train_fwd_tiles: null statistics");
+    return bn_train_fwd_t<bf>((const bf*)x, rows, C, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, (const bf*)residual, relu,
+                              (bf*)y, relu_mask, scratch, (hipStream_t)stream, tile_stats, tile_rows);
 }
 int sat_bn_train_fwd(const float* x, int64_t rows, int32_t C, const float* gamma, const float* beta, float eps, float momentum,
                      float* running_mean, float* running_var, float* save_mean, float* save_invstd, const float* residual, int32_t relu,

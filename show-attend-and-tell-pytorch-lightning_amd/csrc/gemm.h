@@ -54,6 +54,7 @@ struct GemmArgs {
     int c0 = 0, c1 = 0;
     ConvGeom g = {};
     float* slab = nullptr; long slab_elems = 0;   // split-K scratch (optional)
+    float* tile_stats = nullptr; int* tile_rows = nullptr;   // bf16 kernels: per-row-tile column statistics of the stored result (see gemm_bf16_common.h); *tile_rows = rows per tile chosen, 0 if not produced
 };
 
 // Launches on `stream`; returns SAT_OK or sets last_error.  bf16_mfma requests fall back to the exact fp32

@@ -25,6 +25,7 @@ struct BArgs {
     int wide_store;       // bf16 output staged through LDS and written 16 bytes per lane
     int nstage = 2;       // gemm_glds.hip: LDS ring depth
     int rotate = 1 << 20; // gemm_glds.hip: per-workgroup rotation of the k-tile sequence, window in k-tiles (0 = off)
+    float* tile_stats = nullptr;   // optional (wide_store only): per row tile and output column (sum, sum of squares) of the stored bf16 values
 };
 
 template <typename T> struct VecN { static constexpr int n = 16 / sizeof(T); };
@@ -77,6 +78,33 @@ __device__ __forceinline__ void store_tile(const BArgs& a, f32x16 (&acc)[BM / 64
         static_assert(BM * LDC <= SMEM_ELEMS, "C tile must fit the staging buffers");
         __bf16* cs = smem;
         __syncthreads();
+        if (a.tile_stats) {
+            // BatchNorm statistics of the tile while it is still in registers (one HBM pass less for the layer that follows):
+            // per output column the sum and the sum of squares of the ROUNDED (stored) values over this tile's rows, in fp32
+            // (<= 128 terms each); the tiles are combined in double by bn_tile_reduce_kernel (encoder.hip).
+            float* sbuf = reinterpret_cast<float*>(smem + BM * LDC);           // [2 wave rows][BN][2], behind the staged tile
+            static_assert(BM * LDC * 2 + 2 * BN * 2 * 4 <= SMEM_ELEMS * 2, "tile statistics must fit behind the staged C tile");
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = bm + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const float vb = (float)(__bf16)acc[i][j][r];
+                        if (row < a.M) { s1 += vb; s2 = fmaf(vb, vb, s2); }
+                    }
+                s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+                if (lh == 0) { float* q = sbuf + ((wm ? 1 : 0) * BN + wn + j * 32 + li) * 2; q[0] = s1; q[1] = s2; }
+            }
+            __syncthreads();
+            if (tid < BN && bn + tid < a.N) {
+                const float s1 = sbuf[tid * 2] + sbuf[(BN + tid) * 2], s2 = sbuf[tid * 2 + 1] + sbuf[(BN + tid) * 2 + 1];
+                float* o = a.tile_stats + ((long)(bm / BM) * a.N + bn + tid) * 2;
+                o[0] = s1; o[1] = s2;
+            }
+        }
         // Neighbouring lanes hold neighbouring columns.  Registers r, r+1 are rows R, R+1: the even lane of a pair
         // collects both columns of row R, the odd lane both columns of row R+1 (one DPP swap), so every lane writes
         // one packed 4-byte LDS word per register pair instead of two 2-byte ones.

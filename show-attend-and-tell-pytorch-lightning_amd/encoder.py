@@ -103,6 +103,25 @@ def conv_fwd(x, w, stride, pad, bias=None):
     return y
 
 
+def conv_fwd_stats(x, w, stride, pad):
+    """bf16 convolution whose epilogue also leaves the BatchNorm statistics of its output per row tile.  Returns
+    (y, tiles) where tiles = (tile_stats, tile_rows) for ``bn_fwd(..., tiles=tiles)``, or None when the launch took a kernel
+    without that epilogue (fp32 storage, odd shapes)."""
+    if not _is_bf(x):
+        return conv_fwd(x, w, stride, pad), None
+    lib = L.lib()
+    N, H, W, Cc = x.shape
+    K, _, R, S = w.shape
+    P, Q = _out_hw(H, W, R, S, stride, pad)
+    y = torch.empty(N, P, Q, K, dtype=x.dtype, device=x.device)
+    g = _geom(N, H, W, Cc, K, R, S, stride, pad)
+    stats = torch.empty(lib.sat_conv2d_fwd_stats_bytes(C.byref(g)) // 4, dtype=torch.float32, device=x.device)
+    rows = C.c_int32(0)
+    L.check(lib.sat_conv2d_fwd_bf16_stats(L.ptr(x), L.ptr(_krsc(w)), L.ptr(y), C.byref(g), L.ptr(stats), C.byref(rows), L.stream_ptr()),
+            "sat_conv2d_fwd_bf16_stats")
+    return y, ((stats, rows.value) if rows.value > 0 else None)
+
+
 def conv_dgrad(dy, w, x_shape, stride, pad, out=None, accumulate=False):
     N, H, W, Cc = x_shape
     K, _, R, S = w.shape
@@ -143,7 +162,7 @@ _tracked = []      # num_batches_tracked buffers touched by the running whole-en
 _defer = [False]
 
 
-def bn_fwd(x, bn, residual=None, relu=True, training=True, want_mask=False):
+def bn_fwd(x, bn, residual=None, relu=True, training=True, want_mask=False, tiles=None):
     """BatchNorm (+ residual) (+ ReLU) of a (..., C) NHWC tensor.  Returns (y, stats); in training mode stats =
     (mean, invstd[, relu_mask]) -- with ``want_mask`` the sign mask of the output (1 bit per element) that ``bn_bwd``
     reads instead of y."""
@@ -156,9 +175,14 @@ def bn_fwd(x, bn, residual=None, relu=True, training=True, want_mask=False):
         mean = torch.empty(Cc, dtype=torch.float32, device=x.device); invstd = torch.empty_like(mean)
         scratch = torch.empty(lib.sat_bn_scratch_bytes(rows, Cc) // 8 + 1, dtype=torch.float64, device=x.device)
         mom = 0.1 if bn.momentum is None else float(bn.momentum)
-        L.check(lib.sat_bn_train_fwd_t(dt, L.ptr(x), rows, Cc, L.ptr(bn.weight), L.ptr(bn.bias), float(bn.eps), mom, L.ptr(bn.running_mean),
-                                       L.ptr(bn.running_var), L.ptr(mean), L.ptr(invstd), L.ptr(residual), int(relu), L.ptr(y), L.ptr(mask), L.ptr(scratch),
-                                       L.stream_ptr()), "sat_bn_train_fwd")
+        if tiles is not None and dt == 1:          # statistics already reduced per row tile by the producing convolution
+            L.check(lib.sat_bn_train_fwd_tiles_bf16(L.ptr(x), rows, Cc, L.ptr(tiles[0]), int(tiles[1]), L.ptr(bn.weight), L.ptr(bn.bias), float(bn.eps),
+                                                    mom, L.ptr(bn.running_mean), L.ptr(bn.running_var), L.ptr(mean), L.ptr(invstd), L.ptr(residual),
+                                                    int(relu), L.ptr(y), L.ptr(mask), L.ptr(scratch), L.stream_ptr()), "sat_bn_train_fwd_tiles")
+        else:
+            L.check(lib.sat_bn_train_fwd_t(dt, L.ptr(x), rows, Cc, L.ptr(bn.weight), L.ptr(bn.bias), float(bn.eps), mom, L.ptr(bn.running_mean),
+                                           L.ptr(bn.running_var), L.ptr(mean), L.ptr(invstd), L.ptr(residual), int(relu), L.ptr(y), L.ptr(mask),
+                                           L.ptr(scratch), L.stream_ptr()), "sat_bn_train_fwd")
         if _defer[0]:
             _tracked.append(bn.num_batches_tracked)
         else:
@@ -199,20 +223,22 @@ def _block_fwd(blk, x, training, W=None):
     W = W or (lambda p: p)
     r = _Rec(); r.kind, r.blk, r.x = blk.kind, blk, x
     r.cd = r.sd = None
+    # training: the convolution's epilogue leaves the BatchNorm statistics of its output (bf16 storage), see conv_fwd_stats
+    conv = conv_fwd_stats if training else (lambda *a: (conv_fwd(*a), None))
     if blk.downsample is not None:
-        r.cd = conv_fwd(x, W(blk.downsample[0].weight), blk.stride, 0)
-        r.idn, r.sd = bn_fwd(r.cd, blk.downsample[1], None, False, training)
+        r.cd, tl = conv(x, W(blk.downsample[0].weight), blk.stride, 0)
+        r.idn, r.sd = bn_fwd(r.cd, blk.downsample[1], None, False, training, tiles=tl)
     else:
         r.idn = x
     if blk.kind == "basic":
-        r.c1 = conv_fwd(x, W(blk.conv1.weight), blk.stride, 1); r.a1, r.s1 = bn_fwd(r.c1, blk.bn1, None, True, training, want_mask=True)
-        r.c2 = conv_fwd(r.a1, W(blk.conv2.weight), 1, 1)
-        r.out, r.s2 = bn_fwd(r.c2, blk.bn2, r.idn, True, training, want_mask=True)
+        r.c1, tl = conv(x, W(blk.conv1.weight), blk.stride, 1); r.a1, r.s1 = bn_fwd(r.c1, blk.bn1, None, True, training, want_mask=True, tiles=tl)
+        r.c2, tl = conv(r.a1, W(blk.conv2.weight), 1, 1)
+        r.out, r.s2 = bn_fwd(r.c2, blk.bn2, r.idn, True, training, want_mask=True, tiles=tl)
     else:
-        r.c1 = conv_fwd(x, W(blk.conv1.weight), 1, 0); r.a1, r.s1 = bn_fwd(r.c1, blk.bn1, None, True, training, want_mask=True)
-        r.c2 = conv_fwd(r.a1, W(blk.conv2.weight), blk.stride, 1); r.a2, r.s2 = bn_fwd(r.c2, blk.bn2, None, True, training, want_mask=True)
-        r.c3 = conv_fwd(r.a2, W(blk.conv3.weight), 1, 0)
-        r.out, r.s3 = bn_fwd(r.c3, blk.bn3, r.idn, True, training, want_mask=True)
+        r.c1, tl = conv(x, W(blk.conv1.weight), 1, 0); r.a1, r.s1 = bn_fwd(r.c1, blk.bn1, None, True, training, want_mask=True, tiles=tl)
+        r.c2, tl = conv(r.a1, W(blk.conv2.weight), blk.stride, 1); r.a2, r.s2 = bn_fwd(r.c2, blk.bn2, None, True, training, want_mask=True, tiles=tl)
+        r.c3, tl = conv(r.a2, W(blk.conv3.weight), 1, 0)
+        r.out, r.s3 = bn_fwd(r.c3, blk.bn3, r.idn, True, training, want_mask=True, tiles=tl)
     return r
 
 
@@ -297,8 +323,8 @@ class EncoderFn(torch.autograd.Function):
             L.check(lib.sat_image_normalize_nhwc4(L.ptr(img), L.ptr(x0), N, H, W, mean, std, st), "sat_image_normalize_nhwc4")
             L.check(lib.sat_pad_channels_3to4(L.ptr(w3), L.ptr(wp), conv1.out_channels * 49, 0, st), "sat_pad_channels_3to4")
         t["x0"], t["wp"] = x0, wp
-        t["c0"] = conv_fwd(x0, wp, 2, 3)
-        t["a0"], t["s0"] = bn_fwd(t["c0"], enc[2], None, True, training, want_mask=True)
+        t["c0"], tl = conv_fwd_stats(x0, wp, 2, 3) if training else (conv_fwd(x0, wp, 2, 3), None)
+        t["a0"], t["s0"] = bn_fwd(t["c0"], enc[2], None, True, training, want_mask=True, tiles=tl)
         Nn, Hh, Ww, Cc = t["a0"].shape
         P, Q = (Hh + 2 - 3) // 2 + 1, (Ww + 2 - 3) // 2 + 1
         t["p0"] = torch.empty(Nn, P, Q, Cc, dtype=adt, device=img.device)

@@ -293,3 +293,32 @@ def test_residual_block_bf16_storage(E, kind, cin, planes, stride):
         errs[k] = l2(grads[p], refp[k].grad)
     print(errs)
     assert max(errs.values()) <= 0.2, errs
+
+
+@pytest.mark.parametrize("N,H,W,C,K,R,stride,pad", [(4, 16, 16, 64, 64, 3, 1, 1), (3, 9, 9, 64, 256, 1, 1, 0), (2, 20, 20, 8, 64, 7, 2, 3),
+                                                    (5, 13, 11, 128, 72, 3, 2, 1), (8, 32, 32, 64, 128, 3, 1, 1)])
+def test_conv_epilogue_statistics_feed_batchnorm(E, N, H, W, C, K, R, stride, pad):
+    """bf16 conv whose epilogue leaves per-row-tile (sum, sum of squares) of its stored output; BatchNorm built on those tiles
+    must equal BatchNorm with its own statistics pass over the same tensor (ragged last tile, 64- and 128-row tiles, both kernels)."""
+    g = torch.Generator().manual_seed(N + H + C + K)
+    x = (torch.randn(N, H, W, C, generator=g) + 0.3).cuda().to(torch.bfloat16)
+    w = (torch.randn(K, C, R, R, generator=g) / (C * R * R) ** 0.5).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y, tiles = E.conv_fwd_stats(x, w, stride, pad)
+    y_ref = E.conv_fwd(x, w, stride, pad)
+    assert torch.equal(y, y_ref)
+    assert tiles is not None and tiles[1] in (64, 128)
+    rows = y.numel() // K
+    nt = -(-rows // tiles[1])
+    ts = tiles[0][:nt * K * 2].reshape(nt, K, 2).double().cpu()
+    yf = y.reshape(rows, K).double().cpu()
+    assert float((ts[:, :, 0].sum(0) - yf.sum(0)).abs().max()) <= 1e-4 * max(1.0, float(yf.sum(0).abs().max()))
+    assert float((ts[:, :, 1].sum(0) - (yf * yf).sum(0)).abs().max()) <= 1e-4 * float((yf * yf).sum(0).abs().max())
+    bn_a, bn_b = torch.nn.BatchNorm2d(K).cuda(), torch.nn.BatchNorm2d(K).cuda()
+    with torch.no_grad():
+        bn_a.weight.copy_(torch.rand(K, generator=g) + 0.5); bn_a.bias.copy_(torch.randn(K, generator=g) * 0.1)
+        bn_b.weight.copy_(bn_a.weight); bn_b.bias.copy_(bn_a.bias)
+    out_a, st_a = E.bn_fwd(y, bn_a, None, True, True, tiles=tiles)
+    out_b, st_b = E.bn_fwd(y, bn_b, None, True, True)
+    close(st_a[0], st_b[0], 1e-5, "mean from tiles"); close(st_a[1], st_b[1], 1e-4, "invstd from tiles")
+    close(out_a.float(), out_b.float(), 1e-2, "bn output from tiles")
+    close(bn_a.running_var, bn_b.running_var, 1e-5, "running_var from tiles")
