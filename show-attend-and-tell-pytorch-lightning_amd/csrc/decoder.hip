@@ -15,6 +15,7 @@ struct Ws {
     float *U, *mean, *f, *init_img, *H_all, *C_all, *HC, *Z, *XZ, *Y, *GY, *Uact, *Wcat, *bcat;
     float *Udrop, *mean_rows, *f_rows, *init_rows, *df_rows;     // only carved when dropout > 0
     float *GU, *DGU, *bup;                                       // stacked LSTM layers (layers > 1): gates, gate grads, bias sums
+    __bf16 *Wb_out, *Ub;                                         // bf16 mode: bf16 copies of output.output.weight and of the packed deep-output rows
     int* Tok; int* flags;
     // backward scratch
     float *dA, *dHout, *dZout, *DZ, *DHC, *dXZ, *dHc, *dCc, *dU, *dwf_part, *dY, *colpart, *dinit_img, *df, *dmean, *slab;
@@ -51,6 +52,10 @@ Ws layout(const sat_decoder_dims& d, char* base) {
     if (d.dropout > 0.f) {
         w.Udrop = (float*)take((size_t)(d.P > 0 ? d.P : 1) * d.m); w.mean_rows = (float*)take((size_t)N * d.D); w.f_rows = (float*)take((size_t)N * d.m);
         w.init_rows = (float*)take((size_t)N * 2 * d.n * NL); w.df_rows = (float*)take((size_t)N * d.m);
+    }
+    w.Wb_out = w.Ub = nullptr;
+    if (d.precision && d.m % 64 == 0 && d.V % 8 == 0) {           // operands of the vocabulary projection for the direct-to-LDS GEMM
+        w.Wb_out = (__bf16*)take((size_t)d.V * d.m, 2); w.Ub = (__bf16*)take((size_t)(d.P > 0 ? d.P : 1) * d.m, 2);
     }
     w.flags = (int*)take((size_t)d.V);
     w.dA = (float*)take((size_t)(d.P > 0 ? d.P : 1) * d.m);
@@ -96,6 +101,19 @@ static int gemm(hipStream_t st, int amode, int bmode, const float* A, long lda, 
     g.amode = amode; g.bmode = bmode; g.accumulate = acc; g.epi = epi; g.bias = bias; g.a_rows = a_rows; g.c_rows = c_rows;
     g.e0 = e0; g.lde0 = lde0; g.c0 = c0; g.c1 = c1; g.slab = slab; g.slab_elems = slab_elems;
     g.bf16_mfma = t_bf16_mfma;
+    return launch_gemm(g, st);
+}
+
+// fp32 -> bf16 copy of n elements (n % 4 == 0)
+static int cast_bf16(hipStream_t st, const float* src, __bf16* dst, long n) {
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, st, src, dst, n / 4);
+    return launch_ok("cast_bf16");
+}
+// C (fp32) = A (bf16, rows x K) * B^T (bf16, N x K): both operands bf16 in HBM -> gemm_glds.hip
+static int gemm_bb_nt(hipStream_t st, const __bf16* A, long lda, const __bf16* B, long ldb, float* C, long ldc, int M, int N, int K, int epi, const float* bias) {
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.amode = A_ROW; g.bmode = B_ROW; g.epi = epi; g.bias = bias; g.a_bf16 = g.b_bf16 = 1; g.c_bf16 = 0; g.bf16_mfma = 1;
     return launch_gemm(g, st);
 }
 
@@ -159,6 +177,12 @@ static int flush_outputs(hipStream_t st, const sat_decoder_dims& d, const sat_de
                            (unsigned long long)d.dropout_seed, 2u, (long)p0);
         SAT_TRY(launch_ok("output dropout"));
         uin = ud;
+    }
+    if (w.Wb_out) {          // bf16 mode: vocabulary projection on bf16 copies of both operands.  The weight is copied at every flush:
+                             // under weight tying it is the embedding table, which max-norm renormalisation edits during the loop
+        SAT_TRY(cast_bf16(st, p.out_w, w.Wb_out, (long)d.V * d.m));
+        SAT_TRY(cast_bf16(st, uin, w.Ub + (long)p0 * d.m, (long)rows * d.m));
+        return gemm_bb_nt(st, w.Ub + (long)p0 * d.m, d.m, w.Wb_out, d.m, logits + (long)p0 * d.V, d.V, rows, d.V, d.m, p.out_b ? EPI_BIAS : EPI_NONE, p.out_b);
     }
     return gemm(st, A_ROW, B_ROW, uin, d.m, p.out_w, d.m, logits + (long)p0 * d.V, d.V, rows, d.V, d.m, 0,
                 p.out_b ? EPI_BIAS : EPI_NONE, p.out_b);

@@ -24,6 +24,16 @@ __global__ void fill_kernel(float* p, long n, float v) {
     if (i < n) p[i] = v;
 }
 
+// fp32 -> bf16 copy, 4 elements per thread (n4 = elements / 4)
+__global__ void cast_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long n4) {
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n4) return;
+    const float4 v = reinterpret_cast<const float4*>(src)[e];
+    typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+    b4 o; o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+    reinterpret_cast<b4*>(dst)[e] = o;
+}
+
 __global__ void fill_int_kernel(int* p, long n, int v) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;

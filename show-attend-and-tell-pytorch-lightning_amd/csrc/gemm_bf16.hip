@@ -352,9 +352,11 @@ int launch_gemm_bf16(const GemmArgs& g, hipStream_t st) {
     k.kchunk = per * KB; k.nsplit = cdiv(ktiles, per);
     k.wide_store = (g.c_bf16 && !g.c_rows && k.nsplit == 1 && g.N % 8 == 0 && g.ldc % 8 == 0 && al16(g.C) &&
                     (g.epi == EPI_NONE || g.epi == EPI_BIAS || g.epi == EPI_BIAS_RELU)) ? 1 : 0;
+    if (!g.c_bf16 && !g.c_rows && k.nsplit == 1 && g.N % 4 == 0 && g.ldc % 4 == 0 && al16(g.C)) k.wide_store = 1;      // fp32 result
+    k.wide_slab = (k.nsplit > 1 && g.N % 4 == 0 && al16(g.slab)) ? 1 : 0;
     k.tile_stats = nullptr;
     if (g.tile_rows) *g.tile_rows = 0;
-    if (g.tile_stats && g.tile_rows && k.wide_store && !g.accumulate && !g.g.cls) { k.tile_stats = g.tile_stats; *g.tile_rows = BMt; }
+    if (g.tile_stats && g.tile_rows && g.c_bf16 && k.wide_store && !g.accumulate && !g.g.cls) { k.tile_stats = g.tile_stats; *g.tile_rows = BMt; }
 
     static const bool log_shapes = getenv("SAT_LOG_GEMM") != nullptr;     // dev: one stderr line per launch, in launch order
     if (log_shapes) fprintf(stderr, "GEMMLOG am=%d bm=%d M=%d N=%d K=%d ns=%d acc=%d types=%d%d%d epi=%d\n", g.amode, g.bmode, g.M, g.N, g.K, k.nsplit,

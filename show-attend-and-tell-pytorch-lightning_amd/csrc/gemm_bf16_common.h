@@ -22,7 +22,8 @@ struct BArgs {
     ConvGeom g;
     int kchunk, nsplit;
     float* slab;
-    int wide_store;       // bf16 output staged through LDS and written 16 bytes per lane
+    int wide_store;       // output tile staged through LDS and written 16 bytes per lane
+    int wide_slab = 0;    // the same for split-K partials
     int nstage = 2;       // gemm_glds.hip: LDS ring depth
     int rotate = 1 << 20; // gemm_glds.hip: per-workgroup rotation of the k-tile sequence, window in k-tiles (0 = off)
     float* tile_stats = nullptr;   // optional (wide_store only): per row tile and output column (sum, sum of squares) of the stored bf16 values
@@ -144,6 +145,46 @@ __device__ __forceinline__ void store_tile(const BArgs& a, f32x16 (&acc)[BM / 64
                     for (int e = 0; e < 8; ++e) o[e] = (__bf16)((float)o[e] + (float)old[e]);
                 }
                 *reinterpret_cast<bf16x8*>(dst) = o;
+            }
+        }
+        return;
+    }
+    if ((a.nsplit > 1) ? a.wide_slab : (sizeof(TC) == 4 && a.wide_store)) {
+        // fp32 result or split-K partial: the C layout gives each lane one column (4-byte stores).  Stage half the tile at a
+        // time in LDS as fp32 and write 16-byte row segments; accumulate and the epilogue function run in the write phase
+        // (same order as put(): C = f(C_old + acc)).
+        constexpr int LDF = BN + 4, HALF = BM / 2, VPR = BN / 4;
+        static_assert(HALF * LDF * 4 <= SMEM_ELEMS * 2, "half a fp32 C tile must fit the staging buffers");
+        float* fs = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            __syncthreads();
+            if (wm == h * HALF) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            fs[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDF + wn + j * 32 + li] = acc[i][j][r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int jj = 0; jj < HALF * VPR / NT; ++jj) {
+                const int v = tid + jj * NT, lr = v / VPR, lc = (v % VPR) * 4;
+                const int row = bm + h * HALF + lr, col = bn + lc;
+                if (row < a.M && col < a.N) {
+                    float4 o = *reinterpret_cast<const float4*>(fs + lr * LDF + lc);
+                    if (a.nsplit > 1) { *reinterpret_cast<float4*>(a.slab + ((long)bz * a.M + row) * a.N + col) = o; continue; }
+                    const long orow = a.g.cls ? class_row(a, row) : (long)row;
+                    float* dst = reinterpret_cast<float*>(a.C) + orow * a.ldc + col;
+                    if (a.accumulate) { const float4 old = *reinterpret_cast<const float4*>(dst); o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+                    if (a.epi != EPI_NONE) {
+                        o.x = ep_value(a, row, col, o.x); o.y = ep_value(a, row, col + 1, o.y);
+                        o.z = ep_value(a, row, col + 2, o.z); o.w = ep_value(a, row, col + 3, o.w);
+                    }
+                    *reinterpret_cast<float4*>(dst) = o;
+                }
             }
         }
         return;
