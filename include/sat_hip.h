@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SAT_HIP_ABI_VERSION 8
+#define SAT_HIP_ABI_VERSION 9
 
 int sat_abi_version(void);
 const char* sat_last_error(void);
@@ -268,6 +268,8 @@ typedef struct sat_opt_tensor {
     float* v;             /* Adam exp_avg_sq                                       */
     int64_t n;
     float lr, weight_decay;    /* of the parameter's group                        */
+    void* shadow_bf16;         /* or NULL: the updated parameter is also written here as bf16 (same element order): the
+                                  filter copies the bf16 convolutions read, kept current without a cast pass per step */
 } sat_opt_tensor;
 typedef struct sat_opt_chunk { int32_t tensor; int32_t reserved; int64_t start; } sat_opt_chunk;
 typedef struct sat_opt_hyper {

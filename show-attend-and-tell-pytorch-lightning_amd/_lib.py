@@ -63,7 +63,7 @@ class DecoderParams(C.Structure):
 
 class OptTensor(C.Structure):
     _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_int64), ("lr", C.c_float),
-                ("weight_decay", C.c_float)]
+                ("weight_decay", C.c_float), ("shadow_bf16", C.c_void_p)]
 
 
 class OptHyper(C.Structure):
@@ -192,8 +192,8 @@ def lib():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(handle, name)          # AttributeError if the export is missing
             fn.restype, fn.argtypes = res, args
-        if handle.sat_abi_version() != 8:
-            raise SatHipError("libsat_hip.so ABI version %d != 8 (rebuild: make -C csrc)" % handle.sat_abi_version())
+        if handle.sat_abi_version() != 9:
+            raise SatHipError("libsat_hip.so ABI version %d != 9 (rebuild: make -C csrc)" % handle.sat_abi_version())
         _lib = handle
     return _lib
 

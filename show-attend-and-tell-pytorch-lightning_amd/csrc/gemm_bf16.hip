@@ -282,7 +282,8 @@ static int runb(const BArgs& k, hipStream_t st) {
     SAT_TRY(launch_ok("gemm_bf16_kernel"));
     if (k.nsplit > 1) {
         long total = (long)k.M * k.N;
-        hipLaunchKernelGGL(splitk_reduce_b_kernel<TC>, dim3(cdiv(total, 256)), dim3(256), 0, st, k);
+        if (k.wide_slab) hipLaunchKernelGGL(splitk_reduce_b4_kernel<TC>, dim3(cdiv(total / 4, 256)), dim3(256), 0, st, k);
+        else hipLaunchKernelGGL(splitk_reduce_b_kernel<TC>, dim3(cdiv(total, 256)), dim3(256), 0, st, k);
         SAT_TRY(launch_ok("splitk_reduce_b"));
     }
     return SAT_OK;
@@ -352,7 +353,7 @@ int launch_gemm_bf16(const GemmArgs& g, hipStream_t st) {
     k.kchunk = per * KB; k.nsplit = cdiv(ktiles, per);
     k.wide_store = (g.c_bf16 && !g.c_rows && k.nsplit == 1 && g.N % 8 == 0 && g.ldc % 8 == 0 && al16(g.C) &&
                     (g.epi == EPI_NONE || g.epi == EPI_BIAS || g.epi == EPI_BIAS_RELU)) ? 1 : 0;
-    if (!g.c_bf16 && !g.c_rows && k.nsplit == 1 && g.N % 4 == 0 && g.ldc % 4 == 0 && al16(g.C)) k.wide_store = 1;      // fp32 result
+    if (!g.c_bf16 && !g.c_rows && g.N % 4 == 0 && g.ldc % 4 == 0 && al16(g.C)) k.wide_store = 1;      // fp32 result (with split-K: of the reduce kernel)
     k.wide_slab = (k.nsplit > 1 && g.N % 4 == 0 && al16(g.slab)) ? 1 : 0;
     k.tile_stats = nullptr;
     if (g.tile_rows) *g.tile_rows = 0;

@@ -213,6 +213,26 @@ __global__ void splitk_reduce_b_kernel(BArgs a) {
     for (int z = 0; z < a.nsplit; ++z) v += a.slab[(long)z * total + idx];
     put<TC>(a, (int)(idx / a.N), (int)(idx % a.N), v);
 }
+// the same, four consecutive columns per thread (N % 4 == 0, slab 16-byte aligned): fixed z order, 16-byte loads
+template <typename TC>
+__global__ void splitk_reduce_b4_kernel(BArgs a) {
+    const long idx4 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total4 = (long)a.M * a.N / 4;
+    if (idx4 >= total4) return;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* s4 = reinterpret_cast<const float4*>(a.slab);
+#pragma unroll 4
+    for (int z = 0; z < a.nsplit; ++z) { const float4 t = s4[(long)z * total4 + idx4]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+    const long e = idx4 * 4; const int row = (int)(e / a.N), col = (int)(e % a.N);
+    if (sizeof(TC) == 4 && a.wide_store && !a.g.cls) {          // wide_store: fp32 C, no row scatter, 16-byte addressable rows
+        float* dst = reinterpret_cast<float*>(a.C) + (long)row * a.ldc + col;
+        if (a.accumulate) { const float4 old = *reinterpret_cast<const float4*>(dst); v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w; }
+        if (a.epi != EPI_NONE) { v.x = ep_value(a, row, col, v.x); v.y = ep_value(a, row, col + 1, v.y); v.z = ep_value(a, row, col + 2, v.z); v.w = ep_value(a, row, col + 3, v.w); }
+        *reinterpret_cast<float4*>(dst) = v;
+    } else {
+        put<TC>(a, row, col, v.x); put<TC>(a, row, col + 1, v.y); put<TC>(a, row, col + 2, v.z); put<TC>(a, row, col + 3, v.w);
+    }
+}
 
 // XCD-aware tile order: the dispatcher deals workgroups round-robin over the 8 XCDs (each with its own L2), so
 // workgroups i and i+8 share an L2.  Give every XCD a contiguous run of logical tiles (x fastest): the column

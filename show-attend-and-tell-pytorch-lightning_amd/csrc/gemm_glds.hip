@@ -385,7 +385,8 @@ static int rung(const BArgs& k, hipStream_t st) {
     SAT_TRY(launch_ok("gemm_glds_kernel"));
     if (k.nsplit > 1) {
         long total = (long)k.M * k.N;
-        hipLaunchKernelGGL(splitk_reduce_b_kernel<TC>, dim3(cdiv(total, 256)), dim3(256), 0, st, k);
+        if (k.wide_slab) hipLaunchKernelGGL(splitk_reduce_b4_kernel<TC>, dim3(cdiv(total / 4, 256)), dim3(256), 0, st, k);
+        else hipLaunchKernelGGL(splitk_reduce_b_kernel<TC>, dim3(cdiv(total, 256)), dim3(256), 0, st, k);
         SAT_TRY(launch_ok("splitk_reduce_b"));
     }
     return SAT_OK;

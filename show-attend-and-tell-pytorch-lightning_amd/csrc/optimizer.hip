@@ -39,6 +39,26 @@ __global__ __launch_bounds__(256) void grad_norm_finish_kernel(const double* __r
     }
 }
 
+__device__ __forceinline__ void opt_update(const sat_opt_hyper& h, float lr, float wd, float coef, float& p, float g, float& m, float& v) {
+    g *= coef;
+    if (h.clip_value > 0.f) g = fminf(fmaxf(g, -h.clip_value), h.clip_value);        // clip_grad_value_
+    if (h.kind == SAT_OPT_SGD) {
+        if (wd != 0.f) g = fmaf(wd, p, g);
+        if (h.momentum != 0.f) {
+            m = h.first_step ? g : fmaf(h.momentum, m, g);                            // torch: buf = grad on the first step
+            g = h.nesterov ? fmaf(h.momentum, m, g) : m;
+        }
+        p -= lr * g;
+    } else {
+        if (h.kind == SAT_OPT_ADAMW) p *= 1.f - lr * wd;                              // decoupled decay
+        else if (wd != 0.f) g = fmaf(wd, p, g);                                       // Adam: L2 term joins the gradient
+        m = m + (g - m) * (1.f - h.beta1);                                            // exp_avg.lerp_(grad, 1 - beta1)
+        v = h.beta2 * v + (1.f - h.beta2) * g * g;
+        const float denom = sqrtf(v) / h.bias_correction2_sqrt + h.eps;
+        p -= (lr / h.bias_correction1) * (m / denom);
+    }
+}
+
 __global__ __launch_bounds__(256) void optimizer_step_kernel(const sat_opt_tensor* __restrict__ tensors, const sat_opt_chunk* __restrict__ chunks,
                                                              sat_opt_hyper h, const float* __restrict__ clip_coef) {
     const sat_opt_chunk c = chunks[blockIdx.x];
@@ -46,27 +66,40 @@ __global__ __launch_bounds__(256) void optimizer_step_kernel(const sat_opt_tenso
     const long end = (c.start + OPT_CHUNK < t.n) ? c.start + OPT_CHUNK : t.n;
     const float coef = clip_coef ? clip_coef[0] : 1.f;
     const float lr = t.lr, wd = t.weight_decay;
-    for (long i = c.start + threadIdx.x; i < end; i += 256) {
-        float g = t.g[i] * coef;
-        if (h.clip_value > 0.f) g = fminf(fmaxf(g, -h.clip_value), h.clip_value);        // clip_grad_value_
-        float p = t.p[i];
-        if (h.kind == SAT_OPT_SGD) {
-            if (wd != 0.f) g = fmaf(wd, p, g);
-            if (h.momentum != 0.f) {
-                float b = h.first_step ? g : fmaf(h.momentum, t.m[i], g);                 // torch: buf = grad on the first step
-                t.m[i] = b;
-                g = h.nesterov ? fmaf(h.momentum, b, g) : b;
+    const bool has_m = t.m != nullptr, has_v = t.v != nullptr;
+    // 16 bytes per lane where the tensor allows it (chunk starts are multiples of 64 Ki elements; bases come 16-byte aligned
+    // from the allocator, checked here), scalar tail
+    const bool vec = ((reinterpret_cast<uintptr_t>(t.p) | reinterpret_cast<uintptr_t>(t.g) | reinterpret_cast<uintptr_t>(t.m) |
+                       reinterpret_cast<uintptr_t>(t.v)) & 15) == 0;
+    long i = c.start;
+    if (vec) {
+        const long nv = (end - c.start) / 4;
+        for (long q = threadIdx.x; q < nv; q += 256) {
+            const long e = c.start + q * 4;
+            float4 p4 = *reinterpret_cast<const float4*>(t.p + e);
+            const float4 g4 = *reinterpret_cast<const float4*>(t.g + e);
+            float4 m4 = has_m ? *reinterpret_cast<const float4*>(t.m + e) : make_float4(0, 0, 0, 0);
+            float4 v4 = has_v ? *reinterpret_cast<const float4*>(t.v + e) : make_float4(0, 0, 0, 0);
+            opt_update(h, lr, wd, coef, p4.x, g4.x, m4.x, v4.x); opt_update(h, lr, wd, coef, p4.y, g4.y, m4.y, v4.y);
+            opt_update(h, lr, wd, coef, p4.z, g4.z, m4.z, v4.z); opt_update(h, lr, wd, coef, p4.w, g4.w, m4.w, v4.w);
+            *reinterpret_cast<float4*>(t.p + e) = p4;
+            if (t.shadow_bf16) {
+                typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+                b4 o; o[0] = (__bf16)p4.x; o[1] = (__bf16)p4.y; o[2] = (__bf16)p4.z; o[3] = (__bf16)p4.w;
+                *reinterpret_cast<b4*>(reinterpret_cast<__bf16*>(t.shadow_bf16) + e) = o;
             }
-            t.p[i] = p - lr * g;
-        } else {
-            if (h.kind == SAT_OPT_ADAMW) p *= 1.f - lr * wd;                              // decoupled decay
-            else if (wd != 0.f) g = fmaf(wd, p, g);                                       // Adam: L2 term joins the gradient
-            const float m = t.m[i] + (g - t.m[i]) * (1.f - h.beta1);                       // exp_avg.lerp_(grad, 1 - beta1)
-            const float v = h.beta2 * t.v[i] + (1.f - h.beta2) * g * g;
-            t.m[i] = m; t.v[i] = v;
-            const float denom = sqrtf(v) / h.bias_correction2_sqrt + h.eps;
-            t.p[i] = p - (lr / h.bias_correction1) * (m / denom);
+            if (has_m) *reinterpret_cast<float4*>(t.m + e) = m4;
+            if (has_v) *reinterpret_cast<float4*>(t.v + e) = v4;
         }
+        i = c.start + nv * 4;
+    }
+    for (i += threadIdx.x; i < end; i += 256) {
+        float p = t.p[i], m = has_m ? t.m[i] : 0.f, v = has_v ? t.v[i] : 0.f;
+        opt_update(h, lr, wd, coef, p, t.g[i], m, v);
+        t.p[i] = p;
+        if (t.shadow_bf16) reinterpret_cast<__bf16*>(t.shadow_bf16)[i] = (__bf16)p;
+        if (has_m) t.m[i] = m;
+        if (has_v) t.v[i] = v;
     }
 }
 

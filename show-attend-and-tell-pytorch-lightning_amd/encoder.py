@@ -307,7 +307,13 @@ class EncoderFn(torch.autograd.Function):
                 return p
             c = wcopy.get(p)
             if c is None:
-                c = wcopy[p] = cast_bf16(p)
+                # the copy lives on the parameter: FusedOptimizer rewrites it in its update kernel, so a training loop casts
+                # each filter once; any other in-place change of p bumps p._version and the copy is remade here
+                c = getattr(p, "_sat_bf16_shadow", None)
+                if c is None or getattr(p, "_sat_shadow_version", -1) != p._version or c.device != p.device:
+                    c = cast_bf16(p)
+                    p._sat_bf16_shadow, p._sat_shadow_version = c, p._version
+                wcopy[p] = c
             return c
 
         mean = (C.c_float * 3)(*enc[0].mean); std = (C.c_float * 3)(*enc[0].std)

@@ -16,6 +16,12 @@ from . import _lib as L
 KINDS = {"sgd": 0, "adam": 1, "adamw": 2}
 
 
+def _same_layout(a, b):
+    """same memory order: equal strides on every dimension that has more than one element (size-1 dimensions of a
+    channels_last 1x1 filter carry arbitrary strides)"""
+    return a.shape == b.shape and all(sa == sb for sa, sb, n in zip(a.stride(), b.stride(), a.shape) if n > 1)
+
+
 class FusedOptimizer(torch.optim.Optimizer):
     def __init__(self, params, kind="adam", lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, momentum=0.0, nesterov=False,
                  grad_clip=None, clip_value=0.0):
@@ -88,12 +94,16 @@ class FusedOptimizer(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p); st["exp_avg_sq"] = torch.zeros_like(p)
             st["step"] += 1
             steps.add(float(st["step"]))
-            grad = p.grad if p.grad.stride() == p.stride() else torch.empty_like(p).copy_(p.grad)     # element i of g <-> element i of p
+            grad = p.grad if _same_layout(p.grad, p) else torch.empty_like(p).copy_(p.grad)     # element i of g <-> element i of p
             m = st.get("momentum_buffer") if self.kind == "sgd" else st["exp_avg"]
             v = None if self.kind == "sgd" else st["exp_avg_sq"]
             t = table[i]
             t.p = p.data_ptr(); t.g = grad.data_ptr(); t.m = 0 if m is None else m.data_ptr(); t.v = 0 if v is None else v.data_ptr()
             t.n = p.numel(); t.lr = float(group["lr"]); t.weight_decay = float(group["weight_decay"])
+            sh = getattr(p, "_sat_bf16_shadow", None)      # bf16 filter copy of the encoder (encoder.py): kept current by this step
+            t.shadow_bf16 = sh.data_ptr() if (sh is not None and _same_layout(sh, p)) else 0
+            if t.shadow_bf16:
+                p._sat_shadow_version = p._version
             entries[i] = (p, group, grad)              # keep a re-laid-out gradient alive until the launch
         if len(steps) != 1:
             raise ValueError("FusedOptimizer: parameters are at different step counts %s" % sorted(steps))

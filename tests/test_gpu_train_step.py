@@ -145,3 +145,35 @@ def test_bf16_mode_tracks_the_fp32_oracle():
         else:
             assert e <= 0.15, "%s: relative L2 gradient error %.3e" % (k, e)
     print("bf16 mode: worst relative L2 gradient error", worst)
+
+
+def test_bf16_filter_copies_stay_current_through_optimizer_steps():
+    """bf16 mode reads bf16 copies of the conv filters.  The copy is made once (encoder.py) and then rewritten by the fused
+    optimizer's update kernel; after every step it must equal a fresh cast of the fp32 master weight, bit for bit, and two
+    trainings -- one keeping the copies, one re-casting every step -- must produce identical losses."""
+    losses = []
+    for keep in (True, False):
+        model, _, hp = make(dict(encoder_finetune_after=1, decoder_tf="always", encoder_lr=1e-3))
+        model.set_precision("bf16")
+        model.__dict__["_sat_global_step"] = 2
+        opt = model.configure_optimizers()
+        img, caps, lengths = batch(hp)
+        img, caps = img.cuda(), caps.cuda()
+        run = []
+        for step in range(4):
+            opt.zero_grad(set_to_none=True)
+            out = model.training_step((img, caps, lengths), 0)
+            out["loss"].backward()
+            opt.step()
+            run.append(float(out["loss"]))
+            convs = [p for n, p in model.encoder.named_parameters() if p.dim() == 4 and hasattr(p, "_sat_bf16_shadow")]
+            assert len(convs) >= 20
+            for p in convs:
+                if keep:
+                    assert p._sat_shadow_version == p._version
+                    assert torch.equal(p._sat_bf16_shadow.float(), p.detach().to(torch.bfloat16).float())
+                else:
+                    del p._sat_bf16_shadow                       # force a fresh cast at the next forward
+        losses.append(run)
+    assert losses[0] == losses[1], losses
+    assert losses[0][-1] < losses[0][0]
