@@ -107,6 +107,10 @@ def log(msg):
 
 
 MIN_WARM_S = 1.5
+PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+# in-library profile name -> kernel family of profiles/*_pmc_hbm.json (tools/pmc_aggregate.py)
+PMC_FAMILY = {"bn_apply_bwd": "bn_bwd_apply_kernel", "bn_apply_fwd": "bn_apply_kernel", "bn_stats_bwd": "bn_colstats_kernel<1>",
+              "bn_stats_fwd": "bn_colstats_kernel<0>"}
 
 
 def main():
@@ -199,21 +203,26 @@ def main():
         dom = entries[0] if entries else None
         roof = None
         if dom:
+            hbm_bound = dom["flops"] == 0           # streaming kernels (BatchNorm passes) are instrumented with bytes only
             tf = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
+            gbs = dom["bytes"] / (dom["total_ms"] * 1e-3) / 1e9
             peak = PEAK["bf16"] if ("bf16" in dom["name"] or "glds" in dom["name"]) else PEAK["f32"]
             traffic = None      # HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/pmc_aggregate.py), same workload only
             pmc = os.path.join(ROOT, "profiles", "r01_bf16_bench_c2_pmc_hbm.json")
             if args.config == "c2" and args.precision == "bf16" and not args.batch and not args.ragged and os.path.exists(pmc):
                 for row in json.load(open(pmc)):
-                    if row["family"] == dom["name"]:
+                    if row["family"] == PMC_FAMILY.get(dom["name"], dom["name"]):
                         traffic = round(row["hbm_bytes_per_launch"])
-            roof = {"bound": "mfma", "kernel": dom["name"], "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(tf / peak, 4), "traffic": traffic,
+            roof = {"bound": "hbm" if hbm_bound else "mfma", "kernel": dom["name"],
+                    "achieved": round(gbs if hbm_bound else tf, 2), "peak": PEAK_HBM_GBS if hbm_bound else peak,
+                    "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                    "frac": round((gbs / PEAK_HBM_GBS) if hbm_bound else (tf / peak), 4), "traffic": traffic,
                     "avg_launch_us": round(dom["total_ms"] * 1e3 / dom["launches"], 2), "launches_per_step": dom["launches"] // prof_steps,
-                    "flops_per_launch": dom["flops"] / dom["launches"],
+                    "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"], "flops_per_launch": dom["flops"] / dom["launches"],
                     "measured_on": "%d instrumented steps right after the timed region (events add launch overhead)" % prof_steps,
                     "top": [{"kernel": e["name"], "ms_per_step": round(e["total_ms"] / prof_steps, 3),
-                             "tflops": round(e["flops"] / (e["total_ms"] * 1e-3) / 1e12, 2) if e["total_ms"] > 0 else None}
+                             "tflops": round(e["flops"] / (e["total_ms"] * 1e-3) / 1e12, 2) if e["total_ms"] > 0 else None,
+                             "gbytes_per_s": round(e["bytes"] / (e["total_ms"] * 1e-3) / 1e9, 1) if e["total_ms"] > 0 else None}
                             for e in entries[:8]]}
         line = {"metric": "captions/sec (train step) at B=128, 256px, seq_len=22", "value": round(caps_per_s, 1), "unit": "captions/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_steps_run": warm_done, "ms_per_step": round(ms, 3), "higher_is_better": True,

@@ -7,6 +7,7 @@
 #include "../../include/sat_hip.h"
 #include "common.h"
 #include "gemm.h"
+#include "profile.h"
 
 namespace sat {
 
@@ -620,6 +621,7 @@ static int bn_train_fwd_t(const T* x, int64_t rows, int32_t C, const float* gamm
         SAT_TRY(launch_ok("bn_tile_reduce"));
         nparts = np; shift_src = nullptr;
     } else {
+        ProfScope prof("bn_stats_fwd", 0.0, (double)rows * C * sizeof(T), st);
         hipLaunchKernelGGL((bn_colstats_kernel<0, T>), dim3(cdiv(C / E, CV), nparts), dim3(256), 0, st, x, (const T*)nullptr, (const T*)nullptr,
                            (const unsigned char*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, (long)rows, C, CV, rp, p0, p1);
         SAT_TRY(launch_ok("bn_colstats<0>"));
@@ -627,6 +629,7 @@ static int bn_train_fwd_t(const T* x, int64_t rows, int32_t C, const float* gamm
     hipLaunchKernelGGL(bn_fwd_finalize_kernel<T>, dim3(cdiv(C, 4)), dim3(256), 0, st, p0, p1, shift_src, nparts, C, (long)rows, eps, momentum, save_mean, save_invstd, running_mean, running_var);
     SAT_TRY(launch_ok("bn_fwd_finalize"));
     long totalv = rows * (C / E);
+    ProfScope prof("bn_apply_fwd", 0.0, (double)rows * C * (sizeof(T) * (residual ? 3 : 2) + (relu_mask ? 0.125 : 0.0)), st);
     hipLaunchKernelGGL((bn_apply_kernel<T, false>), dim3(cdiv(totalv, 256)), dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta, residual, relu, y, relu_mask, totalv, C / E, -1.0f);
     return launch_ok("bn_apply");
 }
@@ -655,11 +658,15 @@ static int bn_train_bwd_t(const T* dy, const T* x, const T* y, int64_t rows, int
     SAT_REQUIRE(C % E == 0, "bn_train_bwd: C=%d must be a multiple of %d for this storage type", C, E);
     int CV, nparts; long rp; bn_grid(rows, C, E, CV, rp, nparts);
     double* p0 = reinterpret_cast<double*>(scratch); double* p1 = p0 + (long)nparts * C;
-    hipLaunchKernelGGL((bn_colstats_kernel<1, T>), dim3(cdiv(C / E, CV), nparts), dim3(256), 0, st, x, dy, y, relu_mask, save_mean, save_invstd, relu, (long)rows, C, CV, rp, p0, p1);
-    SAT_TRY(launch_ok("bn_colstats<1>"));
+    {
+        ProfScope prof("bn_stats_bwd", 0.0, (double)rows * C * (sizeof(T) * 2 + (relu ? (relu_mask ? 0.125 : (double)sizeof(T)) : 0.0)), st);
+        hipLaunchKernelGGL((bn_colstats_kernel<1, T>), dim3(cdiv(C / E, CV), nparts), dim3(256), 0, st, x, dy, y, relu_mask, save_mean, save_invstd, relu, (long)rows, C, CV, rp, p0, p1);
+        SAT_TRY(launch_ok("bn_colstats<1>"));
+    }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, p0, p1, nparts, C, dbeta, dgamma);
     SAT_TRY(launch_ok("bn_bwd_finalize"));
     long totalv = rows * (C / E);
+    ProfScope prof("bn_apply_bwd", 0.0, (double)rows * C * (sizeof(T) * (3 + (dres ? (dres_accumulate ? 2 : 1) : 0)) + (relu ? (relu_mask ? 0.125 : (double)sizeof(T)) : 0.0)), st);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(cdiv(totalv, 256)), dim3(256), 0, st, x, dy, y, relu_mask, save_mean, save_invstd, gamma, dbeta, dgamma, relu,
                        1.0f / (float)rows, dx, dres, dres_accumulate, totalv, C / E);
     return launch_ok("bn_bwd_apply");

@@ -293,17 +293,18 @@ __global__ __launch_bounds__(NT) void gemm_glds_kernel(BArgs a) {
             for (int t = 0; t < S; ++t) fill_tab(t, t);
             __syncthreads();
         }
-        for (int t = 0; t < S - 1 && t < T; ++t) issue(t, t);
+        const int pre = (S == 1) ? 1 : S - 1;          // a one-stage launch has a single k-tile: load it, multiply it
+        for (int t = 0; t < pre && t < T; ++t) issue(t, t);
         int cur = 0, nxt = S - 1;                      // stage of tile it / of tile it + S - 1
         for (int it = 0; it < T; ++it) {
-            const int ahead = min(T - 1 - it, S - 2);  // tiles newer than `it` already issued
+            const int ahead = (S == 1) ? 0 : min(T - 1 - it, S - 2);  // tiles newer than `it` already issued
             if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
             else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            const bool more = it + S - 1 < T;
+            const bool more = S > 1 && it + S - 1 < T;
             const __bf16* as = smem + cur * STAGE;
             const __bf16* bs = as + A_EL;
             // fragments are double buffered in registers: the reads of k-step s+1 are in flight under the MFMAs of step s
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(NT) void gemm_glds_kernel(BArgs a) {
             nxt = (nxt + 1 == S) ? 0 : nxt + 1;
         }
     }
-    store_tile<BM, BN, TC, 2 * STAGE>(a, acc, smem, bm, bn, bz, wm, wn, tid, lane);     // at least two stages are always allocated
+    store_tile<BM, BN, TC, 2 * STAGE>(a, acc, smem, bm, bn, bz, wm, wn, tid, lane);     // the launch allocates at least the epilogue's staging size
 }
 
 static const char* gname(int am, int bm) {
@@ -374,7 +375,10 @@ static int rung(const BArgs& k, hipStream_t st) {
         else snprintf(pname, sizeof pname, "gemm_glds_%s_%dx%d", gname(AM, BMo), BM, BN);
     }
     ProfScope prof(pname, 2.0 * k.M * k.N * k.K, 2.0 * k.M * k.K + 2.0 * k.N * k.K + (double)sizeof(TC) * k.M * k.N, st);
-    const size_t lds = (size_t)k.nstage * (BM + BN) * 64 * sizeof(__bf16);
+    size_t lds = (size_t)k.nstage * (BM + BN) * 64 * sizeof(__bf16);
+    // the epilogue stages the result tile in the same memory: bf16 tile (+ statistics) or half an fp32 tile
+    const size_t epi_lds = (sizeof(TC) == 2) ? (size_t)BM * (BN + 8) * 2 + 2 * BN * 2 * 4 : (size_t)(BM / 2) * (BN + 4) * 4;
+    if (lds < epi_lds) lds = epi_lds;
     static bool attr_set = false;        // per instantiation: allow the deepest ring (128 KiB of dynamic LDS)
     if (!attr_set) {
         SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BM, BN, AM, BMo, TC>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -409,9 +413,10 @@ int launch_gemm_glds(const BArgs& k0, int amode, int bmode, int c_bf16, int BMt,
     // ring depth: short reductions keep two stages (two workgroups per CU overlap each other); from `deep_from` k-tiles
     // on, one workgroup per CU with three tiles in flight hides the HBM / L2 latency that a cold operand costs
     const int ktiles = cdiv(k.kchunk < k.K ? k.kchunk : k.K, 64);
-    k.nstage = force_stages ? force_stages : (ktiles >= deep_from ? 4 : 2);
+    // a single k-tile needs one stage: less LDS, a third workgroup per CU for the streaming 1x1 layers with 64 input channels
+    k.nstage = force_stages ? force_stages : (ktiles >= deep_from ? 4 : (ktiles == 1 ? 1 : 2));
     k.rotate = rotate;
-    if (k.nstage < 2) k.nstage = 2;
+    if (k.nstage < 1) k.nstage = 1;
     if (k.nstage > 4) k.nstage = 4;
     const ConvGeom& g = k.g;
     if (k.K % 64 || k.kchunk % 64 || k.a_rows) return -1;

@@ -20,6 +20,10 @@ def family(name):
     m = re.search(r"gemm_f32_kernel<(\d+), (\d+), (\d), (\d)>", name)
     if m:
         return "gemm_f32_%s_%sx%s" % (MODE.get((m.group(3), m.group(4)), "?"), m.group(1), m.group(2))
+    if "bn_bwd_apply_kernel" in name: return "bn_bwd_apply_kernel"
+    if "bn_apply_kernel" in name: return "bn_apply_kernel"
+    m = re.search(r"bn_colstats_kernelILi(\d)E", name) or re.search(r"bn_colstats_kernel<(\d),", name)
+    if m: return "bn_colstats_kernel<%s>" % m.group(1)
     return name.split("(")[0][:80]
 
 
