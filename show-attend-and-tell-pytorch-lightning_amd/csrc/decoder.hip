@@ -145,13 +145,18 @@ int launch_attention_fwd(hipStream_t st, const float* ann, const float* U, const
     size_t lds = att_fwd_lds(L, A, vw);
     SAT_REQUIRE(lds <= 160 * 1024, "attention_fwd: L=%d A=%d need %zu B of LDS (> 160 KiB)", L, A, lds);
     dim3 grid(B, cdiv(D, dchunk));
+    const int RN = R < ATT_RMAX ? R : ATT_RMAX;            // rows per pass, compile-time in the kernel
+#define SAT_ATTF(VWV, RNV)                                                                                                                  \
+    case RNV:                                                                                                                               \
+        SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_fwd_kernel<VWV, RNV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((attention_fwd_kernel<VWV, RNV>), grid, dim3(ATTF_THREADS), lds, st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, R, L, D, A, dchunk); \
+        break;
     if (vec) {
-        SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_fwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(attention_fwd_kernel<4>, grid, dim3(ATTF_THREADS), lds, st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, R, L, D, A, dchunk);
+        switch (RN) { SAT_ATTF(4, 1) SAT_ATTF(4, 2) SAT_ATTF(4, 3) SAT_ATTF(4, 4) SAT_ATTF(4, 5) SAT_ATTF(4, 6) SAT_ATTF(4, 7) SAT_ATTF(4, 8) default: break; }
     } else {
-        SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_fwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(attention_fwd_kernel<1>, grid, dim3(ATTF_THREADS), lds, st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, R, L, D, A, dchunk);
+        switch (RN) { SAT_ATTF(1, 1) SAT_ATTF(1, 2) SAT_ATTF(1, 3) SAT_ATTF(1, 4) SAT_ATTF(1, 5) SAT_ATTF(1, 6) SAT_ATTF(1, 7) SAT_ATTF(1, 8) default: break; }
     }
+#undef SAT_ATTF
     return launch_ok("attention_fwd");
 }
 
@@ -365,7 +370,15 @@ int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
     // ---- back through time
     const size_t lds_b = att_bwd_lds(d.L, A, D);
     SAT_REQUIRE(lds_b <= 160 * 1024, "attention_bwd: L=%d A=%d D=%d need %zu B of LDS (> 160 KiB)", d.L, A, D, lds_b);
-    SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+    typedef void (*attb_fn)(const float*, const float*, const float*, int, const float*, const int*, int, const float*, const float*, int, const float*,
+                            const float*, const float*, float*, float*, int, float*, float*, int, int, int, int);
+    attb_fn attb = nullptr;
+    switch (d.R < ATT_RMAX ? d.R : ATT_RMAX) {           // rows per pass are compile-time in the kernel
+        case 1: attb = attention_bwd_kernel<1>; break; case 2: attb = attention_bwd_kernel<2>; break; case 3: attb = attention_bwd_kernel<3>; break;
+        case 4: attb = attention_bwd_kernel<4>; break; case 5: attb = attention_bwd_kernel<5>; break; case 6: attb = attention_bwd_kernel<6>; break;
+        case 7: attb = attention_bwd_kernel<7>; break; default: attb = attention_bwd_kernel<8>; break;
+    }
+    SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
     for (int t = ts - 1; t >= 0; --t) {
         const float* hc = w.HC + (long)t * N * HCW;
         float* dhc = w.DHC + (long)t * N * HCW;
@@ -382,7 +395,7 @@ int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
         SAT_TRY(launch_ok("lstm_cell_bwd"));
         // d(beta*z) = dG * W_ih[:, m:]
         SAT_TRY(gemm(st, A_ROW, B_KMAJOR, dhc + A + D, HCW, p.w_ih + m, m + D, w.dXZ, D, N, D, 4 * n, 0, EPI_NONE, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, slab, se));
-        hipLaunchKernelGGL(attention_bwd_kernel, dim3(d.B), dim3(ATTB_THREADS), lds_b, st, b.ann, w.U, hc, HCW, p.att_f, b.lengths, t, alphas,
+        hipLaunchKernelGGL(attb, dim3(d.B), dim3(ATTB_THREADS), lds_b, st, b.ann, w.U, hc, HCW, p.att_f, b.lengths, t, alphas,
                            dalphas, T1, w.Z + (long)t * N * D, w.dZout + (long)t * N * D, w.dXZ, w.DZ + (long)t * N * D, dhc, HCW, w.dU, w.dwf_part,
                            d.R, d.L, D, A);
         SAT_TRY(launch_ok("attention_bwd"));

@@ -162,7 +162,9 @@ __global__ void init_expand_bwd_kernel(const float* __restrict__ dh0, const floa
 // for all R rows.  dyn LDS: [RMAX*L scores/alpha][RMAX*A q][A w][part: 4*RMAX*chunk]
 constexpr int ATTF_WAVES = 16;                 // forward: 16 waves share the tanh-heavy score phase of one image
 constexpr int ATTF_THREADS = ATTF_WAVES * 64;
-template <int VW>
+// RN = caption rows handled per pass (compile-time: the row loops unroll without per-row guards -- a guard per FMA serialises
+// every FMA behind its operand read; dead rows run on zeros instead and are masked at the stores).
+template <int VW, int RN>
 __global__ __launch_bounds__(ATTF_THREADS) void attention_fwd_kernel(
     const float* __restrict__ ann, const float* __restrict__ U, const float* __restrict__ hc, int hc_ld,
     const float* __restrict__ wf, const int* __restrict__ lengths, int step,
@@ -178,29 +180,29 @@ __global__ __launch_bounds__(ATTF_THREADS) void attention_fwd_kernel(
     const float scale = 1.0f / sqrtf((float)L);
     for (int k = tid; k < A; k += ATTF_THREADS) s_w[k] = wf[k];
 
-    for (int r0 = 0; r0 < R; r0 += ATT_RMAX) {
-        const int rn = min(ATT_RMAX, R - r0);
+    for (int r0 = 0; r0 < R; r0 += RN) {
+        const int rn = min(RN, R - r0);
         const int i0 = b * R + r0;
         unsigned lmask = 0;
         for (int r = 0; r < rn; ++r) if (lengths[i0 + r] > step) lmask |= 1u << r;
         const bool any = lmask != 0;
         __syncthreads();
         if (any) {
-            for (int e = tid; e < rn * A; e += ATTF_THREADS) { int r = e / A, k = e - r * A; s_q[r * A + k] = hc[(long)(i0 + r) * hc_ld + k]; }
+            for (int e = tid; e < RN * A; e += ATTF_THREADS) { int r = e / A, k = e - r * A; s_q[r * A + k] = (r < rn) ? hc[(long)(i0 + r) * hc_ld + k] : 0.f; }
             __syncthreads();
             // ---- scores: wave per location, lanes over the attention dim
             for (int l = wave; l < L; l += ATTF_WAVES) {
-                float part[ATT_RMAX];
+                float part[RN];
 #pragma unroll
-                for (int r = 0; r < ATT_RMAX; ++r) part[r] = 0.f;
+                for (int r = 0; r < RN; ++r) part[r] = 0.f;
                 const float* u = U + ((long)b * L + l) * A;
                 for (int k = lane; k < A; k += 64) {
                     float uv = u[k], w = s_w[k];
 #pragma unroll
-                    for (int r = 0; r < ATT_RMAX; ++r) if (((lmask >> r) & 1u)) part[r] += w * fast_tanh(uv + s_q[r * A + k]);
+                    for (int r = 0; r < RN; ++r) part[r] = fmaf(w, fast_tanh(uv + s_q[r * A + k]), part[r]);
                 }
 #pragma unroll
-                for (int r = 0; r < ATT_RMAX; ++r) if (((lmask >> r) & 1u)) { float s = wave_sum(part[r]); if (lane == 0) s_sc[r * L + l] = s * scale; }
+                for (int r = 0; r < RN; ++r) { float s = wave_sum(part[r]); if (lane == 0) s_sc[r * L + l] = s * scale; }
             }
             __syncthreads();
             // ---- softmax over L: wave per row
@@ -216,6 +218,9 @@ __global__ __launch_bounds__(ATTF_THREADS) void attention_fwd_kernel(
                 for (int l = lane; l < L; l += 64) s_sc[r * L + l] *= inv;
             }
             __syncthreads();
+            // dead rows (finished captions, rows past R) take zero attention weights: the context loop below runs unguarded
+            for (int e = tid; e < RN * L; e += ATTF_THREADS) { int r = e / L; if (!((lmask >> r) & 1u)) s_sc[e] = 0.f; }
+            __syncthreads();
         }
         // ---- alphas out (only the first D-chunk block writes); dead rows are written as zeros
         if (blockIdx.y == 0) {
@@ -230,12 +235,12 @@ __global__ __launch_bounds__(ATTF_THREADS) void attention_fwd_kernel(
         const int gsz = ATT_THREADS / groups;           // threads per group
         const bool ctx_thread = tid < ATT_THREADS;       // the context phase runs on the first 4 waves; all waves do the scores
         const int g = ctx_thread ? tid / gsz : groups, tv = tid - (ctx_thread ? g : 0) * gsz;
-        float acc[ATT_RMAX][VW];
+        float acc[RN][VW];
         if (any) {
             for (int v0 = 0; v0 < nv; v0 += gsz) {
                 const int v = v0 + tv;
 #pragma unroll
-                for (int r = 0; r < ATT_RMAX; ++r)
+                for (int r = 0; r < RN; ++r)
 #pragma unroll
                     for (int c = 0; c < VW; ++c) acc[r][c] = 0.f;
                 if (v < nv && g < groups) {
@@ -245,22 +250,22 @@ __global__ __launch_bounds__(ATTF_THREADS) void attention_fwd_kernel(
                         if (VW == 4) { float4 t4 = *reinterpret_cast<const float4*>(base + (long)l * D); x[0] = t4.x; x[1 % VW] = t4.y; x[2 % VW] = t4.z; x[3 % VW] = t4.w; }
                         else x[0] = base[(long)l * D];
 #pragma unroll
-                        for (int r = 0; r < ATT_RMAX; ++r) if (((lmask >> r) & 1u)) { float al = s_sc[r * L + l];
+                        for (int r = 0; r < RN; ++r) { const float al = s_sc[r * L + l];
 #pragma unroll
-                            for (int c = 0; c < VW; ++c) acc[r][c] += al * x[c]; }
+                            for (int c = 0; c < VW; ++c) acc[r][c] = fmaf(al, x[c], acc[r][c]); }
                     }
                 }
                 // combine the l-groups through LDS in a fixed order
                 __syncthreads();
                 if (v < nv && g < groups)
 #pragma unroll
-                    for (int r = 0; r < ATT_RMAX; ++r)
+                    for (int r = 0; r < RN; ++r)
 #pragma unroll
                         for (int c = 0; c < VW; ++c) s_part[((g * ATT_RMAX + r) * gsz + tv) * VW + c] = acc[r][c];
                 __syncthreads();
                 if (g == 0 && v < nv) {
 #pragma unroll
-                    for (int r = 0; r < ATT_RMAX; ++r) {
+                    for (int r = 0; r < RN; ++r) {
                         if (r >= rn) continue;
                         const long orow = (long)(i0 + r);
 #pragma unroll
@@ -343,6 +348,7 @@ __global__ void lstm_cell_bwd_kernel(const float* __restrict__ gates, int g_ld, 
 // dyn LDS: [RMAX*L alpha][RMAX*L dalpha/ds][RMAX*A q][A w][RMAX*D dz][4*RMAX*A dq partial][4*A dw partial]
 constexpr int ATTB_WAVES = 16;                 // 1024 threads: one block per image, so hide latency with waves
 constexpr int ATTB_THREADS = ATTB_WAVES * 64;
+template <int RN>
 __global__ __launch_bounds__(ATTB_THREADS) void attention_bwd_kernel(
     const float* __restrict__ ann, const float* __restrict__ U, const float* __restrict__ hc, int hc_ld,
     const float* __restrict__ wf, const int* __restrict__ lengths, int step,
@@ -363,15 +369,15 @@ __global__ __launch_bounds__(ATTB_THREADS) void attention_bwd_kernel(
     for (int k = tid; k < A; k += ATTB_THREADS) s_w[k] = wf[k];
     for (int e = tid; e < ATTB_WAVES * A; e += ATTB_THREADS) s_dw[e] = 0.f;
 
-    for (int r0 = 0; r0 < R; r0 += ATT_RMAX) {
-        const int rn = min(ATT_RMAX, R - r0);
+    for (int r0 = 0; r0 < R; r0 += RN) {
+        const int rn = min(RN, R - r0);
         const int i0 = b * R + r0;
         unsigned lmask = 0;
         for (int r = 0; r < rn; ++r) if (lengths[i0 + r] > step) lmask |= 1u << r;
         const bool any = lmask != 0;
         __syncthreads();
-        // gate backward + dz for every row of the chunk (dead rows: zeros)
-        for (int e = tid; e < rn * D; e += ATTB_THREADS) {
+        // gate backward + dz for every row of the pass (dead rows and rows past R: zeros, so the loops below run unguarded)
+        for (int e = tid; e < RN * D; e += ATTB_THREADS) {
             int r = e / D, d = e - r * D; long row = i0 + r;
             float dz = 0.f, dbp = 0.f;
             if (((lmask >> r) & 1u)) {
@@ -380,31 +386,30 @@ __global__ __launch_bounds__(ATTB_THREADS) void attention_bwd_kernel(
                 dbp = dx * z * beta * (1.f - beta);
             }
             s_dz[r * D + d] = dz;
-            DZ[row * D + d] = dz;
-            dhc[row * dhc_ld + A + d] = dbp;
+            if (r < rn) { DZ[row * D + d] = dz; dhc[row * dhc_ld + A + d] = dbp; }
         }
         if (!any) {
             for (int e = tid; e < rn * A; e += ATTB_THREADS) { int r = e / A, k = e - r * A; dhc[(long)(i0 + r) * dhc_ld + k] = 0.f; }
             continue;
         }
-        for (int e = tid; e < rn * A; e += ATTB_THREADS) { int r = e / A, k = e - r * A; s_q[r * A + k] = hc[(long)(i0 + r) * hc_ld + k]; }
-        for (int e = tid; e < rn * L; e += ATTB_THREADS) { int r = e / L, l = e - r * L; s_al[r * L + l] = ((lmask >> r) & 1u) ? alphas[((long)(i0 + r) * T1 + step) * L + l] : 0.f; }
+        for (int e = tid; e < RN * A; e += ATTB_THREADS) { int r = e / A, k = e - r * A; s_q[r * A + k] = (r < rn) ? hc[(long)(i0 + r) * hc_ld + k] : 0.f; }
+        for (int e = tid; e < RN * L; e += ATTB_THREADS) { int r = e / L, l = e - r * L; s_al[r * L + l] = ((lmask >> r) & 1u) ? alphas[((long)(i0 + r) * T1 + step) * L + l] : 0.f; }
         __syncthreads();
         // ---- dalpha[r][l] = dz[r] . ann[b,l,:]  (wave per location)
         for (int l = wave; l < L; l += ATTB_WAVES) {
-            float part[ATT_RMAX];
+            float part[RN];
 #pragma unroll
-            for (int r = 0; r < ATT_RMAX; ++r) part[r] = 0.f;
+            for (int r = 0; r < RN; ++r) part[r] = 0.f;
             const float* a = ann + ((long)b * L + l) * D;
             for (int d = lane; d < D; d += 64) {
                 float av = a[d];
 #pragma unroll
-                for (int r = 0; r < ATT_RMAX; ++r) if (((lmask >> r) & 1u)) part[r] += av * s_dz[r * D + d];
+                for (int r = 0; r < RN; ++r) part[r] = fmaf(av, s_dz[r * D + d], part[r]);
             }
 #pragma unroll
-            for (int r = 0; r < ATT_RMAX; ++r) if (((lmask >> r) & 1u)) {
+            for (int r = 0; r < RN; ++r) {
                 float s = wave_sum(part[r]);
-                if (lane == 0) s_da[r * L + l] = s + (dalphas_ext ? dalphas_ext[((long)(i0 + r) * T1 + step) * L + l] : 0.f);
+                if (lane == 0) s_da[r * L + l] = ((lmask >> r) & 1u) ? s + (dalphas_ext ? dalphas_ext[((long)(i0 + r) * T1 + step) * L + l] : 0.f) : 0.f;
             }
         }
         __syncthreads();
@@ -420,9 +425,9 @@ __global__ __launch_bounds__(ATTB_THREADS) void attention_bwd_kernel(
         // ---- through tanh: wave per location, lanes over the attention dim (2 per lane at A=128)
         for (int k0 = 0; k0 < A; k0 += 64) {
             const int k = k0 + lane;
-            float dq[ATT_RMAX]; float dw = 0.f;
+            float dq[RN]; float dw = 0.f;
 #pragma unroll
-            for (int r = 0; r < ATT_RMAX; ++r) dq[r] = 0.f;
+            for (int r = 0; r < RN; ++r) dq[r] = 0.f;
             if (k < A) {
                 const float w = s_w[k];
                 for (int l = wave; l < L; l += ATTB_WAVES) {
@@ -430,16 +435,16 @@ __global__ __launch_bounds__(ATTB_THREADS) void attention_bwd_kernel(
                     const float uv = U[uo];
                     float du = 0.f;
 #pragma unroll
-                    for (int r = 0; r < ATT_RMAX; ++r) if (((lmask >> r) & 1u)) {
+                    for (int r = 0; r < RN; ++r) {             // dead rows: ds = 0
                         float th = fast_tanh(uv + s_q[r * A + k]);
                         float ds = s_da[r * L + l];
                         float dp = ds * w * (1.f - th * th);
-                        dq[r] += dp; du += dp; dw += ds * th;
+                        dq[r] += dp; du += dp; dw = fmaf(ds, th, dw);
                     }
                     dU[uo] += du;                   // this block owns image b: plain read-modify-write, fixed order
                 }
 #pragma unroll
-                for (int r = 0; r < ATT_RMAX; ++r) s_dq[(wave * ATT_RMAX + r) * A + k] = dq[r];
+                for (int r = 0; r < RN; ++r) s_dq[(wave * ATT_RMAX + r) * A + k] = dq[r];
                 s_dw[wave * A + k] += dw;
             }
         }
