@@ -9,6 +9,7 @@ import math
 from types import SimpleNamespace
 
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from torch.nn.utils.rnn import PackedSequence
@@ -309,7 +310,8 @@ class SAT(SATDecoder, _Base):
     state-dict keys; ``train_batch`` / ``training_step`` / ``configure_optimizers`` keep their signatures.
     Construction order follows the reference (criterion, encoder, embedding, init_lstm, lstm, attention, beta,
     output) so that a seed produces the same parameter stream.  ``caption`` / ``forward`` run the reference's per-image
-    beam search (beam / multinomial / topk sampling, decoder noise) on the HIP step kernels; the nltk metrics (model.py:646-718) are out of scope."""
+    beam search (beam / multinomial / topk sampling, decoder noise) on the HIP step kernels; ``score_captions`` / ``val_batch`` /
+    ``validation_step`` (model.py:646-718) use metrics.py, the nltk algorithms restated."""
 
     def __init__(self, **kwargs):
         nn.Module.__init__(self)
@@ -421,6 +423,88 @@ class SAT(SATDecoder, _Base):
         loss = loss + Dk.DoublyStochasticFn.apply(alphas, float(hp.att_gamma))      # model.py:594
         self.__dict__["_sat_global_step"] = gstep + 1
         return {"loss": loss, "accuracy": self.criterion.last_accuracy, "epsilon_tf": float(epsilon)}
+
+    # ------------------------------------------------------------------ validation (model.py:630-718)
+    def _log_scalar(self, key, val, step):
+        """tensorboard scalar when a Lightning-style logger is attached (model.py:611, 635, 708); a no-op otherwise"""
+        logger = getattr(self, "logger", None)
+        exp = getattr(logger, "experiment", None)
+        if exp is not None and hasattr(exp, "add_scalar"):
+            exp.add_scalar(key, val, global_step=step)
+
+    def training_epoch_end(self, outputs):
+        """model.py:630-644: epoch means of the step metrics, learning rate, per-epoch scheduler step."""
+        epoch = int(getattr(self, "current_epoch", 0))
+        means = {}
+        for k in outputs[0].keys():
+            vals = [float(x[k]) for x in outputs]
+            means[k] = sum(vals) / len(vals) if vals else 0
+            self._log_scalar("{}/train_epoch".format(k), means[k], epoch + 1)
+        if isinstance(getattr(self, "scheduler", None), (MultiStepLR, ExponentialLR)):
+            self.scheduler.step()
+        return means
+
+    @torch.no_grad()
+    def score_captions(self, captions, encoded_captions, lengths, perplexities=None):
+        """model.py:646-682: corpus BLEU-1..4 and GLEU of the generated captions against the R references of each image, and the
+        best cosine similarity between mean embeddings.  BLEU / GLEU: metrics.py (nltk's algorithms restated; nltk is a host-side
+        dependency of the reference and runs on token-id lists); the embedding part runs on the device."""
+        from . import metrics
+        lens = lengths.tolist() if torch.is_tensor(lengths) else lengths
+        references = [[c[1:l] for c, l in zip(refs, lens[i])] for i, refs in enumerate(encoded_captions.tolist())]
+        out = {"bleu1": metrics.corpus_bleu(references, captions, weights=(1, 0, 0, 0)),
+               "bleu2": metrics.corpus_bleu(references, captions, weights=(0.5, 0.5, 0, 0)),
+               "bleu3": metrics.corpus_bleu(references, captions, weights=(0.33, 0.33, 0.33, 0)),
+               "bleu4": metrics.corpus_bleu(references, captions, weights=(0.25, 0.25, 0.25, 0.25))}
+        dev = self.embedding.weight.device
+        enc = encoded_captions.to(dev)
+        E = self.embedding.weight
+        cossims = torch.zeros(enc.shape[0], dtype=torch.float, device=dev)
+        for i in range(enc.shape[0]):
+            cv = E[torch.as_tensor(captions[i], dtype=torch.long, device=dev)].mean(0).unsqueeze(0)
+            rvs = torch.zeros(enc.shape[1], dtype=torch.float, device=dev)
+            for j, l in enumerate(lens[i]):
+                rv = E[enc[i][j][1:l]].mean(0).unsqueeze(0)
+                rvs[j] = F.cosine_similarity(rv, cv)
+            cossims[i] = rvs.max()
+        out["cosine_similarity"] = cossims.mean().item()
+        out["gleu"] = metrics.corpus_gleu(references, captions)
+        if type(perplexities) == list:
+            out["perplexity"] = sum(perplexities) / len(perplexities)
+        return out
+
+    def val_batch(self, batch, beamk=3, max_gen_length=32, temperature=0.5, sample_method="beam", sample_topk=3, decoder_noise=None,
+                  rescore_method=None, rescore_reward=0.5):
+        """model.py:684-691"""
+        img, encoded_captions, lengths = batch
+        captions, scores, alphas, perplexities = self.caption(img, beamk, max_gen_length, temperature, sample_method, sample_topk, decoder_noise,
+                                                              rescore_method, rescore_reward, return_all=False)
+        return self.score_captions(captions, encoded_captions, lengths, perplexities)
+
+    def validation_step(self, batch, batch_idx=0):
+        """model.py:693-697"""
+        return self.val_batch(batch, beamk=self.hp.val_beamk, max_gen_length=self.hp.val_max_len, temperature=1.0, rescore_method="LN")
+
+    def validation_epoch_end(self, outputs):
+        """model.py:699-718: epoch means; the monitored ones go to ``self.log`` when a trainer is attached; plateau scheduler step."""
+        epoch = int(getattr(self, "current_epoch", 0))
+        means, plateau_val = {}, None
+        for k in outputs[0].keys():
+            vals = [x[k] for x in outputs]
+            try:
+                val = sum(vals) / len(vals)
+            except Exception:
+                val = 0
+            means[k] = val
+            if epoch != 0:
+                self._log_scalar("{}/val_epoch".format(k), val, epoch + 1)
+            if hasattr(self, "log") and getattr(self, "_trainer", None) is not None and k in (getattr(self.hp, "save_monitor", None), getattr(self.hp, "early_stop_monitor", None)):
+                self.log(k, val)
+            if k == getattr(self.hp, "plateau_monitor", None):
+                plateau_val = val
+        if isinstance(getattr(self, "scheduler", None), ReduceLROnPlateau) and plateau_val is not None:
+            self.scheduler.step(plateau_val)
+        return means
 
     # ------------------------------------------------------------------ configure_optimizers (model.py:720-817)
     def configure_optimizers(self):

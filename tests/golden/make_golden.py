@@ -227,6 +227,35 @@ def g9():
                 arrs["c%d_b%d_%d_alpha" % (ci, b, j)] = al[j].numpy()
     save("g9_sampled", **arrs)
 
+
+# ---------------------------------------------------------------- G10 (validation metrics: the reference's own BLEU)
+def g10():
+    """token_bleu of dev/dev_corpus_metrics.py:19-55 (the author's BLEU written "straight from the paper", kept in the reference
+    to be compared with nltk) on its own toy corpus and on seeded token corpora.  The module is imported as it stands (its
+    top-level nltk import resolves to ref_shim's placeholders; its prints go to stdout)."""
+    import contextlib, importlib.util, io
+    spec = importlib.util.spec_from_file_location("ref_dev_corpus_metrics", os.path.join(ref_shim.REFERENCE_DIR, "dev", "dev_corpus_metrics.py"))
+    mod = importlib.util.module_from_spec(spec)
+    with contextlib.redirect_stdout(io.StringIO()):
+        spec.loader.exec_module(mod)
+    weights = [[1, 0, 0, 0], [0.5, 0.5, 0, 0], [0.33, 0.33, 0.33, 0], [0.25, 0.25, 0.25, 0.25], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]]
+    corpora = {"toy": (mod.references, mod.captions)}
+    for ci, (nseg, vocab, seed) in enumerate([(12, 6, 1), (30, 9, 2), (8, 4, 3)]):
+        rs = np.random.RandomState(seed)
+        refs = [[rs.randint(1, vocab, size=rs.randint(5, 12)).tolist() for _ in range(rs.randint(2, 6))] for _ in range(nseg)]
+        caps = [rs.randint(1, vocab, size=rs.randint(4, 13)).tolist() for _ in range(nseg)]
+        corpora["rand%d" % ci] = (refs, caps)
+    arrs = {"weights": np.array(weights), "names": np.array(sorted(corpora))}
+    for name, (refs, caps) in corpora.items():
+        arrs[name + "_nseg"] = np.int64(len(caps))
+        for i, (rl, c) in enumerate(zip(refs, caps)):
+            arrs["%s_cap%d" % (name, i)] = np.array(c, np.int64)
+            arrs["%s_nref%d" % (name, i)] = np.int64(len(rl))
+            for j, r in enumerate(rl):
+                arrs["%s_ref%d_%d" % (name, i, j)] = np.array(r, np.int64)
+        arrs[name + "_token_bleu"] = np.array([float(mod.token_bleu(refs, caps, list(w))) for w in weights])
+    save("g10_metrics", **arrs)
+
 # ---------------------------------------------------------------- G8 (C1 decoder shapes)
 def g8():
     hp = O.default_hparams(vocab_size=6400, encoder_dim=256, embed_dim=256, attention_dim=128, decoder_dim=512, input_size=64)
@@ -285,4 +314,4 @@ if __name__ == "__main__":
     g4("layers2", 1.0, 46, decoder_layers=2)
     g4("embnorm", 1.0, 47, embed_norm=0.3)
     g4("gamma", 0.0, 48, att_gamma=0.5, B=4, R=3, T=9, H=3, W=3)
-    g6(); g7(); g8(); g9(); g_encoder()
+    g6(); g7(); g8(); g9(); g10(); g_encoder()

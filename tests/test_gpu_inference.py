@@ -93,3 +93,40 @@ def test_sampled_decoding_runs_on_device_generators():
         assert len(caps) == 2 and all(len(c) >= 1 for c in caps)
         for c, a, sc in zip(caps, alphas, scores):
             assert all(al.shape == (len(tok), 2, 3) for tok, al in zip(c, a)) and all(np.isfinite(x) for x in sc)
+
+
+def test_validation_step_scores_generated_captions():
+    """val_batch / validation_step / score_captions (model.py:646-697): captions from the HIP beam search, BLEU/GLEU from
+    metrics.py, best mean-embedding cosine similarity -- against the same quantities from the oracle's captions on the CPU."""
+    import sat_amd  # noqa: F401
+    from sat_amd import metrics, model as M
+    from oracle import prng, sat_oracle as O
+    import torch.nn.functional as F
+    over = dict(encoder_arch="resnet18", encoder_dim=32, input_size=64, encoder_size=3, vocab_size=60, embed_dim=24, attention_dim=16,
+                decoder_dim=40, deep_output=True, val_beamk=3, val_max_len=7)
+    torch.manual_seed(5)
+    model = M.SAT(**vars(O.default_hparams(**over))).cuda()
+    oracle = O.OracleSAT(O.default_hparams(**over), {k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+    B, R, T = 4, 3, 9
+    img = torch.from_numpy(prng.uniform((B, 3, 64, 64), 41, 0.0, 1.0))
+    caps, lengths = prng.captions(B, R, T, 60, 42, min_len=3)
+    caps, lengths = torch.from_numpy(caps), torch.from_numpy(lengths)
+    got = model.validation_step((img.cuda(), caps.cuda(), lengths), 0)
+    oracle.encoder.eval()
+    with torch.no_grad():
+        ann = oracle.encoder(img.clone())
+        ocaps, _, _, oppl = O.beam_search(oracle.sd, oracle.hp, ann, beamk=3, max_gen_length=7, temperature=1.0, rescore_method="LN")
+        refs = [[c[1:l] for c, l in zip(r, lengths[i].tolist())] for i, r in enumerate(caps.tolist())]
+        E = oracle.sd["embedding.weight"]
+        best = []
+        for i in range(B):
+            cv = E[torch.tensor(ocaps[i])].mean(0, keepdim=True)
+            best.append(max(float(F.cosine_similarity(E[caps[i][j][1:int(lengths[i][j])]].mean(0, keepdim=True), cv)) for j in range(R)))
+    expect = {"bleu1": metrics.corpus_bleu(refs, ocaps, (1, 0, 0, 0)), "bleu4": metrics.corpus_bleu(refs, ocaps), "gleu": metrics.corpus_gleu(refs, ocaps),
+              "cosine_similarity": sum(best) / B, "perplexity": sum(oppl) / B}
+    assert set(got) == {"bleu1", "bleu2", "bleu3", "bleu4", "cosine_similarity", "gleu", "perplexity"}
+    for k, v in expect.items():
+        assert abs(got[k] - v) <= 1e-4 * max(1.0, abs(v)), (k, got[k], v)
+    means = model.validation_epoch_end([got, got])
+    assert abs(means["gleu"] - got["gleu"]) < 1e-12
+    assert model.training_epoch_end([{"loss": torch.tensor(2.0), "accuracy": 0.5}, {"loss": torch.tensor(4.0), "accuracy": 0.0}]) == {"loss": 3.0, "accuracy": 0.25}

@@ -264,3 +264,46 @@ def test_g9_sampled_decoding_noise_and_stacked_layers(golden_dir):
             out = O.beam_search(sd, hp, ann, beamk=c["beamk"], max_gen_length=c["mgl"], rescore_method="LN", return_all=c["return_all"],
                                 sample_method=c["method"], sample_topk=c["topk"], decoder_noise=c["noise"])
         check_beam_against_golden(g, c["ci"], c["return_all"], *out, tol=2e-6)
+
+
+def _g10_corpus(g, name):
+    refs, caps = [], []
+    for i in range(int(g[name + "_nseg"])):
+        caps.append(g["%s_cap%d" % (name, i)].tolist())
+        refs.append([g["%s_ref%d_%d" % (name, i, j)].tolist() for j in range(int(g["%s_nref%d" % (name, i)]))])
+    return refs, caps
+
+
+def test_g10_bleu_against_the_references_own_token_bleu(golden_dir):
+    """metrics.corpus_bleu (nltk's corpus BLEU restated; nltk is absent, parity with it unpinned) against the reference's own
+    independent BLEU, dev/dev_corpus_metrics.py:token_bleu, wherever the definitions coincide: every weighted n-gram order has
+    at least one clipped match (token_bleu adds 1e-9 inside the log, nltk's method0 substitutes the smallest float otherwise)."""
+    import sat_amd  # noqa: F401
+    from sat_amd import metrics
+    g = load(golden_dir, "g10_metrics")
+    checked = 0
+    for name in g["names"].tolist():
+        refs, caps = _g10_corpus(g, name)
+        for w, expect in zip(g["weights"].tolist(), g[name + "_token_bleu"].tolist()):
+            nums = [sum(metrics.modified_precision(r, c, n)[0] for r, c in zip(refs, caps)) for n in range(1, 5)]
+            if any(wi != 0 and nums[i] == 0 for i, wi in enumerate(w)):
+                continue
+            got = metrics.corpus_bleu(refs, caps, weights=w)
+            assert abs(got - expect) <= 1e-6 * max(1.0, expect), (name, w, got, expect)
+            checked += 1
+    assert checked >= 20
+
+
+def test_bleu_gleu_hand_computed_cases():
+    import sat_amd  # noqa: F401
+    from sat_amd import metrics
+    refs = [[[1, 2, 3], [4, 5, 6]], [[1], [4, 5]]]
+    caps = [[2, 4, 5, 6, 7], [1, 3, 6, 7, 8, 9]]
+    assert abs(metrics.corpus_bleu(refs, caps, (1, 0, 0, 0)) - 5 / 11) < 1e-12            # clipped unigrams 4/5 and 1/6, no brevity penalty
+    assert metrics.corpus_bleu([[[1, 2]]], [[3, 4]], (0.5, 0.5)) == 0                      # no unigram match
+    # brevity penalty: hypothesis of 2 tokens against a closest reference of 4 -> exp(1 - 4/2)
+    import math
+    assert abs(metrics.corpus_bleu([[[1, 2, 3, 4]]], [[1, 2]], (1,)) - math.exp(-1.0)) < 1e-12
+    # GLEU: hypothesis [1,2,3] vs reference [1,2,4]: shared 1..4-grams {1,2,(1,2)} = 3 of max(6, 6)
+    assert abs(metrics.corpus_gleu([[[1, 2, 4]]], [[1, 2, 3]]) - 0.5) < 1e-12
+    assert metrics.corpus_gleu([[[5]]], [[]]) == 0.0
