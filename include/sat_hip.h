@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SAT_HIP_ABI_VERSION 9
+#define SAT_HIP_ABI_VERSION 10
 
 int sat_abi_version(void);
 const char* sat_last_error(void);
@@ -163,6 +163,19 @@ int sat_decoder_infer_step(const sat_decoder_dims* d, const sat_decoder_params* 
                            const float* h_noise /* (layers, beams, n) or NULL: decoder_noise (model.py:322-324), added to h for the
                                                    LSTM update only; attention and the beta gate see the clean h[-1] */,
                            void* workspace, size_t workspace_bytes, void* stream);
+/* Batched beam search ("beam" sampling, model.py:260-448 for every image of the batch at once; d->B = images, rows are (B, beamk)).
+ * Enqueues max_gen_length + 1 decode steps without a host round trip and leaves the back-trace on the device:
+ *   tok_in   (max_gen_length + 2, B, beamk)  token fed to each live row of each step ([0] = START)
+ *   prev_row (max_gen_length + 2, B, beamk)  row of the previous step the hypothesis came from
+ *   alpha_hist (max_gen_length + 1, B, beamk, L)  attention weights of each step's rows
+ *   fin_*    (B, beamk)  finished hypotheses in the reference's append order: step at which they ended, the row they came from, raw score,
+ *            mean beam score at that moment (for "BAR" rescoring); fin_count (B)
+ * temperatures and special ids {START, PAD, END, UNK} are HOST arrays (read while enqueueing). */
+size_t sat_beam_search_workspace_bytes(const sat_decoder_dims* d, int32_t beamk);
+int sat_beam_search_batched(const sat_decoder_dims* d, const sat_decoder_params* w, const float* ann /* (B, L, D) */, int32_t beamk,
+                            int32_t max_gen_length, const float* temperatures_host, int32_t n_temperatures, const int32_t* special_ids_host,
+                            int32_t* tok_in, int32_t* prev_row, float* alpha_hist, int32_t* fin_count, int32_t* fin_step, int32_t* fin_row,
+                            float* fin_score, float* fin_mean, void* workspace, size_t workspace_bytes, void* stream);
 int sat_beam_scores(const float* logits, int32_t beams, int32_t V, float temperature, const int32_t* masked_ids /* device */,
                     int32_t n_masked, const float* parent_scores /* (beams) or NULL */, float* scores, void* stream);
 int sat_topk(const float* x, float* work /* n floats scratch */, int64_t n, int32_t k, float* values, int32_t* indices, void* stream);

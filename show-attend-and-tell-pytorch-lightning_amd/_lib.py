@@ -155,6 +155,9 @@ SYMBOLS.update({
     "sat_decoder_infer_begin": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), _vp, _i32, _i32, _vp, _vp, _vp, C.c_size_t, _vp]),
     "sat_decoder_infer_step": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                                          C.c_size_t, _vp]),
+    "sat_beam_search_workspace_bytes": (C.c_size_t, [C.POINTER(DecoderDims), _i32]),
+    "sat_beam_search_batched": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), _vp, _i32, _i32, C.POINTER(C.c_float), _i32, C.POINTER(C.c_int32),
+                                          _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "sat_beam_scores": (C.c_int, [_vp, _i32, _i32, _f, _vp, _i32, _vp, _vp, _vp]),
     "sat_topk": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
 })
@@ -192,8 +195,8 @@ def lib():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(handle, name)          # AttributeError if the export is missing
             fn.restype, fn.argtypes = res, args
-        if handle.sat_abi_version() != 9:
-            raise SatHipError("libsat_hip.so ABI version %d != 9 (rebuild: make -C csrc)" % handle.sat_abi_version())
+        if handle.sat_abi_version() != 10:
+            raise SatHipError("libsat_hip.so ABI version %d != 10 (rebuild: make -C csrc)" % handle.sat_abi_version())
         _lib = handle
     return _lib
 

@@ -584,6 +584,129 @@ int decoder_infer_step(const sat_decoder_dims& d, const sat_decoder_params& p, c
     return gemm(st, A_ROW, B_ROW, w.u, m, p.out_w, m, logits, d.V, K, d.V, m, 0, p.out_b ? EPI_BIAS : EPI_NONE, p.out_b);
 }
 
+// ------------------------------------------------------------------ batched beam search: every image of the batch at once
+// (the reference loops over images, model.py:260).  Rows (B, K); the per-image semantics -- F3 initial
+// states, top-k over the live beams' flattened scores, completed hypotheses leaving the beam, cut at max_gen_length -- are
+// those of model.py:262-448; the whole loop is enqueued without a host round trip and leaves a back-trace
+// (token and parent row of every step, attention maps, finished list) for the host to read once.
+struct BeamWs {
+    size_t total; float *U, *Wcat, *bcat, *mean, *f, *init_img, *hc, *Z, *XZ, *Y, *u, *gu, *bup, *h, *c, *h2, *c2, *logits, *scores, *work, *vals, *top;
+    int *live, *klive, *inds, *gmap, *mask_first, *mask_rest;
+};
+static BeamWs beam_layout(const sat_decoder_dims& d, int K, char* base) {
+    BeamWs w; size_t off = 0;
+    const long HCW = d.A + d.D + 4L * d.n, N = (long)d.B * K;
+    auto take = [&](size_t elems) { size_t o = off; off += (elems * 4 + 255) & ~(size_t)255; return base ? base + o : (char*)nullptr; };
+    w.U = (float*)take((size_t)d.B * d.L * d.A); w.Wcat = (float*)take((size_t)HCW * d.n); w.bcat = (float*)take((size_t)HCW);
+    w.mean = (float*)take((size_t)d.B * d.D); w.f = (float*)take((size_t)d.B * d.m); w.init_img = (float*)take((size_t)d.B * 2 * d.n * d.layers);
+    w.gu = (float*)take((size_t)N * 4 * d.n); w.bup = (float*)take((size_t)d.layers * 4 * d.n);
+    w.hc = (float*)take((size_t)N * HCW); w.Z = (float*)take((size_t)N * d.D); w.XZ = (float*)take((size_t)N * d.D);
+    w.Y = (float*)take((size_t)N * d.m); w.u = (float*)take((size_t)N * d.m);
+    w.h = (float*)take((size_t)d.layers * N * d.n); w.c = (float*)take((size_t)d.layers * N * d.n);
+    w.h2 = (float*)take((size_t)d.layers * N * d.n); w.c2 = (float*)take((size_t)d.layers * N * d.n);
+    w.logits = (float*)take((size_t)N * d.V); w.scores = (float*)take((size_t)N * d.V); w.work = (float*)take((size_t)N * d.V);
+    w.vals = (float*)take(N); w.top = (float*)take(N);
+    w.live = (int*)take(N); w.klive = (int*)take(d.B); w.inds = (int*)take(N); w.gmap = (int*)take(N); w.mask_first = (int*)take(4); w.mask_rest = (int*)take(4);
+    w.total = off;
+    return w;
+}
+size_t decoder_beam_workspace_bytes(const sat_decoder_dims& d, int K) { return beam_layout(d, K, nullptr).total; }
+
+int decoder_beam_batched(const sat_decoder_dims& d, const sat_decoder_params& p, const float* ann, int K, int max_gen_length, const float* temps_host,
+                         int n_temps, const int* special_host /* START, PAD, END, UNK */, int* tok_in, int* prev_row, float* alpha_hist, int* fin_count,
+                         int* fin_step, int* fin_row, float* fin_score, float* fin_mean, char* ws, size_t ws_bytes, hipStream_t st) {
+    BeamWs w = beam_layout(d, K, ws);
+    SAT_REQUIRE(ws_bytes >= w.total && K >= 1 && max_gen_length >= 0 && n_temps >= 1, "beam_batched: workspace %zu < %zu, K=%d, max_gen_length=%d", ws_bytes, w.total, K, max_gen_length);
+    t_bf16_mfma = d.precision ? 1 : 0;
+    const int B = d.B, N = B * K, n = d.n, A = d.A, D = d.D, m = d.m, V = d.V, NL = d.layers, HCW = A + D + 4 * n;
+    const int START = special_host[0], PAD = special_host[1], END = special_host[2], UNK = special_host[3];
+    // ---- once per batch: stacked step weights, att_enc, initial states of the K copies of every image
+    SAT_CHECK_HIP(hipMemcpyAsync(w.Wcat, p.att_dec, (size_t)A * n * 4, hipMemcpyDeviceToDevice, st));
+    SAT_CHECK_HIP(hipMemcpyAsync(w.Wcat + (long)A * n, p.beta_w, (size_t)D * n * 4, hipMemcpyDeviceToDevice, st));
+    SAT_CHECK_HIP(hipMemcpyAsync(w.Wcat + (long)(A + D) * n, p.w_hh, (size_t)4 * n * n * 4, hipMemcpyDeviceToDevice, st));
+    SAT_CHECK_HIP(hipMemsetAsync(w.bcat, 0, (size_t)A * 4, st));
+    SAT_CHECK_HIP(hipMemcpyAsync(w.bcat + A, p.beta_b, (size_t)D * 4, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(add_kernel, dim3(cdiv(4 * n, 256)), dim3(256), 0, st, w.bcat + A + D, p.b_ih, p.b_hh, (long)4 * n);
+    SAT_TRY(launch_ok("bias add"));
+    for (int l = 1; l < NL; ++l) {
+        hipLaunchKernelGGL(add_kernel, dim3(cdiv(4 * n, 256)), dim3(256), 0, st, w.bup + (long)(l - 1) * 4 * n, p.up_b_ih[l - 1], p.up_b_hh[l - 1], (long)4 * n);
+        SAT_TRY(launch_ok("bias add (stacked layer)"));
+    }
+    hipLaunchKernelGGL(set4_int_kernel, dim3(1), dim3(1), 0, st, w.mask_first, START, PAD, END, UNK);
+    hipLaunchKernelGGL(set4_int_kernel, dim3(1), dim3(1), 0, st, w.mask_rest, START, PAD, -1, -1);
+    SAT_TRY(launch_ok("beam masks"));
+    SAT_TRY(gemm(st, A_ROW, B_ROW, ann, D, p.att_enc, D, w.U, A, B * d.L, A, D));
+    hipLaunchKernelGGL(ann_mean_kernel, dim3(B), dim3(256), 0, st, ann, w.mean, d.L, D);
+    SAT_TRY(launch_ok("ann_mean"));
+    SAT_TRY(gemm(st, A_ROW, B_ROW, w.mean, D, p.init_f_w, D, w.f, m, B, m, D, 0, EPI_BIAS, p.init_f_b));
+    SAT_TRY(gemm(st, A_ROW, B_ROW, w.f, m, p.init_i_w, m, w.init_img, 2 * n * NL, B, 2 * n * NL, m, 0, EPI_BIAS, p.init_i_b));
+    hipLaunchKernelGGL(init_expand_images_kernel, dim3(cdiv(2L * NL * N * n, 256)), dim3(256), 0, st, w.init_img, w.h, w.c, B, K, n, NL);
+    SAT_TRY(launch_ok("init_expand_images"));
+    hipLaunchKernelGGL(fill_int_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, w.klive, (long)B, K);
+    SAT_TRY(launch_ok("fill klive"));
+    SAT_CHECK_HIP(hipMemsetAsync(tok_in, 0, (size_t)(max_gen_length + 2) * N * 4, st));       // rows that are not live still index the embedding table
+    SAT_CHECK_HIP(hipMemsetAsync(prev_row, 0, (size_t)(max_gen_length + 2) * N * 4, st));
+    hipLaunchKernelGGL(fill_int_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, tok_in, (long)N, START);
+    SAT_TRY(launch_ok("fill start tokens"));
+    SAT_CHECK_HIP(hipMemsetAsync(w.h2, 0, (size_t)NL * N * n * 4, st));
+    SAT_CHECK_HIP(hipMemsetAsync(w.c2, 0, (size_t)NL * N * n * 4, st));
+    SAT_CHECK_HIP(hipMemsetAsync(w.top, 0, (size_t)N * 4, st));
+    SAT_CHECK_HIP(hipMemsetAsync(fin_count, 0, (size_t)B * 4, st));
+
+    float *h = w.h, *c = w.c, *h2 = w.h2, *c2 = w.c2;
+    for (int step = 0; step <= max_gen_length; ++step) {
+        const int* tok = tok_in + (long)step * N;
+        float* alpha = alpha_hist + (long)step * N * d.L;
+        const long KS = (long)N * n;
+        float* htop = h + (NL - 1) * KS;
+        hipLaunchKernelGGL(beam_live_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, w.klive, w.live, B, K);
+        SAT_TRY(launch_ok("beam_live"));
+        // ---- model.py:298-327 for all rows (dead rows: zero attention, state carried, ignored below)
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(N), dim3(64), 0, st, p.embedding, tok, w.Y, N, m, 0.f, 0ull, 0L);
+        SAT_TRY(launch_ok("embedding gather"));
+        if (NL == 1) {
+            SAT_TRY(gemm(st, A_ROW, B_ROW, h, n, w.Wcat, n, w.hc, HCW, N, HCW, n, 0, EPI_BIAS_SIGMOID_RANGE, w.bcat, nullptr, nullptr, nullptr, 0, A, A + D));
+        } else {
+            SAT_TRY(gemm(st, A_ROW, B_ROW, htop, n, w.Wcat, n, w.hc, HCW, N, A + D, n, 0, EPI_BIAS_SIGMOID_RANGE, w.bcat, nullptr, nullptr, nullptr, 0, A, A + D));
+            SAT_TRY(gemm(st, A_ROW, B_ROW, h, n, w.Wcat + (long)(A + D) * n, n, w.hc + A + D, HCW, N, 4 * n, n, 0, EPI_BIAS, w.bcat + A + D));
+        }
+        SAT_TRY(launch_attention_fwd(st, ann, w.U, w.hc, HCW, p.att_f, w.live, 0, alpha, 1, w.Z, w.XZ, B, K, d.L, D, A));
+        SAT_TRY(gemm(st, A_ROW, B_ROW, w.Y, m, p.w_ih, m + D, w.hc + A + D, HCW, N, 4 * n, m, 1));
+        SAT_TRY(gemm(st, A_ROW, B_ROW, w.XZ, D, p.w_ih + m, m + D, w.hc + A + D, HCW, N, 4 * n, D, 1));
+        hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(cdiv((long)N * n, 256)), dim3(256), 0, st, w.hc + A + D, HCW, (const float*)nullptr, c, h, c, h, w.live, 0, N, n);
+        SAT_TRY(launch_ok("lstm_cell_fwd"));
+        for (int l = 1; l < NL; ++l) {
+            float* hl = h + l * KS; float* cl = c + l * KS;
+            SAT_TRY(gemm(st, A_ROW, B_ROW, hl - KS, n, p.up_w_ih[l - 1], n, w.gu, 4 * n, N, 4 * n, n, 0, EPI_BIAS, w.bup + (long)(l - 1) * 4 * n));
+            SAT_TRY(gemm(st, A_ROW, B_ROW, hl, n, p.up_w_hh[l - 1], n, w.gu, 4 * n, N, 4 * n, n, 1));
+            hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(cdiv((long)N * n, 256)), dim3(256), 0, st, w.gu, 4 * n, (const float*)nullptr, cl, hl, cl, hl, w.live, 0, N, n);
+            SAT_TRY(launch_ok("lstm_cell_fwd (stacked layer)"));
+        }
+        SAT_TRY(gemm(st, A_ROW, B_ROW, htop, n, p.out_hidden, n, w.u, m, N, m, n));
+        if (d.deep_output) SAT_TRY(gemm(st, A_ROW, B_ROW, w.Z, D, p.out_context, D, w.u, m, N, m, D, 1, EPI_ADD_TANH, nullptr, nullptr, nullptr, w.Y, m));
+        SAT_TRY(gemm(st, A_ROW, B_ROW, w.u, m, p.out_w, m, w.logits, V, N, V, m, 0, p.out_b ? EPI_BIAS : EPI_NONE, p.out_b));
+        // ---- model.py:330-359: log-softmax, special-token masks, parent scores, top-k per image
+        const float T = temps_host[step % n_temps];
+        hipLaunchKernelGGL(beam_scores_kernel, dim3(N), dim3(256), 0, st, w.logits, V, 1.0f / T, step == 0 ? w.mask_first : w.mask_rest, step == 0 ? 4 : 2,
+                           step == 0 ? (const float*)nullptr : w.top, w.scores);
+        SAT_TRY(launch_ok("beam_scores"));
+        hipLaunchKernelGGL(beam_topk_kernel, dim3(B), dim3(1024), 0, st, w.scores, w.work, w.klive, K, V, step == 0 ? 1 : 0, w.vals, w.inds);
+        SAT_TRY(launch_ok("beam_topk"));
+        hipLaunchKernelGGL(beam_update_kernel, dim3(cdiv(B, 64)), dim3(64), 0, st, w.vals, w.inds, w.klive, B, K, V, step, max_gen_length, END,
+                           tok_in + (long)(step + 1) * N, prev_row + (long)(step + 1) * N, w.top, w.gmap, fin_count, fin_step, fin_row, fin_score, fin_mean);
+        SAT_TRY(launch_ok("beam_update"));
+        if (step < max_gen_length) {
+            const long tot = (long)NL * N * n;
+            hipLaunchKernelGGL(beam_gather_state_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, st, h, h2, w.gmap, w.klive, B, K, n, NL);
+            SAT_TRY(launch_ok("beam_gather h"));
+            hipLaunchKernelGGL(beam_gather_state_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, st, c, c2, w.gmap, w.klive, B, K, n, NL);
+            SAT_TRY(launch_ok("beam_gather c"));
+            float* t1 = h; h = h2; h2 = t1; t1 = c; c = c2; c2 = t1;
+        }
+    }
+    return SAT_OK;
+}
+
 int beam_scores(const float* logits, int K, int V, float temperature, const int* masked, int n_masked, const float* parent, float* scores, hipStream_t st) {
     SAT_REQUIRE(K > 0 && V > 0 && temperature > 0.f, "beam_scores: bad arguments");
     hipLaunchKernelGGL(beam_scores_kernel, dim3(K), dim3(256), 0, st, logits, V, 1.0f / temperature, masked, n_masked, parent, scores);

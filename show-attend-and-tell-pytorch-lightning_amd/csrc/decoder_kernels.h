@@ -34,6 +34,7 @@ __global__ void cast_bf16_kernel(const float* __restrict__ src, __bf16* __restri
     reinterpret_cast<b4*>(dst)[e] = o;
 }
 
+__global__ void set4_int_kernel(int* p, int a, int b, int c, int d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
 __global__ void fill_int_kernel(int* p, long n, int v) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -770,6 +771,117 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float* __restrict__ x,
         }
         __syncthreads();
     }
+}
+
+
+// ------------------------------------------------------------------ batched beam search (all images of a batch at once)
+// Rows are laid out (B, K): image b owns rows b*K .. b*K + K - 1, its klive[b] live hypotheses first.
+// InitLSTM over the K expanded copies of ONE image's annotation (model.py:265-269), for every image: the raw reshape of
+// F3 acts on each image's own (K, 2*layers*n) buffer.  h, c: (layers, B*K, n).
+__global__ void init_expand_images_kernel(const float* __restrict__ init_img, float* __restrict__ h0, float* __restrict__ c0, int B, int K, int n,
+                                          int layers) {
+    const long per = 2L * layers * K * n;                      // flat elements of one image
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= per * B) return;
+    const int b = (int)(e / per); const long f = e - (long)b * per;
+    const long w2 = 2L * layers * n, slab_sz = (long)K * n;
+    const float v = init_img[(long)b * w2 + f % w2];           // every one of the K rows is the image's init vector
+    const long slab = f / slab_sz, within = f - slab * slab_sz;
+    const long row = within / n, col = within - row * n;
+    const long N = (long)B * K;
+    if (slab < layers) h0[(slab * N + (long)b * K + row) * n + col] = v;
+    else c0[((slab - layers) * N + (long)b * K + row) * n + col] = v;
+}
+// live[i] = 1 for the first klive[b] rows of image b (the kernels' `lengths[i] > step` predicate with step = 0)
+__global__ void beam_live_kernel(const int* __restrict__ klive, int* __restrict__ live, int B, int K) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B * K) live[i] = (i % K) < klive[i / K] ? 1 : 0;
+}
+// torch.topk of the flattened live scores of every image (model.py:343 at step 0: row 0 only; model.py:359 afterwards),
+// descending, ties to the lowest index.  One block per image; `work` (B, K*V) is scratch.
+__global__ __launch_bounds__(1024) void beam_topk_kernel(const float* __restrict__ scores, float* __restrict__ work, const int* __restrict__ klive,
+                                                         int K, int V, int first_step, float* __restrict__ values, int* __restrict__ indices) {
+    __shared__ float s_v[16]; __shared__ long s_i[16];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int k = klive[b];
+    if (k <= 0) return;
+    const long n = first_step ? V : (long)k * V;
+    const float* x = scores + (long)b * K * V; float* wk = work + (long)b * K * V;
+    for (long i = tid; i < n; i += 1024) wk[i] = x[i];
+    __syncthreads();
+    for (int it = 0; it < k; ++it) {
+        float bv = -INFINITY; long bi = 0x7fffffffffffffffL;
+        for (long i = tid; i < n; i += 1024) { float v = wk[i]; if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; } }
+        for (int o = 32; o > 0; o >>= 1) {
+            float ov = __shfl_xor(bv, o, 64); long oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if ((tid & 63) == 0) { s_v[tid >> 6] = bv; s_i[tid >> 6] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 16; ++w) if (s_v[w] > bv || (s_v[w] == bv && s_i[w] < bi)) { bv = s_v[w]; bi = s_i[w]; }
+            values[b * K + it] = bv; indices[b * K + it] = (int)bi;
+            if (bi < n) wk[bi] = -INFINITY;
+        }
+        __syncthreads();
+    }
+}
+// Beam bookkeeping of one step for every image (model.py:343-447), one thread per image, in the reference's order:
+// extend each kept hypothesis (parent row, word), record the completed ones (word == END) in index order, drop them from the
+// beam, and at the last step record whatever is left.  Writes the next step's inputs: token, parent row (for the back-trace
+// and the state gather), parent score; the finished list keeps (step, parent row, raw score, mean of the beam's scores at
+// that moment -- what the BAR rescoring needs).
+__global__ void beam_update_kernel(const float* __restrict__ values, const int* __restrict__ indices, int* __restrict__ klive, int B, int K, int V,
+                                   int step, int last_step, int end_id, int* __restrict__ tok_next, int* __restrict__ prev_next,
+                                   float* __restrict__ top_scores, int* __restrict__ gmap, int* __restrict__ fin_count, int* __restrict__ fin_step,
+                                   int* __restrict__ fin_row, float* __restrict__ fin_score, float* __restrict__ fin_mean) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int k = klive[b];
+    int nk = 0;
+    if (k > 0) {
+        float mean_all = 0.f;
+        for (int j = 0; j < k; ++j) mean_all += values[b * K + j];
+        mean_all /= (float)k;
+        int fc = fin_count[b];
+        // completed hypotheses first, in index order (torch.nonzero(complete))
+        for (int j = 0; j < k; ++j) {
+            const int ind = indices[b * K + j];
+            const int parent = step == 0 ? j : ind / V, tok = step == 0 ? ind : ind - (ind / V) * V;
+            if (tok == end_id) {
+                fin_step[b * K + fc] = step; fin_row[b * K + fc] = parent; fin_score[b * K + fc] = values[b * K + j]; fin_mean[b * K + fc] = mean_all; ++fc;
+            }
+        }
+        // the incomplete ones continue, order kept
+        float rest = 0.f;
+        for (int j = 0; j < k; ++j) {
+            const int ind = indices[b * K + j];
+            const int parent = step == 0 ? j : ind / V, tok = step == 0 ? ind : ind - (ind / V) * V;
+            if (tok != end_id) {
+                tok_next[b * K + nk] = tok; prev_next[b * K + nk] = parent; top_scores[b * K + nk] = values[b * K + j]; gmap[b * K + nk] = parent;
+                rest += values[b * K + j]; ++nk;
+            }
+        }
+        if (step >= last_step && nk > 0) {           // model.py:438-447: cut at max_gen_length
+            const float mean_rest = rest / (float)nk;
+            for (int j = 0; j < nk; ++j) {
+                fin_step[b * K + fc] = step; fin_row[b * K + fc] = prev_next[b * K + j]; fin_score[b * K + fc] = top_scores[b * K + j]; fin_mean[b * K + fc] = mean_rest; ++fc;
+            }
+            nk = 0;
+        }
+        fin_count[b] = fc;
+    }
+    klive[b] = nk;
+}
+// state of the next step's row j' = this step's new state of its parent row (model.py:366: h, c = h[:, keep], c[:, keep])
+__global__ void beam_gather_state_kernel(const float* __restrict__ src, float* __restrict__ dst, const int* __restrict__ gmap, const int* __restrict__ klive,
+                                         int B, int K, int n, int layers) {
+    const long N = (long)B * K;
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)layers * N * n) return;
+    const long l = e / (N * n); const long rem = e - l * N * n; const long i = rem / n; const int col = (int)(rem - i * n);
+    const int b = (int)(i / K), j = (int)(i - (long)b * K);
+    if (j < klive[b]) dst[e] = src[(l * N + (long)b * K + gmap[i]) * n + col];
 }
 
 }  // namespace sat

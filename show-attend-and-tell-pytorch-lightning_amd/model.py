@@ -269,6 +269,91 @@ class SATDecoder(nn.Module):
                 cap_scores.append(fin_scores[best]); cap_ppl.append(fin_ppl[best])
         return captions, cap_scores, cap_alphas, cap_ppl
 
+    @torch.no_grad()
+    def beam_decode_batched(self, ann_bld, hw, beamk=3, max_gen_length=32, temperature=1.0, rescore_method=None, rescore_reward=0.5,
+                            return_all=False):
+        """The same beam search as ``beam_decode`` ("beam" sampling, no decoder noise) for ALL images of the batch at once
+        (SURVEY 8f row 2): one library call enqueues every decode step for the (B, beamk) hypothesis rows -- per-image top-k,
+        completed hypotheses leaving their image's beam, cut at ``max_gen_length`` -- without a host round trip; the host reads
+        the back-trace once and rebuilds the reference's four lists (model.py:449-472)."""
+        import ctypes as C
+        import numpy as np
+        lib = L.lib()
+        L.require_gpu(ann_bld)
+        hp = self.hp
+        dev = ann_bld.device
+        ann_bld = ann_bld.contiguous()
+        B, Lc, D = ann_bld.shape
+        Hh, Ww = hw
+        V, m = self.embedding.weight.shape
+        n = self.lstm.weight_hh_l0.shape[1]
+        A = self.attention.decoder_att.weight.shape[0]
+        K, S = int(beamk), int(max_gen_length)
+        temps = temperature if isinstance(temperature, list) else [temperature]
+        tarr = (C.c_float * len(temps))(*[float(t) for t in temps])
+        ids = (C.c_int32 * 4)(int(hp.vocab_stoi["<START>"]), int(hp.vocab_stoi["<PAD>"]), int(hp.vocab_stoi["<END>"]), int(hp.vocab_stoi["<UNK>"]))
+        dims = Dk.decoder_dims(B, K, 2, Lc, D, A, m, n, V, 0, hp.deep_output, self.pad_idx, int(getattr(self, "sat_precision", "fp32") == "bf16"),
+                               layers=int(hp.decoder_layers))
+        w, _keep = self._params_struct()
+        ws_bytes = lib.sat_beam_search_workspace_bytes(C.byref(dims), K)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev); f32 = dict(dtype=torch.float32, device=dev)
+        tok_in = torch.empty(S + 2, B, K, **i32); prev_row = torch.empty(S + 2, B, K, **i32)
+        alpha_hist = torch.empty(S + 1, B, K, Lc, **f32)
+        fin_count = torch.empty(B, **i32); fin_step = torch.empty(B, K, **i32); fin_row = torch.empty(B, K, **i32)
+        fin_score = torch.empty(B, K, **f32); fin_mean = torch.empty(B, K, **f32)
+        L.check(lib.sat_beam_search_batched(C.byref(dims), C.byref(w), L.ptr(ann_bld), K, S, tarr, len(temps), ids, L.ptr(tok_in), L.ptr(prev_row),
+                                            L.ptr(alpha_hist), L.ptr(fin_count), L.ptr(fin_step), L.ptr(fin_row), L.ptr(fin_score), L.ptr(fin_mean),
+                                            L.ptr(ws), ws_bytes, L.stream_ptr()), "sat_beam_search_batched")
+        tok_in, prev_row = tok_in.cpu().numpy(), prev_row.cpu().numpy()
+        alpha_np = alpha_hist.cpu().numpy()
+        fin_count, fin_step, fin_row = fin_count.cpu().numpy(), fin_step.cpu().numpy(), fin_row.cpu().numpy()
+        fin_score, fin_mean = fin_score.cpu(), fin_mean.cpu()
+        # back-trace of every finished hypothesis at once: walk the parent rows from the step it ended at down to step 0
+        bidx = np.repeat(np.arange(B), K)[(np.arange(K)[None, :] < fin_count[:, None]).reshape(-1)]
+        fidx = np.tile(np.arange(K), B)[(np.arange(K)[None, :] < fin_count[:, None]).reshape(-1)]
+        hstep, cur = fin_step[bidx, fidx].astype(np.int64), fin_row[bidx, fidx].astype(np.int64)
+        nh = len(bidx)
+        rows = np.zeros((S + 1, nh), np.int64)
+        for s_ in range(S, -1, -1):
+            act = hstep >= s_
+            rows[s_, act] = cur[act]
+            if s_ > 0:
+                cur[act] = prev_row[s_, bidx[act], cur[act]]
+        sidx = np.arange(S + 1)[:, None]
+        toks_all = tok_in[sidx, bidx[None, :], rows]                       # (S+1, nh): token fed at step s to the hypothesis' ancestor
+        als_all = torch.from_numpy(alpha_np[sidx, bidx[None, :], rows])    # (S+1, nh, L)
+        if rescore_method == "LN":
+            resc = fin_score[bidx, fidx] / torch.from_numpy(hstep).float()
+        elif rescore_method == "WR":
+            resc = fin_score[bidx, fidx] + rescore_reward * torch.from_numpy(hstep).float()
+        elif rescore_method == "BAR":
+            resc = fin_score[bidx, fidx] + rescore_reward * (-fin_mean[bidx, fidx])
+        else:
+            resc = fin_score[bidx, fidx]
+        ppl_all = torch.exp(-fin_score[bidx, fidx] / torch.from_numpy(hstep).float())
+        resc, ppl_all = resc.tolist(), ppl_all.tolist()
+        captions, cap_scores, cap_alphas, cap_ppl = [], [], [], []
+        hpos = 0
+        for b in range(B):
+            fin_caps, fin_alphas, fin_scores, fin_ppl = [], [], [], []
+            for f in range(int(fin_count[b])):
+                hh, step = hpos + f, int(hstep[hpos + f])
+                # top_preds[:, i][1:-1] / alphas[:, i][1:-1] (model.py:412-413): without START / the zero map and without the last step
+                fin_caps.append(toks_all[1:step + 1, hh].tolist())
+                fin_alphas.append(als_all[:step, hh].reshape(-1, Hh, Ww).clone())
+                fin_scores.append(resc[hh]); fin_ppl.append(ppl_all[hh])
+            hpos += int(fin_count[b])
+            if return_all:
+                order = [i for _, i in sorted([[fin_scores[i], i] for i in range(len(fin_scores))], reverse=True)]
+                captions.append([fin_caps[i] for i in order]); cap_alphas.append([fin_alphas[i] for i in order])
+                cap_scores.append([fin_scores[i] for i in order]); cap_ppl.append([fin_ppl[i] for i in order])
+            else:
+                best = fin_scores.index(max(fin_scores))
+                captions.append(fin_caps[best]); cap_alphas.append(fin_alphas[best])
+                cap_scores.append(fin_scores[best]); cap_ppl.append(fin_ppl[best])
+        return captions, cap_scores, cap_alphas, cap_ppl
+
     def _dropout_args(self, seed=None):
         """(p, p_embedding, seed) of this call: nn.Dropout is the identity in eval mode; the seed comes from a generator of
         its own so that the CPU generator stream of scheduled sampling (F7) stays exactly the reference's."""
@@ -376,6 +461,8 @@ class SAT(SATDecoder, _Base):
         assert sample_method in ["beam", "multinomial", "topk"]
         with torch.no_grad():
             ann_bld, hw = self.encode(img)
+            if sample_method == "beam" and not decoder_noise and max_gen_length >= 1:        # every image at once
+                return self.beam_decode_batched(ann_bld.contiguous(), hw, beamk, max_gen_length, temperature, rescore_method, rescore_reward, return_all)
             return self.beam_decode(ann_bld.contiguous(), hw, beamk, max_gen_length, temperature, sample_method, sample_topk,
                                     decoder_noise, rescore_method, rescore_reward, return_all)
 

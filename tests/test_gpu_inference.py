@@ -130,3 +130,48 @@ def test_validation_step_scores_generated_captions():
     means = model.validation_epoch_end([got, got])
     assert abs(means["gleu"] - got["gleu"]) < 1e-12
     assert model.training_epoch_end([{"loss": torch.tensor(2.0), "accuracy": 0.5}, {"loss": torch.tensor(4.0), "accuracy": 0.0}]) == {"loss": 3.0, "accuracy": 0.25}
+
+
+def test_g7_batched_beam_search_on_hip(golden_dir):
+    """The batched search (every image at once, no host round trip per step) against the same reference fixture as the
+    per-image loop: token ids exact, scores / perplexities / attention maps within 1e-4, list order included."""
+    import sat_amd  # noqa: F401
+    from sat_amd import model as M
+    from oracle import sat_oracle as O
+    g = np.load(os.path.join(golden_dir, "g7_beam.npz"))
+    sd = sd_from(g)
+    V, m = sd["embedding.weight"].shape
+    hp = O.default_hparams(vocab_size=V, embed_dim=m, decoder_dim=sd["lstm.weight_hh_l0"].shape[1],
+                           encoder_dim=sd["attention.encoder_att.weight"].shape[1], attention_dim=sd["attention.encoder_att.weight"].shape[0])
+    dec = M.SATDecoder(hp).cuda().eval()
+    dec.load_decoder_state(sd)
+    ann = torch.tensor(g["ann"])
+    B, D, Hh, Ww = ann.shape
+    ann_bld = ann.permute(0, 2, 3, 1).reshape(B, Hh * Ww, D).contiguous().cuda()
+    for ci, beamk, rm, ra, mgl in _beam_cases(g):
+        out = dec.beam_decode_batched(ann_bld, (Hh, Ww), beamk=beamk, max_gen_length=mgl, rescore_method=rm, rescore_reward=0.5, return_all=ra)
+        check_beam_against_golden(g, ci, ra, *out, tol=1e-4)
+
+
+@pytest.mark.parametrize("layers", [1, 2])
+def test_batched_beam_search_equals_the_per_image_loop(layers):
+    """larger random model, 9 images, beams 1 / 4, temperature schedule, two LSTM layers: identical captions and list order,
+    scores and maps within 1e-5 of the per-image path."""
+    import sat_amd  # noqa: F401
+    from sat_amd import model as M
+    from oracle import prng, sat_oracle as O
+    hp = O.default_hparams(vocab_size=83, encoder_dim=32, embed_dim=24, attention_dim=16, decoder_dim=40, decoder_layers=layers)
+    torch.manual_seed(3 + layers)
+    dec = M.SATDecoder(hp).cuda().eval()
+    ann_bld = torch.from_numpy(prng.uniform((9, 12, 32), 55, 0.0, 1.0)).cuda()
+    for beamk, rm, ra in [(1, None, False), (4, "BAR", True), (4, "LN", False)]:
+        a = dec.beam_decode(ann_bld, (3, 4), beamk=beamk, max_gen_length=9, temperature=[1.0, 0.7], rescore_method=rm, return_all=ra)
+        b = dec.beam_decode_batched(ann_bld, (3, 4), beamk=beamk, max_gen_length=9, temperature=[1.0, 0.7], rescore_method=rm, return_all=ra)
+        assert a[0] == b[0], (beamk, rm)
+        flat = lambda x: [v for e in x for v in (e if isinstance(e, list) else [e])]
+        for u, v in zip(flat(a[1]), flat(b[1])):
+            assert abs(u - v) <= 1e-5 * max(1.0, abs(u))
+        for u, v in zip(flat(a[2]), flat(b[2])):
+            assert u.shape == v.shape and float((u - v).abs().max()) <= 1e-5
+        for u, v in zip(flat(a[3]), flat(b[3])):
+            assert abs(u - v) <= 1e-5 * max(1.0, abs(u))
