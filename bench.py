@@ -129,11 +129,16 @@ def main():
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the SAT hot path has no CPU fallback")
+    # SAT_BENCH_REHEARSAL=1 (dev): every rank on GPU 0 with the gloo backend -- rehearses the multi-process flow (buckets, hooks,
+    # timing protocol) on a one-GPU box; the numbers it prints are meaningless
+    rehearsal = os.environ.get("SAT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     import sat_amd  # noqa: F401
@@ -165,7 +170,14 @@ def main():
     # W untimed steps, and in any case MIN_WARM_S seconds of them: a GPU coming out of idle (fresh box / fresh process) needs
     # ~1 s of load before its clocks settle -- with 3 warm-up steps the first 10 timed steps ran 20 % slow (37-42 vs 32 ms)
     t_warm = time.perf_counter(); warm_done = 0
-    while warm_done < args.warmup or time.perf_counter() - t_warm < MIN_WARM_S:
+    while True:
+        more = warm_done < args.warmup or time.perf_counter() - t_warm < MIN_WARM_S
+        if world > 1:        # every rank must run the same number of steps (each step holds collectives): agree on the flag
+            flag = torch.tensor([1 if more else 0], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            more = bool(flag.item())
+        if not more:
+            break
         out = step()
         torch.cuda.synchronize(); warm_done += 1
         if warm_done <= 3 or warm_done % 10 == 0:
