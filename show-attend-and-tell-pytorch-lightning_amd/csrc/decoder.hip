@@ -342,7 +342,7 @@ int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
     // ---- output layer, all packed rows at once (DeepOutput backward)
     if (P > 0) {
         SAT_TRY(gemm(st, A_ROW, B_KMAJOR, dlogits, V, p.out_w, m, w.dA, m, P, m, V, 0, d.deep_output ? EPI_MUL_DTANH : EPI_NONE, nullptr,
-                     nullptr, nullptr, w.Uact, m));
+                     nullptr, nullptr, w.Uact, m, 0, 0, slab, se));           // few output tiles, long reduction over the vocabulary: split-K
         if (d.dropout > 0.f) {
             hipLaunchKernelGGL(dropout_rows_kernel, dim3(cdiv((long)P * m, 256)), dim3(256), 0, st, w.dA, w.dA, (long)P * m, m, d.dropout,
                                (unsigned long long)d.dropout_seed, 2u, 0L);

@@ -328,7 +328,8 @@ int launch_gemm_bf16(const GemmArgs& g, hipStream_t st) {
     k.c0 = g.c0; k.c1 = g.c1; k.g = g.g; k.slab = g.slab;
     const int KB = 64;
     int BMt = 64;
-    if ((long)cdiv(g.M, 128) * cdiv(g.N, 128) >= 192 && g.M >= 128 && g.N >= 128) BMt = 128;
+    static const long tiles128_min = getenv("SAT_TILES128_MIN") ? atol(getenv("SAT_TILES128_MIN")) : 192;
+    if ((long)cdiv(g.M, 128) * cdiv(g.N, 128) >= tiles128_min && g.M >= 128 && g.N >= 128) BMt = 128;
     // long reductions (weight gradients): split-K supplies the parallelism, so keep the 64x64-per-wave tile
     if (g.slab && g.M >= 128 && g.N >= 128 && g.K >= 64 * KB) BMt = 128;
     long blocks = (long)cdiv(g.M, BMt) * cdiv(g.N, BMt);
