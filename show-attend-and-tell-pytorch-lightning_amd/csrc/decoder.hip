@@ -121,7 +121,10 @@ static int colsum(hipStream_t st, const Ws& w, const float* x, long ld, int rows
     if (cols <= 0) return SAT_OK;
     if (rows <= 0) { if (!accumulate) SAT_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)cols * 4, st)); return SAT_OK; }
     int nparts = cdiv(rows, 256);
-    hipLaunchKernelGGL(colsum_part_kernel, dim3(cdiv(cols, 256), nparts), dim3(256), 0, st, x, ld, rows, cols, 256, w.colpart);
+    if (cols % 4 == 0 && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+        hipLaunchKernelGGL(colsum_part4_kernel, dim3(cdiv(cols / 4, 128), nparts), dim3(128), 0, st, x, ld, rows, cols / 4, 256, w.colpart);
+    else
+        hipLaunchKernelGGL(colsum_part_kernel, dim3(cdiv(cols, 256), nparts), dim3(256), 0, st, x, ld, rows, cols, 256, w.colpart);
     SAT_TRY(launch_ok("colsum_part"));
     hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, st, w.colpart, nparts, cols, out, accumulate, scale);
     return launch_ok("colsum_finish");

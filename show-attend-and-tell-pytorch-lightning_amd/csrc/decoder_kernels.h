@@ -633,6 +633,29 @@ __global__ void colsum_part_kernel(const float* __restrict__ x, long ld, int row
     for (int r = r0; r < r1; ++r) s += x[(long)r * ld + c];
     part[(long)blockIdx.y * cols + c] = s;
 }
+// the same, four columns per thread (16-byte loads; x 16-byte aligned, ld % 4 == 0, cols % 4 == 0) and four independent row
+// accumulators so that four loads are in flight per thread; combined in a fixed order
+__global__ void colsum_part4_kernel(const float* __restrict__ x, long ld, int rows, int cols4, int rows_per, float* __restrict__ part) {
+    const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c4 >= cols4) return;
+    const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
+    float4 a[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int r = r0;
+    for (; r + 3 < r1; r += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4 v = *reinterpret_cast<const float4*>(x + (long)(r + u) * ld + 4 * c4);
+            a[u].x += v.x; a[u].y += v.y; a[u].z += v.z; a[u].w += v.w;
+        }
+    }
+    for (; r < r1; ++r) { const float4 v = *reinterpret_cast<const float4*>(x + (long)r * ld + 4 * c4); a[0].x += v.x; a[0].y += v.y; a[0].z += v.z; a[0].w += v.w; }
+    float4 s;
+    s.x = (a[0].x + a[1].x) + (a[2].x + a[3].x); s.y = (a[0].y + a[1].y) + (a[2].y + a[3].y);
+    s.z = (a[0].z + a[1].z) + (a[2].z + a[3].z); s.w = (a[0].w + a[1].w) + (a[2].w + a[3].w);
+    *reinterpret_cast<float4*>(part + (long)blockIdx.y * cols4 * 4 + 4 * c4) = s;
+}
 __global__ void colsum_finish_kernel(const float* __restrict__ part, int nparts, int cols, float* __restrict__ out, int accumulate, float scale) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= cols) return;
