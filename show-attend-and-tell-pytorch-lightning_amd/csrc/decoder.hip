@@ -17,6 +17,7 @@ struct Ws {
     float *GU, *DGU, *bup;                                       // stacked LSTM layers (layers > 1): gates, gate grads, bias sums
     __bf16 *Wb_out, *Ub;                                         // bf16 mode: bf16 copies of output.output.weight and of the packed deep-output rows
     int* Tok; int* flags;
+    int *emb_count, *emb_offset, *emb_cursor, *emb_list;         // embedding gradient: per-row token segments
     // backward scratch
     float *dA, *dHout, *dZout, *DZ, *DHC, *dXZ, *dHc, *dCc, *dU, *dwf_part, *dY, *colpart, *dinit_img, *df, *dmean, *slab;
     long slab_elems;
@@ -58,6 +59,8 @@ Ws layout(const sat_decoder_dims& d, char* base) {
         w.Wb_out = (__bf16*)take((size_t)d.V * d.m, 2); w.Ub = (__bf16*)take((size_t)(d.P > 0 ? d.P : 1) * d.m, 2);
     }
     w.flags = (int*)take((size_t)d.V);
+    w.emb_count = (int*)take((size_t)d.V); w.emb_offset = (int*)take((size_t)d.V + 1); w.emb_cursor = (int*)take((size_t)d.V);
+    w.emb_list = (int*)take((size_t)T1 * N);
     w.dA = (float*)take((size_t)(d.P > 0 ? d.P : 1) * d.m);
     w.dHout = (float*)take((size_t)T1 * N * d.n);
     w.dZout = (float*)take((size_t)T1 * N * d.D);
@@ -439,8 +442,14 @@ int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
                            (unsigned long long)d.dropout_seed, 1u, 0L);
         SAT_TRY(launch_ok("embedding dropout bwd"));
     }
-    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(V), dim3(256), 0, st, w.dY, w.Tok, g.embedding, KR, m, d.padding_idx);
-    SAT_TRY(launch_ok("embedding_bwd"));
+    if (KR > 0) {
+        SAT_CHECK_HIP(hipMemsetAsync(w.emb_count, 0, (size_t)V * 4, st));
+        hipLaunchKernelGGL(embedding_count_kernel, dim3(cdiv(KR, 256)), dim3(256), 0, st, w.Tok, KR, V, d.padding_idx, w.emb_count);
+        hipLaunchKernelGGL(embedding_scan_kernel, dim3(1), dim3(1024), 0, st, w.emb_count, V, w.emb_offset, w.emb_cursor);
+        hipLaunchKernelGGL(embedding_place_kernel, dim3(cdiv(KR, 256)), dim3(256), 0, st, w.Tok, KR, V, d.padding_idx, w.emb_offset, w.emb_cursor, w.emb_list);
+        hipLaunchKernelGGL(embedding_sum_kernel, dim3(V), dim3(256), 0, st, w.dY, w.Tok, w.emb_offset, w.emb_list, g.embedding, KR, m, d.padding_idx);
+        SAT_TRY(launch_ok("embedding gradient"));
+    } else SAT_CHECK_HIP(hipMemsetAsync(g.embedding, 0, (size_t)V * m * 4, st));
     // attention parameters and the annotation gradient
     SAT_TRY(colsum(st, w, w.dwf_part, A, d.B, A, g.att_f));
     SAT_TRY(gemm(st, A_KMAJOR, B_KMAJOR, w.dU, A, b.ann, D, g.att_enc, D, A, D, d.B * d.L, 0, EPI_NONE, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, slab, se));

@@ -665,45 +665,96 @@ __global__ void colsum_finish_kernel(const float* __restrict__ part, int nparts,
     out[c] = accumulate ? out[c] + s : s;
 }
 
-// embedding gradient, deterministic: one block per vocabulary row v collects, in increasing r, the rows with
-// tok[r] == v (ordered compaction by wave ballots) and sums their dY rows in that order.  No atomics: the result
-// does not depend on scheduling.  The padding row and rows without a token (-1) get zeros.
+// embedding gradient, deterministic (no floating-point atomics: the result does not depend on scheduling).  The padding row
+// and rows without a token (-1) get zeros.
 constexpr int EMB_LIST = 1024;
-__global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* __restrict__ dY, const int* __restrict__ tok, float* __restrict__ dE,
-                                                            int rows, int width, int padding_idx) {
-    __shared__ int s_list[EMB_LIST];
-    __shared__ int s_wcnt[4];
-    __shared__ int s_total;
-    const int v = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float* out = dE + (long)v * width;
-    if (v == padding_idx) { for (int c = tid; c < width; c += 256) out[c] = 0.f; return; }
-    for (int c0 = 0; c0 < width; c0 += 256) { if (c0 + tid < width) out[c0 + tid] = 0.f; }
-    if (tid == 0) s_total = 0;
+// Four small launches:
+// count tokens per vocabulary row (integer atomics: the counts do not depend on the order), exclusive scan, scatter the token
+// positions into per-row segments (unordered), then one block per row SORTS its segment and adds the dY rows in increasing
+// position -- the summation order is again fixed.  Rows with more than EMB_LIST tokens take the scanning kernel's path.
+__global__ void embedding_count_kernel(const int* __restrict__ tok, int rows, int V, int padding_idx, int* __restrict__ count) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    int v = tok[r];
+    if (v >= 0 && v < V && v != padding_idx) atomicAdd(&count[v], 1);
+}
+__global__ __launch_bounds__(1024) void embedding_scan_kernel(const int* __restrict__ count, int V, int* __restrict__ offset, int* __restrict__ cursor) {
+    __shared__ int s_part[1024];
+    const int tid = threadIdx.x, per = (V + 1023) / 1024, b0 = tid * per, b1 = min(V, b0 + per);
+    int s = 0;
+    for (int v = b0; v < b1; ++v) s += count[v];
+    s_part[tid] = s;
     __syncthreads();
-    for (int base = 0; base < rows; base += 256) {
-        const int r = base + tid;
-        const bool hit = (r < rows) && (tok[r] == v);
-        const unsigned long long m = __ballot(hit);
-        if (lane == 0) s_wcnt[wave] = __popcll(m);
+    if (tid == 0) { int run = 0; for (int i = 0; i < 1024; ++i) { int t = s_part[i]; s_part[i] = run; run += t; } offset[V] = run; }
+    __syncthreads();
+    int run = s_part[tid];
+    for (int v = b0; v < b1; ++v) { offset[v] = run; cursor[v] = 0; run += count[v]; }
+}
+__global__ void embedding_place_kernel(const int* __restrict__ tok, int rows, int V, int padding_idx, const int* __restrict__ offset, int* __restrict__ cursor,
+                                       int* __restrict__ list) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    int v = tok[r];
+    if (v >= 0 && v < V && v != padding_idx) list[offset[v] + atomicAdd(&cursor[v], 1)] = r;
+}
+__global__ __launch_bounds__(256) void embedding_sum_kernel(const float* __restrict__ dY, const int* __restrict__ tok, const int* __restrict__ offset,
+                                                            const int* __restrict__ list, float* __restrict__ dE, int rows, int width, int padding_idx) {
+    __shared__ int s_list[EMB_LIST];
+    const int v = blockIdx.x, tid = threadIdx.x;
+    float* out = dE + (long)v * width;
+    const int o0 = offset[v], n = offset[v + 1] - o0;
+    if (n == 0 || v == padding_idx) { for (int c = tid; c < width; c += 256) out[c] = 0.f; return; }
+    if (n > EMB_LIST) {          // very frequent token: ordered compaction by scanning the token array, flushed whenever the
+                                 // next 256-token chunk might not fit the list any more
+        __shared__ int s_wcnt[4]; __shared__ int s_total;
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int c = tid; c < width; c += 256) out[c] = 0.f;
+        if (tid == 0) s_total = 0;
         __syncthreads();
-        int off = s_total;
-        for (int w = 0; w < wave; ++w) off += s_wcnt[w];
-        const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
-        if (hit && pos < EMB_LIST) s_list[pos] = r;
-        __syncthreads();
-        if (tid == 0) s_total += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
-        __syncthreads();
-        if (s_total >= EMB_LIST || base + 256 >= rows) {           // flush the ordered list
-            const int cnt = min(s_total, EMB_LIST);
-            for (int c = tid; c < width; c += 256) {
-                float acc = out[c];
-                for (int i = 0; i < cnt; ++i) acc += dY[(long)s_list[i] * width + c];
-                out[c] = acc;
+        for (int base = 0;; base += 256) {           // one extra pass after the last chunk flushes what is left
+            const bool last = base >= rows;
+            if (last || s_total + 256 > EMB_LIST) {
+                const int cnt = s_total;
+                for (int c = tid; c < width; c += 256) { float acc = out[c]; for (int i = 0; i < cnt; ++i) acc += dY[(long)s_list[i] * width + c]; out[c] = acc; }
+                __syncthreads();
+                if (tid == 0) s_total = 0;
+                __syncthreads();
+                if (last) break;
             }
+            const int r = base + tid;
+            const bool hit = (r < rows) && (tok[r] == v);
+            const unsigned long long mk = __ballot(hit);
+            if (lane == 0) s_wcnt[wave] = __popcll(mk);
             __syncthreads();
-            if (tid == 0) s_total = 0;
+            int off = s_total;
+            for (int w = 0; w < wave; ++w) off += s_wcnt[w];
+            const int pos = off + __popcll(mk & ((1ull << lane) - 1ull));
+            if (hit) s_list[pos] = r;
+            __syncthreads();
+            if (tid == 0) s_total += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
             __syncthreads();
         }
+        return;
+    }
+    // bitonic sort of the segment (padded with INT_MAX to a power of two) in LDS
+    int np2 = 1; while (np2 < n) np2 <<= 1;
+    for (int i = tid; i < np2; i += 256) s_list[i] = i < n ? list[o0 + i] : 0x7fffffff;
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < np2; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const int a = s_list[i], b = s_list[ixj];
+                    if (((i & k) == 0) ? (a > b) : (a < b)) { s_list[i] = b; s_list[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int c = tid; c < width; c += 256) {
+        float acc = 0.f;
+        for (int i = 0; i < n; ++i) acc += dY[(long)s_list[i] * width + c];
+        out[c] = acc;
     }
 }
 

@@ -249,3 +249,26 @@ def test_stacked_lstm_layers_against_oracle(M, layers, dropout):
     close(ann_bld.grad.reshape(B, Hh, Ww, 24).permute(0, 3, 1, 2), ann_o.grad, 2e-4, "d_ann")
     for k, p in dec.named_parameters():
         close(p.grad, sdo[k].grad, 2e-4, k)
+
+
+def test_embedding_gradient_with_very_frequent_tokens(M):
+    """tiny vocabulary: every word occurs > 1024 times among the fed tokens (the embedding gradient's long-segment path), plus the
+    sorted short-segment path for the rest; against the oracle."""
+    from oracle import prng, sat_oracle as O
+    hp = O.default_hparams(vocab_size=9, encoder_dim=16, embed_dim=12, attention_dim=8, decoder_dim=20)
+    sd = {k: torch.from_numpy(v) for k, v in prng.decoder_state(hp, 401).items()}
+    B, R, T, Hh, Ww = 64, 5, 22, 2, 2
+    ann = torch.from_numpy(prng.uniform((B, 16, Hh, Ww), 411, 0.0, 2.0))
+    caps, lengths = prng.captions(B, R, T, 9, 412, min_len=18)
+    caps, lengths = torch.from_numpy(caps), torch.from_numpy(lengths)
+    counts = torch.bincount(caps[:, :, :-1].reshape(-1), minlength=9)
+    assert int(counts.max()) > 1024
+    dec = M.SATDecoder(hp).cuda(); dec.load_decoder_state(sd)
+    ann_bld = ann.permute(0, 2, 3, 1).reshape(B, Hh * Ww, 16).contiguous().cuda().requires_grad_()
+    res = dec.train_decode(ann_bld, caps.cuda(), lengths, 1.0)
+    (res["ce"] + res["ds"]).backward()
+    sdo = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    loss_o, out_o = O.training_loss(sdo, hp, ann.clone().requires_grad_(), caps, lengths, 1.0)
+    loss_o.backward()
+    close(dec.embedding.weight.grad, sdo["embedding.weight"].grad, 2e-4, "embedding gradient")
+    assert float(dec.embedding.weight.grad[dec.pad_idx].abs().max()) == 0.0
