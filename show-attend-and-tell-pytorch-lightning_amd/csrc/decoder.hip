@@ -2,6 +2,7 @@
 // (model.py:487-548) and its backward through time, as a fixed sequence of kernel launches.
 // No allocation, no synchronisation: everything lives in the caller's workspace.
 #include "../../include/sat_hip.h"
+#include <stdlib.h>
 #include "decoder.h"
 #include "decoder_kernels.h"
 #include "gemm.h"
@@ -18,6 +19,7 @@ struct Ws {
     __bf16 *Wb_out, *Ub;                                         // bf16 mode: bf16 copies of output.output.weight and of the packed deep-output rows
     int* Tok; int* flags;
     int *emb_count, *emb_offset, *emb_cursor, *emb_list;         // embedding gradient: per-row token segments
+    float *SC, *DA;                                              // attention: raw scores / score gradients of one step (N, L)
     // backward scratch
     float *dA, *dHout, *dZout, *DZ, *DHC, *dXZ, *dHc, *dCc, *dU, *dwf_part, *dY, *colpart, *dinit_img, *df, *dmean, *slab;
     long slab_elems;
@@ -61,6 +63,7 @@ Ws layout(const sat_decoder_dims& d, char* base) {
     w.flags = (int*)take((size_t)d.V);
     w.emb_count = (int*)take((size_t)d.V); w.emb_offset = (int*)take((size_t)d.V + 1); w.emb_cursor = (int*)take((size_t)d.V);
     w.emb_list = (int*)take((size_t)T1 * N);
+    w.SC = (float*)take((size_t)N * d.L); w.DA = (float*)take((size_t)N * d.L);
     w.dA = (float*)take((size_t)(d.P > 0 ? d.P : 1) * d.m);
     w.dHout = (float*)take((size_t)T1 * N * d.n);
     w.dZout = (float*)take((size_t)T1 * N * d.D);
@@ -142,8 +145,36 @@ static int live_steps(const sat_decoder_dims& d, const sat_decoder_batch& b) {
 static size_t att_fwd_lds(int L, int A, int vw) { return (size_t)(ATT_RMAX * L + ATT_RMAX * A + A + ATT_RMAX * ATT_THREADS * vw) * 4; }
 static size_t att_bwd_lds(int L, int A, int D) { return (size_t)(2 * ATT_RMAX * L + ATT_RMAX * A + A + ATT_RMAX * D + ATTB_WAVES * ATT_RMAX * A + ATTB_WAVES * A) * 4; }
 
+template <int RN>
+static int attention_fwd_split(hipStream_t st, const float* ann, const float* U, const float* hc, int hc_ld, const float* wf, const int* lengths, int step,
+                               float* alphas, int T1, float* Z, float* XZ, int B, int R, int L, int D, int A, float* sc) {
+    const size_t lds_s = (size_t)(RN * A + A) * 4, lds_c = (size_t)((RN * L + 3) & ~3) * 4 + (size_t)16 * RN * 16 * 16;
+    SAT_REQUIRE(lds_s <= 160 * 1024 && lds_c <= 160 * 1024, "attention_fwd: L=%d A=%d do not fit the LDS", L, A);
+    SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_scores_kernel<RN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
+    SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_context_kernel<RN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
+    hipLaunchKernelGGL(attention_scores_kernel<RN>, dim3(B, cdiv(L, ATTS_WAVES)), dim3(ATTS_WAVES * 64), lds_s, st, U, hc, hc_ld, wf, sc, R, L, A);
+    SAT_TRY(launch_ok("attention_scores"));
+    hipLaunchKernelGGL(attention_context_kernel<RN>, dim3(B, cdiv(D, ATTC_DCH)), dim3(256), lds_c, st, ann, sc, hc, hc_ld, lengths, step, alphas, T1, Z, XZ, R, L, D, A);
+    return launch_ok("attention_context");
+}
+
 int launch_attention_fwd(hipStream_t st, const float* ann, const float* U, const float* hc, int hc_ld, const float* wf,
-                                const int* lengths, int step, float* alphas, int T1, float* Z, float* XZ, int B, int R, int L, int D, int A) {
+                                const int* lengths, int step, float* alphas, int T1, float* Z, float* XZ, int B, int R, int L, int D, int A, float* sc) {
+    static const int no_split = getenv("SAT_ATT_FUSED") ? atoi(getenv("SAT_ATT_FUSED")) : 0;
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (sc && !no_split && D % 4 == 0 && A % 4 == 0 && hc_ld % 4 == 0 && al16(ann) && al16(hc) && al16(Z) && al16(XZ)) {
+        // scores and context as two chip-wide launches (scratch: raw scores (B*R, L))
+        switch (R < ATT_RMAX ? R : ATT_RMAX) {
+            case 1: return attention_fwd_split<1>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc);
+            case 2: return attention_fwd_split<2>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc);
+            case 3: return attention_fwd_split<3>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc);
+            case 4: return attention_fwd_split<4>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc);
+            case 5: return attention_fwd_split<5>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc);
+            case 6: return attention_fwd_split<6>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc);
+            case 7: return attention_fwd_split<7>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc);
+            default: return attention_fwd_split<8>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc);
+        }
+    }
     const bool vec = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(ann) & 15) == 0);
     const int vw = vec ? 4 : 1;
     int dchunk = vec ? 256 : 64;
@@ -301,7 +332,7 @@ int decoder_fwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
             SAT_TRY(gemm(st, A_ROW, B_ROW, Hs(t, 0), n, w.Wcat + (long)(A + D) * n, n, hc + A + D, HCW, N, 4 * n, n, 0, EPI_BIAS, w.bcat + A + D));
         }
         SAT_TRY(launch_attention_fwd(st, b.ann, w.U, hc, HCW, p.att_f, b.lengths, t, alphas, T1, w.Z + (long)t * N * D, w.XZ + (long)t * N * D,
-                                     d.B, d.R, d.L, D, A));
+                                     d.B, d.R, d.L, D, A, w.SC));
         // gates += (beta*z) * W_ih[:, m:]^T
         SAT_TRY(gemm(st, A_ROW, B_ROW, w.XZ + (long)t * N * D, D, p.w_ih + m, m + D, hc + A + D, HCW, N, 4 * n, D, 1));
         hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(cdiv((long)N * n, 256)), dim3(256), 0, st, hc + A + D, HCW, w.GY + (long)t * N * 4 * n,
@@ -509,7 +540,7 @@ int colsum_public(const float* x, long ld, long rows, int cols, float* out, floa
 size_t decoder_workspace_bytes(const sat_decoder_dims& d) { return layout(d, nullptr).total; }
 
 // ------------------------------------------------------------------ inference: one image, K live beams
-struct InferWs { size_t total; float *U, *Wcat, *bcat, *mean, *f, *init_img, *hc, *Z, *XZ, *Y, *u, *gu, *bup; int* ones; };
+struct InferWs { size_t total; float *U, *Wcat, *bcat, *mean, *f, *init_img, *hc, *Z, *XZ, *Y, *u, *gu, *bup, *sc; int* ones; };
 static InferWs infer_layout(const sat_decoder_dims& d, int Kmax, char* base) {
     InferWs w; size_t off = 0;
     const long HCW = d.A + d.D + 4L * d.n;
@@ -518,7 +549,7 @@ static InferWs infer_layout(const sat_decoder_dims& d, int Kmax, char* base) {
     w.mean = (float*)take(d.D); w.f = (float*)take(d.m); w.init_img = (float*)take(2 * (size_t)d.n * d.layers);
     w.gu = (float*)take((size_t)Kmax * 4 * d.n); w.bup = (float*)take((size_t)d.layers * 4 * d.n);
     w.hc = (float*)take((size_t)Kmax * HCW); w.Z = (float*)take((size_t)Kmax * d.D); w.XZ = (float*)take((size_t)Kmax * d.D);
-    w.Y = (float*)take((size_t)Kmax * d.m); w.u = (float*)take((size_t)Kmax * d.m); w.ones = (int*)take(Kmax);
+    w.Y = (float*)take((size_t)Kmax * d.m); w.u = (float*)take((size_t)Kmax * d.m); w.ones = (int*)take(Kmax); w.sc = (float*)take((size_t)Kmax * d.L);
     w.total = off;
     return w;
 }
@@ -574,7 +605,7 @@ int decoder_infer_step(const sat_decoder_dims& d, const sat_decoder_params& p, c
     // decoder_noise (model.py:322-324): the noise joins h after attention and the gate were taken from the clean state, so
     // it reaches the step through the recurrent products only: gates += noise * W_hh^T (the GEMM is linear in h)
     if (h_noise) SAT_TRY(gemm(st, A_ROW, B_ROW, h_noise, n, w.Wcat + (long)(A + D) * n, n, w.hc + A + D, HCW, K, 4 * n, n, 1));
-    SAT_TRY(launch_attention_fwd(st, ann, w.U, w.hc, HCW, p.att_f, w.ones, 0, alpha, 1, w.Z, w.XZ, 1, K, d.L, D, A));
+    SAT_TRY(launch_attention_fwd(st, ann, w.U, w.hc, HCW, p.att_f, w.ones, 0, alpha, 1, w.Z, w.XZ, 1, K, d.L, D, A, w.sc));
     SAT_TRY(gemm(st, A_ROW, B_ROW, w.Y, m, p.w_ih, m + D, w.hc + A + D, HCW, K, 4 * n, m, 1));
     SAT_TRY(gemm(st, A_ROW, B_ROW, w.XZ, D, p.w_ih + m, m + D, w.hc + A + D, HCW, K, 4 * n, D, 1));
     hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(cdiv((long)K * n, 256)), dim3(256), 0, st, w.hc + A + D, HCW, (const float*)nullptr, c, h, c, h, w.ones, 0, K, n);
@@ -602,7 +633,7 @@ int decoder_infer_step(const sat_decoder_dims& d, const sat_decoder_params& p, c
 // those of model.py:262-448; the whole loop is enqueued without a host round trip and leaves a back-trace
 // (token and parent row of every step, attention maps, finished list) for the host to read once.
 struct BeamWs {
-    size_t total; float *U, *Wcat, *bcat, *mean, *f, *init_img, *hc, *Z, *XZ, *Y, *u, *gu, *bup, *h, *c, *h2, *c2, *logits, *scores, *work, *vals, *top;
+    size_t total; float *U, *Wcat, *bcat, *mean, *f, *init_img, *hc, *Z, *XZ, *Y, *u, *gu, *bup, *h, *c, *h2, *c2, *logits, *scores, *work, *vals, *top, *sc;
     int *live, *klive, *inds, *gmap, *mask_first, *mask_rest;
 };
 static BeamWs beam_layout(const sat_decoder_dims& d, int K, char* base) {
@@ -617,7 +648,7 @@ static BeamWs beam_layout(const sat_decoder_dims& d, int K, char* base) {
     w.h = (float*)take((size_t)d.layers * N * d.n); w.c = (float*)take((size_t)d.layers * N * d.n);
     w.h2 = (float*)take((size_t)d.layers * N * d.n); w.c2 = (float*)take((size_t)d.layers * N * d.n);
     w.logits = (float*)take((size_t)N * d.V); w.scores = (float*)take((size_t)N * d.V); w.work = (float*)take((size_t)N * d.V);
-    w.vals = (float*)take(N); w.top = (float*)take(N);
+    w.vals = (float*)take(N); w.top = (float*)take(N); w.sc = (float*)take((size_t)N * d.L);
     w.live = (int*)take(N); w.klive = (int*)take(d.B); w.inds = (int*)take(N); w.gmap = (int*)take(N); w.mask_first = (int*)take(4); w.mask_rest = (int*)take(4);
     w.total = off;
     return w;
@@ -682,7 +713,7 @@ int decoder_beam_batched(const sat_decoder_dims& d, const sat_decoder_params& p,
             SAT_TRY(gemm(st, A_ROW, B_ROW, htop, n, w.Wcat, n, w.hc, HCW, N, A + D, n, 0, EPI_BIAS_SIGMOID_RANGE, w.bcat, nullptr, nullptr, nullptr, 0, A, A + D));
             SAT_TRY(gemm(st, A_ROW, B_ROW, h, n, w.Wcat + (long)(A + D) * n, n, w.hc + A + D, HCW, N, 4 * n, n, 0, EPI_BIAS, w.bcat + A + D));
         }
-        SAT_TRY(launch_attention_fwd(st, ann, w.U, w.hc, HCW, p.att_f, w.live, 0, alpha, 1, w.Z, w.XZ, B, K, d.L, D, A));
+        SAT_TRY(launch_attention_fwd(st, ann, w.U, w.hc, HCW, p.att_f, w.live, 0, alpha, 1, w.Z, w.XZ, B, K, d.L, D, A, w.sc));
         SAT_TRY(gemm(st, A_ROW, B_ROW, w.Y, m, p.w_ih, m + D, w.hc + A + D, HCW, N, 4 * n, m, 1));
         SAT_TRY(gemm(st, A_ROW, B_ROW, w.XZ, D, p.w_ih + m, m + D, w.hc + A + D, HCW, N, 4 * n, D, 1));
         hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(cdiv((long)N * n, 256)), dim3(256), 0, st, w.hc + A + D, HCW, (const float*)nullptr, c, h, c, h, w.live, 0, N, n);

@@ -287,6 +287,109 @@ __global__ __launch_bounds__(ATTF_THREADS) void attention_fwd_kernel(
     }
 }
 
+// ------------------------------------------------------------------ attention forward, split over the chip
+// The fused kernel above runs one workgroup per (image, 256-wide slice of D): 256 workgroups, each recomputing the image's
+// scores, and a context phase on 4 waves.  The two kernels below spread the step over ~1000 workgroups:
+//   scores : grid (B, ceil(L / 16)), wave per location -> raw scaled scores (N, L) in scratch
+//   context: grid (B, D / 64): softmax of the image's RN rows (cheap, redundant per slice), then 16 location groups x 16
+//            float4 vectors accumulate the slice of the context; fixed combination order.
+constexpr int ATTS_WAVES = 16;
+template <int RN>
+__global__ __launch_bounds__(ATTS_WAVES * 64) void attention_scores_kernel(const float* __restrict__ U, const float* __restrict__ hc, int hc_ld,
+                                                                           const float* __restrict__ wf, float* __restrict__ sc, int R, int L, int A) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* s_q = sm;                 // [RN][A]
+    float* s_w = s_q + RN * A;       // [A]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l = blockIdx.y * ATTS_WAVES + wave;
+    const float scale = 1.0f / sqrtf((float)L);
+    for (int k = tid; k < A; k += ATTS_WAVES * 64) s_w[k] = wf[k];
+    for (int r0 = 0; r0 < R; r0 += RN) {
+        const int rn = min(RN, R - r0), i0 = b * R + r0;
+        __syncthreads();
+        for (int e = tid; e < RN * A; e += ATTS_WAVES * 64) { int r = e / A, k = e - r * A; s_q[e] = (r < rn) ? hc[(long)(i0 + r) * hc_ld + k] : 0.f; }
+        __syncthreads();
+        if (l < L) {
+            float part[RN];
+#pragma unroll
+            for (int r = 0; r < RN; ++r) part[r] = 0.f;
+            const float* u = U + ((long)b * L + l) * A;
+            for (int k = lane; k < A; k += 64) {
+                const float uv = u[k], w = s_w[k];
+#pragma unroll
+                for (int r = 0; r < RN; ++r) part[r] = fmaf(w, fast_tanh(uv + s_q[r * A + k]), part[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < RN; ++r) { const float s = wave_sum(part[r]); if (lane == 0 && r < rn) sc[(long)(i0 + r) * L + l] = s * scale; }
+        }
+    }
+}
+
+constexpr int ATTC_DCH = 64;          // context slice: 64 features = 16 float4 vectors x 16 location groups per 256 threads
+template <int RN>
+__global__ __launch_bounds__(256) void attention_context_kernel(const float* __restrict__ ann, const float* __restrict__ sc, const float* __restrict__ hc,
+                                                                int hc_ld, const int* __restrict__ lengths, int step, float* __restrict__ alphas, int T1,
+                                                                float* __restrict__ Z, float* __restrict__ XZ, int R, int L, int D, int A) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* s_al = sm;                          // [RN][L]
+    float4* s_part = reinterpret_cast<float4*>(sm + ((RN * L + 3) & ~3));   // [16 groups][RN][16 vectors]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int d0 = blockIdx.y * ATTC_DCH;
+    const int v = tid & 15, g = tid >> 4;
+    for (int r0 = 0; r0 < R; r0 += RN) {
+        const int rn = min(RN, R - r0), i0 = b * R + r0;
+        unsigned lmask = 0;
+        for (int r = 0; r < rn; ++r) if (lengths[i0 + r] > step) lmask |= 1u << r;
+        __syncthreads();
+        // softmax over L of the live rows (wave per row); dead rows and rows past R get zero weights
+        for (int r = wave; r < RN; r += 4) {
+            const bool livr = (lmask >> r) & 1u;
+            float mx = -INFINITY;
+            if (livr) for (int l = lane; l < L; l += 64) mx = fmaxf(mx, sc[(long)(i0 + r) * L + l]);
+            mx = wave_max(mx);
+            float sum = 0.f;
+            if (livr) for (int l = lane; l < L; l += 64) { const float e = __expf(sc[(long)(i0 + r) * L + l] - mx); s_al[r * L + l] = e; sum += e; }
+            sum = wave_sum(sum);
+            const float inv = livr ? 1.0f / sum : 0.f;
+            for (int l = lane; l < L; l += 64) s_al[r * L + l] = livr ? s_al[r * L + l] * inv : 0.f;
+        }
+        __syncthreads();
+        if (blockIdx.y == 0)
+            for (int e = tid; e < rn * L; e += 256) { int r = e / L, l = e - r * L; alphas[((long)(i0 + r) * T1 + step) * L + l] = s_al[r * L + l]; }
+        // context slice
+        float4 acc[RN];
+#pragma unroll
+        for (int r = 0; r < RN; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int d = d0 + 4 * v;
+        if (d < D && lmask) {
+            const float* base = ann + (long)b * L * D + d;
+            for (int l = g; l < L; l += 16) {
+                const float4 x = *reinterpret_cast<const float4*>(base + (long)l * D);
+#pragma unroll
+                for (int r = 0; r < RN; ++r) {
+                    const float al = s_al[r * L + l];
+                    acc[r].x = fmaf(al, x.x, acc[r].x); acc[r].y = fmaf(al, x.y, acc[r].y); acc[r].z = fmaf(al, x.z, acc[r].z); acc[r].w = fmaf(al, x.w, acc[r].w);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RN; ++r) s_part[(g * RN + r) * 16 + v] = acc[r];
+        __syncthreads();
+        // thread (r = tid / 16 .., v): sums the 16 location groups in order and writes z and beta * z
+        for (int e = tid; e < rn * 16; e += 256) {
+            const int r = e >> 4, vv = e & 15, dd = d0 + 4 * vv;
+            if (dd >= D) continue;
+            float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int gg = 0; gg < 16; ++gg) { const float4 t = s_part[(gg * RN + r) * 16 + vv]; z.x += t.x; z.y += t.y; z.z += t.z; z.w += t.w; }
+            const long orow = i0 + r;
+            float4 be = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((lmask >> r) & 1u) be = *reinterpret_cast<const float4*>(hc + orow * hc_ld + A + dd);
+            *reinterpret_cast<float4*>(Z + orow * D + dd) = z;
+            *reinterpret_cast<float4*>(XZ + orow * D + dd) = make_float4(be.x * z.x, be.y * z.y, be.z * z.z, be.w * z.w);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ LSTM cell (pointwise part)
 // gates (N,4n) pre-activation = h W_hh^T + xz W_ih_z^T + biases (already in HC) + GY (embedding part).
 // Gate order i,f,g,o.  Activated gates are written back in place for backward.
