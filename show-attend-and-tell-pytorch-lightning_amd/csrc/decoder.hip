@@ -197,6 +197,29 @@ int launch_attention_fwd(hipStream_t st, const float* ann, const float* U, const
     return launch_ok("attention_fwd");
 }
 
+template <int RN>
+static int attention_bwd_split_t(hipStream_t st, const float* ann, const float* U, const float* hc, int hc_ld, const float* wf, const int* lengths, int step,
+                                 const float* alphas, const float* dalphas, int T1, const float* Zs, const float* dZ_out, const float* dXZ, float* DZ, float* dhc,
+                                 int dhc_ld, float* dU, float* dwf_part, float* da, int B, int R, int L, int D, int A) {
+    const size_t lds_a = (size_t)RN * D * 4, lds_t = (size_t)(RN * L + RN * ATTB_KCH + 32 * (RN + 1) * ATTB_KCH) * 4;
+    SAT_REQUIRE(lds_a <= 160 * 1024 && lds_t <= 160 * 1024, "attention_bwd: L=%d D=%d do not fit the LDS", L, D);
+    SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_dalpha_kernel<RN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
+    SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_tanh_kernel<RN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
+    hipLaunchKernelGGL(attention_bwd_dalpha_kernel<RN>, dim3(B, cdiv(L, 16)), dim3(1024), lds_a, st, ann, hc, hc_ld, lengths, step, dalphas, T1, Zs, dZ_out, dXZ, DZ, dhc,
+                       dhc_ld, da, R, L, D, A);
+    SAT_TRY(launch_ok("attention_bwd_dalpha"));
+    hipLaunchKernelGGL(attention_bwd_tanh_kernel<RN>, dim3(B, cdiv(A, ATTB_KCH)), dim3(1024), lds_t, st, U, hc, hc_ld, wf, lengths, step, alphas, T1, da, dhc, dhc_ld, dU,
+                       dwf_part, R, L, A);
+    return launch_ok("attention_bwd_tanh");
+}
+static int attention_bwd_split(int RN, hipStream_t st, const float* ann, const float* U, const float* hc, int hc_ld, const float* wf, const int* lengths, int step,
+                               const float* alphas, const float* dalphas, int T1, const float* Zs, const float* dZ_out, const float* dXZ, float* DZ, float* dhc,
+                               int dhc_ld, float* dU, float* dwf_part, float* da, int B, int R, int L, int D, int A) {
+#define SAT_ATTB(RNV) case RNV: return attention_bwd_split_t<RNV>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, dalphas, T1, Zs, dZ_out, dXZ, DZ, dhc, dhc_ld, dU, dwf_part, da, B, R, L, D, A);
+    switch (RN) { SAT_ATTB(1) SAT_ATTB(2) SAT_ATTB(3) SAT_ATTB(4) SAT_ATTB(5) SAT_ATTB(6) SAT_ATTB(7) default: return attention_bwd_split_t<8>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, dalphas, T1, Zs, dZ_out, dXZ, DZ, dhc, dhc_ld, dU, dwf_part, da, B, R, L, D, A); }
+#undef SAT_ATTB
+}
+
 // ------------------------------------------------------------------ output stage for packed rows [p0, p1)
 static int flush_outputs(hipStream_t st, const sat_decoder_dims& d, const sat_decoder_params& p, const sat_decoder_batch& b,
                          const Ws& w, float* logits, int p0, int p1) {
@@ -407,6 +430,7 @@ int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
     // ---- back through time
     const size_t lds_b = att_bwd_lds(d.L, A, D);
     SAT_REQUIRE(lds_b <= 160 * 1024, "attention_bwd: L=%d A=%d D=%d need %zu B of LDS (> 160 KiB)", d.L, A, D, lds_b);
+    static const int att_fused = getenv("SAT_ATT_FUSED") ? atoi(getenv("SAT_ATT_FUSED")) : 0;
     typedef void (*attb_fn)(const float*, const float*, const float*, int, const float*, const int*, int, const float*, const float*, int, const float*,
                             const float*, const float*, float*, float*, int, float*, float*, int, int, int, int);
     attb_fn attb = nullptr;
@@ -432,6 +456,10 @@ int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
         SAT_TRY(launch_ok("lstm_cell_bwd"));
         // d(beta*z) = dG * W_ih[:, m:]
         SAT_TRY(gemm(st, A_ROW, B_KMAJOR, dhc + A + D, HCW, p.w_ih + m, m + D, w.dXZ, D, N, D, 4 * n, 0, EPI_NONE, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, slab, se));
+        if (!att_fused) {
+            SAT_TRY(attention_bwd_split(d.R < ATT_RMAX ? d.R : ATT_RMAX, st, b.ann, w.U, hc, HCW, p.att_f, b.lengths, t, alphas, dalphas, T1, w.Z + (long)t * N * D,
+                                        w.dZout + (long)t * N * D, w.dXZ, w.DZ + (long)t * N * D, dhc, HCW, w.dU, w.dwf_part, w.DA, d.B, d.R, d.L, D, A));
+        } else
         hipLaunchKernelGGL(attb, dim3(d.B), dim3(ATTB_THREADS), lds_b, st, b.ann, w.U, hc, HCW, p.att_f, b.lengths, t, alphas,
                            dalphas, T1, w.Z + (long)t * N * D, w.dZout + (long)t * N * D, w.dXZ, w.DZ + (long)t * N * D, dhc, HCW, w.dU, w.dwf_part,
                            d.R, d.L, D, A);

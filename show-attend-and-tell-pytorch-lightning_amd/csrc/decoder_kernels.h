@@ -564,6 +564,126 @@ __global__ __launch_bounds__(ATTB_THREADS) void attention_bwd_kernel(
     for (int k = tid; k < A; k += ATTB_THREADS) { float sw = 0.f; for (int w = 0; w < ATTB_WAVES; ++w) sw += s_dw[w * A + k]; dwf_part[(long)b * A + k] += sw; }
 }
 
+// ------------------------------------------------------------------ attention backward, split over the chip (see the forward split)
+//   dalpha : grid (B, ceil(L / 16)): dz rows of the image in LDS (block 0 of an image also writes DZ and the gate gradient),
+//            wave per location: dalpha[r][l] = dz[r] . ann[b, l, :] (+ external gradient) -> scratch (N, L)
+//   tanh   : grid (B, ceil(A / 32)): softmax backward of the image's rows (redundant per slice), then 32 attention units x 32
+//            location lanes go through the tanh; the block owns dU[b, :, its units], dq and dw of its units.
+template <int RN>
+__global__ __launch_bounds__(1024) void attention_bwd_dalpha_kernel(const float* __restrict__ ann, const float* __restrict__ hc, int hc_ld,
+        const int* __restrict__ lengths, int step, const float* __restrict__ dalphas_ext, int T1, const float* __restrict__ Zs,
+        const float* __restrict__ dZ_out, const float* __restrict__ dXZ, float* __restrict__ DZ, float* __restrict__ dhc, int dhc_ld,
+        float* __restrict__ da, int R, int L, int D, int A) {
+    extern __shared__ __attribute__((aligned(16))) float s_dz[];          // [RN][D]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l = blockIdx.y * 16 + wave;
+    for (int r0 = 0; r0 < R; r0 += RN) {
+        const int rn = min(RN, R - r0), i0 = b * R + r0;
+        unsigned lmask = 0;
+        for (int r = 0; r < rn; ++r) if (lengths[i0 + r] > step) lmask |= 1u << r;
+        __syncthreads();
+        for (int e = tid; e < RN * D; e += 1024) {
+            const int r = e / D, d = e - r * D; const long row = i0 + r;
+            float dz = 0.f, dbp = 0.f;
+            if ((lmask >> r) & 1u) {
+                const float beta = hc[row * hc_ld + A + d], z = Zs[row * D + d], dx = dXZ[row * D + d];
+                dz = dZ_out[row * D + d] + dx * beta;
+                dbp = dx * z * beta * (1.f - beta);
+            }
+            s_dz[e] = dz;
+            if (blockIdx.y == 0 && r < rn) { DZ[row * D + d] = dz; dhc[row * dhc_ld + A + d] = dbp; }
+        }
+        __syncthreads();
+        if (l < L) {
+            float part[RN];
+#pragma unroll
+            for (int r = 0; r < RN; ++r) part[r] = 0.f;
+            const float* a = ann + ((long)b * L + l) * D;
+            for (int d = lane; d < D; d += 64) {
+                const float av = a[d];
+#pragma unroll
+                for (int r = 0; r < RN; ++r) part[r] = fmaf(av, s_dz[r * D + d], part[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < RN; ++r) {
+                const float sdot = wave_sum(part[r]);
+                if (lane == 0 && r < rn)
+                    da[(long)(i0 + r) * L + l] = ((lmask >> r) & 1u) ? sdot + (dalphas_ext ? dalphas_ext[((long)(i0 + r) * T1 + step) * L + l] : 0.f) : 0.f;
+            }
+        }
+    }
+}
+
+constexpr int ATTB_KCH = 32;
+template <int RN>
+__global__ __launch_bounds__(1024) void attention_bwd_tanh_kernel(const float* __restrict__ U, const float* __restrict__ hc, int hc_ld, const float* __restrict__ wf,
+        const int* __restrict__ lengths, int step, const float* __restrict__ alphas, int T1, const float* __restrict__ da, float* __restrict__ dhc,
+        int dhc_ld, float* __restrict__ dU, float* __restrict__ dwf_part, int R, int L, int A) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* s_ds = sm;                               // [RN][L]
+    float* s_q = s_ds + RN * L;                     // [RN][KCH]
+    float* s_red = s_q + RN * ATTB_KCH;             // [32 lanes][RN + 1][KCH]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kk = tid & 31, lg = tid >> 5, k = blockIdx.y * ATTB_KCH + kk;
+    const float scale = 1.0f / sqrtf((float)L);
+    const float w = k < A ? wf[k] : 0.f;
+    float dw_total = 0.f;
+    for (int r0 = 0; r0 < R; r0 += RN) {
+        const int rn = min(RN, R - r0), i0 = b * R + r0;
+        unsigned lmask = 0;
+        for (int r = 0; r < rn; ++r) if (lengths[i0 + r] > step) lmask |= 1u << r;
+        __syncthreads();
+        // softmax backward: ds = alpha * (dalpha - sum alpha * dalpha) * L^-1/2, wave per row; dead rows: 0
+        for (int r = wave; r < RN; r += 16) {
+            const bool livr = (lmask >> r) & 1u;
+            float dot = 0.f;
+            if (livr) for (int l = lane; l < L; l += 64) dot += alphas[((long)(i0 + r) * T1 + step) * L + l] * da[(long)(i0 + r) * L + l];
+            dot = wave_sum(dot);
+            for (int l = lane; l < L; l += 64)
+                s_ds[r * L + l] = livr ? alphas[((long)(i0 + r) * T1 + step) * L + l] * (da[(long)(i0 + r) * L + l] - dot) * scale : 0.f;
+        }
+        for (int e = tid; e < RN * ATTB_KCH; e += 1024) {
+            const int r = e / ATTB_KCH, k2 = blockIdx.y * ATTB_KCH + (e - r * ATTB_KCH);
+            s_q[e] = (r < rn && k2 < A) ? hc[(long)(i0 + r) * hc_ld + k2] : 0.f;
+        }
+        __syncthreads();
+        float dq[RN], dw = 0.f;
+#pragma unroll
+        for (int r = 0; r < RN; ++r) dq[r] = 0.f;
+        if (k < A && lmask) {
+            for (int l = lg; l < L; l += 32) {
+                const long uo = ((long)b * L + l) * A + k;
+                const float uv = U[uo];
+                float du = 0.f;
+#pragma unroll
+                for (int r = 0; r < RN; ++r) {
+                    const float th = fast_tanh(uv + s_q[r * ATTB_KCH + kk]);
+                    const float ds = s_ds[r * L + l];
+                    const float dp = ds * w * (1.f - th * th);
+                    dq[r] += dp; du += dp; dw = fmaf(ds, th, dw);
+                }
+                dU[uo] += du;                        // (b, k) belongs to this block alone: plain read-modify-write, fixed order
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RN; ++r) s_red[(lg * (RN + 1) + r) * ATTB_KCH + kk] = dq[r];
+        s_red[(lg * (RN + 1) + RN) * ATTB_KCH + kk] = dw;
+        __syncthreads();
+        for (int e = tid; e < (RN + 1) * ATTB_KCH; e += 1024) {
+            const int r = e / ATTB_KCH, k2 = e - r * ATTB_KCH, kg = blockIdx.y * ATTB_KCH + k2;
+            float sacc = 0.f;
+            for (int g2 = 0; g2 < 32; ++g2) sacc += s_red[(g2 * (RN + 1) + r) * ATTB_KCH + k2];
+            if (kg < A) {
+                if (r < RN) { if (r < rn) dhc[(long)(i0 + r) * dhc_ld + kg] = sacc; }
+                else s_q[k2] = sacc;                 // dw of this pass (s_q is free until the next pass reloads it)
+            }
+        }
+        __syncthreads();
+        if (tid < ATTB_KCH) dw_total += s_q[tid];
+    }
+    if (tid < ATTB_KCH && k < A) dwf_part[(long)b * A + k] += dw_total;
+}
+
 // d ann[b, l, :] += sum over the image's captions r and steps t of alpha[i, t, l] * DZ[t, i, :]  (i = b*R + r):
 // the context path of the attention backward, summed over time.  One block per (image, 256-wide slice of D).  The
 // image's alphas are staged in LDS once, rows zero-padded to a multiple of 4 floats so that a location slab is NQ
