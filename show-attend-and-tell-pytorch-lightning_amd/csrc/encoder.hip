@@ -115,12 +115,16 @@ __device__ __forceinline__ void mask_to_floats(const unsigned char* __restrict__
     for (int i = 0; i < N; ++i) o[i] = (b >> i) & 1u ? 1.f : 0.f;
 }
 
+#ifndef UNROLL_BWD_BF16
+#define UNROLL_BWD_BF16 2
+#endif
 template <int MODE, typename T>
 __global__ __launch_bounds__(256) void bn_colstats_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
                                                           const unsigned char* __restrict__ rmask,
                                                           const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
                                                           long rows, int C, int CV, long rows_per, double* __restrict__ part0, double* __restrict__ part1) {
     constexpr int E = EPT<T>::n;
+    constexpr int UN = (MODE == 1 && E == 8) ? UNROLL_BWD_BF16 : 4;          // rows in flight per thread
     __shared__ double sh[2][256][E > 4 ? 4 : E];      // reduced in two halves when E == 8
     const int tid = threadIdx.x, tc = tid % CV, tr = tid / CV, RL = 256 / CV;
     const int cv = blockIdx.x * CV + tc;              // vector column
@@ -137,10 +141,10 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const T* __restrict__ 
         } else ldv<T, E>(x, cv, mu);                 // shift = row 0
         long r0 = (long)blockIdx.y * rows_per, r1 = r0 + rows_per; if (r1 > rows) r1 = rows;
         long r = r0 + tr;
-        for (; r + 3L * RL < r1; r += 4L * RL) {     // 4 independent 16-byte loads in flight per operand, kept packed until used
-            uint4 xr[4], gr[4], yr[4]; unsigned mb[4];
+        for (; r + (UN - 1L) * RL < r1; r += (long)UN * RL) {     // UN independent 16-byte loads in flight per operand, kept packed until used
+            uint4 xr[UN], gr[UN], yr[UN]; unsigned mb[UN];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < UN; ++u) {
                 const long iv = (r + (long)u * RL) * CVT + cv;
                 xr[u] = reinterpret_cast<const uint4*>(x)[iv];
                 if (MODE == 1) {
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(256) void bn_colstats_kernel(const T* __restrict__ 
 #pragma unroll
             for (int i = 0; i < E; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < UN; ++u) {
                 float xv[E], gv[E], yv[E];
                 unpack<T, E>(xr[u], xv);
                 if (MODE == 1) {
@@ -577,13 +581,15 @@ int sat_pad_channels_3to4(const float* src, float* dst, int64_t pixels, int32_t 
 
 }  // extern "C" (typed implementations follow)
 
-static void bn_grid(long rows, int C, int E, int& CV, long& rows_per, int& nparts) {
+static void bn_grid(long rows, int C, int E, int& CV, long& rows_per, int& nparts, int backward = 0) {
     int CVT = C / E;
     CV = CVT < 256 ? CVT : 256;
     while (256 % CV) --CV;                      // CV must divide 256
     int RL = 256 / CV;
     int colblocks = cdiv(CVT, CV);
-    static const long target = getenv("SAT_BN_BLOCKS") ? atol(getenv("SAT_BN_BLOCKS")) : 512;
+    static const long target_f = getenv("SAT_BN_BLOCKS") ? atol(getenv("SAT_BN_BLOCKS")) : 512;
+    static const long target_b = getenv("SAT_BN_BLOCKS_BWD") ? atol(getenv("SAT_BN_BLOCKS_BWD")) : 768;      // the backward pass keeps 2 rows x 2 operands in flight: 4 blocks per CU fit
+    const long target = backward ? target_b : target_f;
     long want = target / colblocks; if (want < 1) want = 1;         // ~2 blocks per CU: measured best on the C2 step (fewer, longer blocks; fewer partials to finalise)
     rows_per = cdiv(rows, want);
     long minrows = (long)RL * 8; if (rows_per < minrows) rows_per = minrows;
@@ -592,10 +598,12 @@ static void bn_grid(long rows, int C, int E, int& CV, long& rows_per, int& npart
 
 extern "C" size_t sat_bn_scratch_bytes(int64_t rows, int32_t C) {
     if (rows <= 0 || C <= 0 || C % 4) return 0;
-    int CV, nparts; long rp; bn_grid(rows, C, 4, CV, rp, nparts);
-    int CV8 = 0, np8 = 0; long rp8 = 0;
-    if (C % 8 == 0) bn_grid(rows, C, 8, CV8, rp8, np8);
-    int np = nparts > np8 ? nparts : np8;
+    int np = 0;
+    for (int bwd = 0; bwd < 2; ++bwd) {            // the largest partial count of the forward / backward grids at either vector width
+        int CV, nparts; long rp; bn_grid(rows, C, 4, CV, rp, nparts, bwd);
+        if (nparts > np) np = nparts;
+        if (C % 8 == 0) { bn_grid(rows, C, 8, CV, rp, nparts, bwd); if (nparts > np) np = nparts; }
+    }
     return (size_t)np * C * 2 * sizeof(double) + 64;
 }
 
@@ -656,7 +664,7 @@ static int bn_train_bwd_t(const T* dy, const T* x, const T* y, int64_t rows, int
     SAT_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, "bn_train_bwd: bad shape");
     constexpr int E = EPT<T>::n;
     SAT_REQUIRE(C % E == 0, "bn_train_bwd: C=%d must be a multiple of %d for this storage type", C, E);
-    int CV, nparts; long rp; bn_grid(rows, C, E, CV, rp, nparts);
+    int CV, nparts; long rp; bn_grid(rows, C, E, CV, rp, nparts, 1);
     double* p0 = reinterpret_cast<double*>(scratch); double* p1 = p0 + (long)nparts * C;
     {
         ProfScope prof("bn_stats_bwd", 0.0, (double)rows * C * (sizeof(T) * 2 + (relu ? (relu_mask ? 0.125 : (double)sizeof(T)) : 0.0)), st);
