@@ -17,6 +17,7 @@ struct Ws {
     float *Udrop, *mean_rows, *f_rows, *init_rows, *df_rows;     // only carved when dropout > 0
     float *GU, *DGU, *bup;                                       // stacked LSTM layers (layers > 1): gates, gate grads, bias sums
     __bf16 *Wb_out, *Ub;                                         // bf16 mode: bf16 copies of output.output.weight and of the packed deep-output rows
+    __bf16 *Hb, *XZb, *Wcat_b, *Wz_b;                            // bf16 mode, one LSTM layer: operands of the per-step GEMMs (state, gated context, weights)
     int* Tok; int* flags;
     int *emb_count, *emb_offset, *emb_cursor, *emb_list;         // embedding gradient: per-row token segments
     float *SC, *DA;                                              // attention: raw scores / score gradients of one step (N, L)
@@ -59,6 +60,11 @@ Ws layout(const sat_decoder_dims& d, char* base) {
     w.Wb_out = w.Ub = nullptr;
     if (d.precision && d.m % 64 == 0 && d.V % 8 == 0) {           // operands of the vocabulary projection for the direct-to-LDS GEMM
         w.Wb_out = (__bf16*)take((size_t)d.V * d.m, 2); w.Ub = (__bf16*)take((size_t)(d.P > 0 ? d.P : 1) * d.m, 2);
+    }
+    w.Hb = w.XZb = w.Wcat_b = w.Wz_b = nullptr;
+    if (d.precision && d.layers == 1 && d.n % 64 == 0 && d.D % 64 == 0 && d.A % 4 == 0 && d.m % 4 == 0) {
+        w.Hb = (__bf16*)take((size_t)(T1 + 1) * N * d.n, 2); w.XZb = (__bf16*)take((size_t)N * d.D, 2);
+        w.Wcat_b = (__bf16*)take((size_t)HCW * d.n, 2); w.Wz_b = (__bf16*)take((size_t)4 * d.n * d.D, 2);
     }
     w.flags = (int*)take((size_t)d.V);
     w.emb_count = (int*)take((size_t)d.V); w.emb_offset = (int*)take((size_t)d.V + 1); w.emb_cursor = (int*)take((size_t)d.V);
@@ -116,10 +122,12 @@ static int cast_bf16(hipStream_t st, const float* src, __bf16* dst, long n) {
     return launch_ok("cast_bf16");
 }
 // C (fp32) = A (bf16, rows x K) * B^T (bf16, N x K): both operands bf16 in HBM -> gemm_glds.hip
-static int gemm_bb_nt(hipStream_t st, const __bf16* A, long lda, const __bf16* B, long ldb, float* C, long ldc, int M, int N, int K, int epi, const float* bias) {
+static int gemm_bb_nt(hipStream_t st, const __bf16* A, long lda, const __bf16* B, long ldb, float* C, long ldc, int M, int N, int K, int epi, const float* bias,
+                      int acc = 0, int c0 = 0, int c1 = 0) {
     GemmArgs g;
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.amode = A_ROW; g.bmode = B_ROW; g.epi = epi; g.bias = bias; g.a_bf16 = g.b_bf16 = 1; g.c_bf16 = 0; g.bf16_mfma = 1;
+    g.accumulate = acc; g.c0 = c0; g.c1 = c1;
     return launch_gemm(g, st);
 }
 
@@ -145,36 +153,42 @@ static int live_steps(const sat_decoder_dims& d, const sat_decoder_batch& b) {
 static size_t att_fwd_lds(int L, int A, int vw) { return (size_t)(ATT_RMAX * L + ATT_RMAX * A + A + ATT_RMAX * ATT_THREADS * vw) * 4; }
 static size_t att_bwd_lds(int L, int A, int D) { return (size_t)(2 * ATT_RMAX * L + ATT_RMAX * A + A + ATT_RMAX * D + ATTB_WAVES * ATT_RMAX * A + ATTB_WAVES * A) * 4; }
 
+static bool attention_split_enabled() {
+    static const int no_split = getenv("SAT_ATT_FUSED") ? atoi(getenv("SAT_ATT_FUSED")) : 0;
+    return !no_split;
+}
 template <int RN>
 static int attention_fwd_split(hipStream_t st, const float* ann, const float* U, const float* hc, int hc_ld, const float* wf, const int* lengths, int step,
-                               float* alphas, int T1, float* Z, float* XZ, int B, int R, int L, int D, int A, float* sc) {
+                               float* alphas, int T1, float* Z, float* XZ, int B, int R, int L, int D, int A, float* sc, __bf16* xzb) {
     const size_t lds_s = (size_t)(RN * A + A) * 4, lds_c = (size_t)((RN * L + 3) & ~3) * 4 + (size_t)16 * RN * 16 * 16;
     SAT_REQUIRE(lds_s <= 160 * 1024 && lds_c <= 160 * 1024, "attention_fwd: L=%d A=%d do not fit the LDS", L, A);
     SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_scores_kernel<RN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
     SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_context_kernel<RN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
     hipLaunchKernelGGL(attention_scores_kernel<RN>, dim3(B, cdiv(L, ATTS_WAVES)), dim3(ATTS_WAVES * 64), lds_s, st, U, hc, hc_ld, wf, sc, R, L, A);
     SAT_TRY(launch_ok("attention_scores"));
-    hipLaunchKernelGGL(attention_context_kernel<RN>, dim3(B, cdiv(D, ATTC_DCH)), dim3(256), lds_c, st, ann, sc, hc, hc_ld, lengths, step, alphas, T1, Z, XZ, R, L, D, A);
+    hipLaunchKernelGGL(attention_context_kernel<RN>, dim3(B, cdiv(D, ATTC_DCH)), dim3(256), lds_c, st, ann, sc, hc, hc_ld, lengths, step, alphas, T1, Z, XZ, R, L, D, A, xzb);
     return launch_ok("attention_context");
 }
 
 int launch_attention_fwd(hipStream_t st, const float* ann, const float* U, const float* hc, int hc_ld, const float* wf,
-                                const int* lengths, int step, float* alphas, int T1, float* Z, float* XZ, int B, int R, int L, int D, int A, float* sc) {
+                                const int* lengths, int step, float* alphas, int T1, float* Z, float* XZ, int B, int R, int L, int D, int A, float* sc, void* xzb_v) {
+    __bf16* xzb = reinterpret_cast<__bf16*>(xzb_v);
     static const int no_split = getenv("SAT_ATT_FUSED") ? atoi(getenv("SAT_ATT_FUSED")) : 0;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     if (sc && !no_split && D % 4 == 0 && A % 4 == 0 && hc_ld % 4 == 0 && al16(ann) && al16(hc) && al16(Z) && al16(XZ)) {
         // scores and context as two chip-wide launches (scratch: raw scores (B*R, L))
         switch (R < ATT_RMAX ? R : ATT_RMAX) {
-            case 1: return attention_fwd_split<1>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc);
-            case 2: return attention_fwd_split<2>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc);
-            case 3: return attention_fwd_split<3>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc);
-            case 4: return attention_fwd_split<4>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc);
-            case 5: return attention_fwd_split<5>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc);
-            case 6: return attention_fwd_split<6>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc);
-            case 7: return attention_fwd_split<7>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc);
-            default: return attention_fwd_split<8>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc);
+            case 1: return attention_fwd_split<1>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc, xzb);
+            case 2: return attention_fwd_split<2>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc, xzb);
+            case 3: return attention_fwd_split<3>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc, xzb);
+            case 4: return attention_fwd_split<4>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc, xzb);
+            case 5: return attention_fwd_split<5>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc, xzb);
+            case 6: return attention_fwd_split<6>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc, xzb);
+            case 7: return attention_fwd_split<7>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc, xzb);
+            default: return attention_fwd_split<8>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc, xzb);
         }
     }
+    SAT_REQUIRE(!xzb, "attention_fwd: the bf16 copy of the gated context needs the split kernels (aligned shapes)");
     const bool vec = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(ann) & 15) == 0);
     const int vw = vec ? 4 : 1;
     int dchunk = vec ? 256 : 64;
@@ -305,6 +319,15 @@ int decoder_fwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
         SAT_TRY(launch_ok("init_expand"));
     }
 
+    // bf16 mode, one layer: the per-step GEMMs read bf16 copies (state written by the cell kernel, gated context by the attention
+    // kernel, weights cast here once) through the direct-to-LDS kernel instead of rounding fp32 operands in registers every step
+    const bool use_b = w.Hb != nullptr && attention_split_enabled();
+    if (use_b) {
+        SAT_TRY(cast_bf16(st, w.Wcat, w.Wcat_b, (long)HCW * n));
+        hipLaunchKernelGGL(cast_block_bf16_kernel, dim3(cdiv((long)4 * n * (D / 4), 256)), dim3(256), 0, st, p.w_ih + m, (long)(m + D), w.Wz_b, 4 * n, D);
+        SAT_TRY(launch_ok("cast W_ih[:, m:]"));
+        SAT_TRY(cast_bf16(st, Hs(0, 0), w.Hb, (long)N * n));
+    }
     // alphas of steps that never run stay zero (model.py:506)
     if (ts < T1) SAT_CHECK_HIP(hipMemsetAsync(alphas, 0, (size_t)N * T1 * d.L * 4, st));
 
@@ -346,7 +369,9 @@ int decoder_fwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
         }
         // [q | beta | gates_h] = h_{t-1} * Wcat^T + bcat, sigmoid on the beta columns.  Attention and the gate read the TOP
         // layer's state (h[-1], model.py:533,538); the recurrent term of layer 0 reads layer 0's.
-        if (NL == 1) {
+        if (use_b) {
+            SAT_TRY(gemm_bb_nt(st, w.Hb + (long)t * N * n, n, w.Wcat_b, n, hc, HCW, N, HCW, n, EPI_BIAS_SIGMOID_RANGE, w.bcat, 0, A, A + D));
+        } else if (NL == 1) {
             SAT_TRY(gemm(st, A_ROW, B_ROW, Hs(t, 0), n, w.Wcat, n, hc, HCW, N, HCW, n, 0, EPI_BIAS_SIGMOID_RANGE, w.bcat,
                          nullptr, nullptr, nullptr, 0, A, A + D));
         } else {
@@ -355,11 +380,12 @@ int decoder_fwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
             SAT_TRY(gemm(st, A_ROW, B_ROW, Hs(t, 0), n, w.Wcat + (long)(A + D) * n, n, hc + A + D, HCW, N, 4 * n, n, 0, EPI_BIAS, w.bcat + A + D));
         }
         SAT_TRY(launch_attention_fwd(st, b.ann, w.U, hc, HCW, p.att_f, b.lengths, t, alphas, T1, w.Z + (long)t * N * D, w.XZ + (long)t * N * D,
-                                     d.B, d.R, d.L, D, A, w.SC));
+                                     d.B, d.R, d.L, D, A, w.SC, use_b ? w.XZb : nullptr));
         // gates += (beta*z) * W_ih[:, m:]^T
-        SAT_TRY(gemm(st, A_ROW, B_ROW, w.XZ + (long)t * N * D, D, p.w_ih + m, m + D, hc + A + D, HCW, N, 4 * n, D, 1));
+        if (use_b) SAT_TRY(gemm_bb_nt(st, w.XZb, D, w.Wz_b, D, hc + A + D, HCW, N, 4 * n, D, EPI_NONE, nullptr, 1));
+        else SAT_TRY(gemm(st, A_ROW, B_ROW, w.XZ + (long)t * N * D, D, p.w_ih + m, m + D, hc + A + D, HCW, N, 4 * n, D, 1));
         hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(cdiv((long)N * n, 256)), dim3(256), 0, st, hc + A + D, HCW, w.GY + (long)t * N * 4 * n,
-                           Cs(t, 0), Hs(t, 0), Cs(t + 1, 0), Hs(t + 1, 0), b.lengths, t, N, n);
+                           Cs(t, 0), Hs(t, 0), Cs(t + 1, 0), Hs(t + 1, 0), b.lengths, t, N, n, use_b ? w.Hb + (long)(t + 1) * N * n : (__bf16*)nullptr);
         SAT_TRY(launch_ok("lstm_cell_fwd"));
         for (int l = 1; l < NL; ++l) {          // stacked layers: input = the layer below's new h (nn.LSTM, no inter-layer dropout: model.py:175-180)
             float* gu = GUs(t, l);

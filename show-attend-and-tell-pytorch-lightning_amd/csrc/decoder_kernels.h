@@ -34,6 +34,17 @@ __global__ void cast_bf16_kernel(const float* __restrict__ src, __bf16* __restri
     reinterpret_cast<b4*>(dst)[e] = o;
 }
 
+// rows x cols fp32 block with row stride ld -> compact bf16 (cols % 4 == 0)
+__global__ void cast_block_bf16_kernel(const float* __restrict__ src, long ld, __bf16* __restrict__ dst, int rows, int cols) {
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c4 = cols / 4;
+    if (e >= (long)rows * c4) return;
+    const long r = e / c4; const int c = (int)(e - r * c4) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(src + r * ld + c);
+    typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+    b4 o; o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+    *reinterpret_cast<b4*>(dst + r * cols + c) = o;
+}
 __global__ void set4_int_kernel(int* p, int a, int b, int c, int d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
 __global__ void fill_int_kernel(int* p, long n, int v) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -329,7 +340,8 @@ constexpr int ATTC_DCH = 64;          // context slice: 64 features = 16 float4 
 template <int RN>
 __global__ __launch_bounds__(256) void attention_context_kernel(const float* __restrict__ ann, const float* __restrict__ sc, const float* __restrict__ hc,
                                                                 int hc_ld, const int* __restrict__ lengths, int step, float* __restrict__ alphas, int T1,
-                                                                float* __restrict__ Z, float* __restrict__ XZ, int R, int L, int D, int A) {
+                                                                float* __restrict__ Z, float* __restrict__ XZ, int R, int L, int D, int A,
+                                                                __bf16* __restrict__ xzb) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* s_al = sm;                          // [RN][L]
     float4* s_part = reinterpret_cast<float4*>(sm + ((RN * L + 3) & ~3));   // [16 groups][RN][16 vectors]
@@ -386,6 +398,11 @@ __global__ __launch_bounds__(256) void attention_context_kernel(const float* __r
             if ((lmask >> r) & 1u) be = *reinterpret_cast<const float4*>(hc + orow * hc_ld + A + dd);
             *reinterpret_cast<float4*>(Z + orow * D + dd) = z;
             *reinterpret_cast<float4*>(XZ + orow * D + dd) = make_float4(be.x * z.x, be.y * z.y, be.z * z.z, be.w * z.w);
+            if (xzb) {
+                typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+                b4 o; o[0] = (__bf16)(be.x * z.x); o[1] = (__bf16)(be.y * z.y); o[2] = (__bf16)(be.z * z.z); o[3] = (__bf16)(be.w * z.w);
+                *reinterpret_cast<b4*>(xzb + orow * D + dd) = o;
+            }
         }
     }
 }
@@ -396,12 +413,14 @@ __global__ __launch_bounds__(256) void attention_context_kernel(const float* __r
 __global__ void lstm_cell_fwd_kernel(float* __restrict__ gates, int g_ld, const float* __restrict__ gy,
                                      const float* __restrict__ c_prev, const float* __restrict__ h_prev,
                                      float* __restrict__ c_new, float* __restrict__ h_new,
-                                     const int* __restrict__ lengths, int step, int N, int n) {
+                                     const int* __restrict__ lengths, int step, int N, int n, __bf16* __restrict__ hb_new = nullptr) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)N * n) return;
     int i = (int)(idx / n), j = (int)(idx - (long)i * n);
     if (lengths[i] <= step) {       // finished caption: state is carried unchanged (model.py:544 updates live rows only)
-        c_new[idx] = c_prev[idx]; h_new[idx] = h_prev[idx];
+        const float hp = h_prev[idx];
+        c_new[idx] = c_prev[idx]; h_new[idx] = hp;
+        if (hb_new) hb_new[idx] = (__bf16)hp;
         float* g = gates + (long)i * g_ld;
         g[j] = 0.f; g[n + j] = 0.f; g[2 * n + j] = 0.f; g[3 * n + j] = 0.f;
         return;
@@ -414,7 +433,9 @@ __global__ void lstm_cell_fwd_kernel(float* __restrict__ gates, int g_ld, const 
     float go = fast_sigmoid(g[3 * n + j] + (y ? y[3 * n + j] : 0.f));
     float c = gf * c_prev[idx] + gi * gg;
     c_new[idx] = c;
-    h_new[idx] = go * fast_tanh(c);
+    const float hn = go * fast_tanh(c);
+    h_new[idx] = hn;
+    if (hb_new) hb_new[idx] = (__bf16)hn;          // bf16 copy: operand of the next step's GEMM (bf16 mode)
     g[j] = gi; g[n + j] = gf; g[2 * n + j] = gg; g[3 * n + j] = go;
 }
 
