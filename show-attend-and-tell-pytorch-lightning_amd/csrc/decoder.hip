@@ -17,7 +17,7 @@ struct Ws {
     float *Udrop, *mean_rows, *f_rows, *init_rows, *df_rows;     // only carved when dropout > 0
     float *GU, *DGU, *bup;                                       // stacked LSTM layers (layers > 1): gates, gate grads, bias sums
     __bf16 *Wb_out, *Ub;                                         // bf16 mode: bf16 copies of output.output.weight and of the packed deep-output rows
-    __bf16 *Hb, *XZb, *Wcat_b, *Wz_b;                            // bf16 mode, one LSTM layer: operands of the per-step GEMMs (state, gated context, weights)
+    __bf16 *Hb, *XZb, *Wcat_b, *Wz_b, *DHCb;                            // bf16 mode, one LSTM layer: operands of the per-step GEMMs (state, gated context, weights)
     int* Tok; int* flags;
     int *emb_count, *emb_offset, *emb_cursor, *emb_list;         // embedding gradient: per-row token segments
     float *SC, *DA;                                              // attention: raw scores / score gradients of one step (N, L)
@@ -61,10 +61,11 @@ Ws layout(const sat_decoder_dims& d, char* base) {
     if (d.precision && d.m % 64 == 0 && d.V % 8 == 0) {           // operands of the vocabulary projection for the direct-to-LDS GEMM
         w.Wb_out = (__bf16*)take((size_t)d.V * d.m, 2); w.Ub = (__bf16*)take((size_t)(d.P > 0 ? d.P : 1) * d.m, 2);
     }
-    w.Hb = w.XZb = w.Wcat_b = w.Wz_b = nullptr;
+    w.Hb = w.XZb = w.Wcat_b = w.Wz_b = w.DHCb = nullptr;
     if (d.precision && d.layers == 1 && d.n % 64 == 0 && d.D % 64 == 0 && d.A % 4 == 0 && d.m % 4 == 0) {
         w.Hb = (__bf16*)take((size_t)(T1 + 1) * N * d.n, 2); w.XZb = (__bf16*)take((size_t)N * d.D, 2);
         w.Wcat_b = (__bf16*)take((size_t)HCW * d.n, 2); w.Wz_b = (__bf16*)take((size_t)4 * d.n * d.D, 2);
+        w.DHCb = (__bf16*)take((size_t)N * HCW, 2);
     }
     w.flags = (int*)take((size_t)d.V);
     w.emb_count = (int*)take((size_t)d.V); w.emb_offset = (int*)take((size_t)d.V + 1); w.emb_cursor = (int*)take((size_t)d.V);
@@ -128,6 +129,14 @@ static int gemm_bb_nt(hipStream_t st, const __bf16* A, long lda, const __bf16* B
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.amode = A_ROW; g.bmode = B_ROW; g.epi = epi; g.bias = bias; g.a_bf16 = g.b_bf16 = 1; g.c_bf16 = 0; g.bf16_mfma = 1;
     g.accumulate = acc; g.c0 = c0; g.c1 = c1;
+    return launch_gemm(g, st);
+}
+
+// C (fp32) (+)= A (bf16, rows x K, row stride lda) * B (bf16, K x N k-major): data gradients of the per-step products
+static int gemm_bb_nn(hipStream_t st, const __bf16* A, long lda, const __bf16* B, long ldb, float* C, long ldc, int M, int N, int K, int acc, float* slab, long slab_elems) {
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.amode = A_ROW; g.bmode = B_KMAJOR; g.a_bf16 = g.b_bf16 = 1; g.c_bf16 = 0; g.bf16_mfma = 1; g.accumulate = acc; g.slab = slab; g.slab_elems = slab_elems;
     return launch_gemm(g, st);
 }
 
@@ -214,23 +223,23 @@ int launch_attention_fwd(hipStream_t st, const float* ann, const float* U, const
 template <int RN>
 static int attention_bwd_split_t(hipStream_t st, const float* ann, const float* U, const float* hc, int hc_ld, const float* wf, const int* lengths, int step,
                                  const float* alphas, const float* dalphas, int T1, const float* Zs, const float* dZ_out, const float* dXZ, float* DZ, float* dhc,
-                                 int dhc_ld, float* dU, float* dwf_part, float* da, int B, int R, int L, int D, int A) {
+                                 int dhc_ld, float* dU, float* dwf_part, float* da, int B, int R, int L, int D, int A, __bf16* dhcb) {
     const size_t lds_a = (size_t)RN * D * 4, lds_t = (size_t)(RN * L + RN * ATTB_KCH + 32 * (RN + 1) * ATTB_KCH) * 4;
     SAT_REQUIRE(lds_a <= 160 * 1024 && lds_t <= 160 * 1024, "attention_bwd: L=%d D=%d do not fit the LDS", L, D);
     SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_dalpha_kernel<RN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
     SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_tanh_kernel<RN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
     hipLaunchKernelGGL(attention_bwd_dalpha_kernel<RN>, dim3(B, cdiv(L, 16)), dim3(1024), lds_a, st, ann, hc, hc_ld, lengths, step, dalphas, T1, Zs, dZ_out, dXZ, DZ, dhc,
-                       dhc_ld, da, R, L, D, A);
+                       dhc_ld, da, R, L, D, A, dhcb);
     SAT_TRY(launch_ok("attention_bwd_dalpha"));
     hipLaunchKernelGGL(attention_bwd_tanh_kernel<RN>, dim3(B, cdiv(A, ATTB_KCH)), dim3(1024), lds_t, st, U, hc, hc_ld, wf, lengths, step, alphas, T1, da, dhc, dhc_ld, dU,
-                       dwf_part, R, L, A);
+                       dwf_part, R, L, A, dhcb);
     return launch_ok("attention_bwd_tanh");
 }
 static int attention_bwd_split(int RN, hipStream_t st, const float* ann, const float* U, const float* hc, int hc_ld, const float* wf, const int* lengths, int step,
                                const float* alphas, const float* dalphas, int T1, const float* Zs, const float* dZ_out, const float* dXZ, float* DZ, float* dhc,
-                               int dhc_ld, float* dU, float* dwf_part, float* da, int B, int R, int L, int D, int A) {
-#define SAT_ATTB(RNV) case RNV: return attention_bwd_split_t<RNV>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, dalphas, T1, Zs, dZ_out, dXZ, DZ, dhc, dhc_ld, dU, dwf_part, da, B, R, L, D, A);
-    switch (RN) { SAT_ATTB(1) SAT_ATTB(2) SAT_ATTB(3) SAT_ATTB(4) SAT_ATTB(5) SAT_ATTB(6) SAT_ATTB(7) default: return attention_bwd_split_t<8>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, dalphas, T1, Zs, dZ_out, dXZ, DZ, dhc, dhc_ld, dU, dwf_part, da, B, R, L, D, A); }
+                               int dhc_ld, float* dU, float* dwf_part, float* da, int B, int R, int L, int D, int A, __bf16* dhcb) {
+#define SAT_ATTB(RNV) case RNV: return attention_bwd_split_t<RNV>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, dalphas, T1, Zs, dZ_out, dXZ, DZ, dhc, dhc_ld, dU, dwf_part, da, B, R, L, D, A, dhcb);
+    switch (RN) { SAT_ATTB(1) SAT_ATTB(2) SAT_ATTB(3) SAT_ATTB(4) SAT_ATTB(5) SAT_ATTB(6) SAT_ATTB(7) default: return attention_bwd_split_t<8>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, dalphas, T1, Zs, dZ_out, dXZ, DZ, dhc, dhc_ld, dU, dwf_part, da, B, R, L, D, A, dhcb); }
 #undef SAT_ATTB
 }
 
@@ -457,6 +466,7 @@ int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
     const size_t lds_b = att_bwd_lds(d.L, A, D);
     SAT_REQUIRE(lds_b <= 160 * 1024, "attention_bwd: L=%d A=%d D=%d need %zu B of LDS (> 160 KiB)", d.L, A, D, lds_b);
     static const int att_fused = getenv("SAT_ATT_FUSED") ? atoi(getenv("SAT_ATT_FUSED")) : 0;
+    const bool use_b = w.Hb != nullptr && !att_fused;           // bf16 operand copies (the forward cast the weights into Wcat_b / Wz_b)
     typedef void (*attb_fn)(const float*, const float*, const float*, int, const float*, const int*, int, const float*, const float*, int, const float*,
                             const float*, const float*, float*, float*, int, float*, float*, int, int, int, int);
     attb_fn attb = nullptr;
@@ -478,20 +488,25 @@ int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
             SAT_TRY(gemm(st, A_ROW, B_KMAJOR, dgu, 4 * n, p.up_w_hh[l - 1], n, dHcs(l), n, N, n, 4 * n, 1, EPI_NONE, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, slab, se));
         }
         hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(cdiv((long)N * n, 256)), dim3(256), 0, st, hc + A + D, HCW, Cs(t, 0),
-                           Cs(t + 1, 0), top == 0 ? w.dHout + (long)t * N * n : (const float*)nullptr, dHcs(0), dCcs(0), dhc + A + D, HCW, b.lengths, t, N, n);
+                           Cs(t + 1, 0), top == 0 ? w.dHout + (long)t * N * n : (const float*)nullptr, dHcs(0), dCcs(0), dhc + A + D, HCW, b.lengths, t, N, n,
+                           use_b ? w.DHCb + A + D : (__bf16*)nullptr);
         SAT_TRY(launch_ok("lstm_cell_bwd"));
         // d(beta*z) = dG * W_ih[:, m:]
-        SAT_TRY(gemm(st, A_ROW, B_KMAJOR, dhc + A + D, HCW, p.w_ih + m, m + D, w.dXZ, D, N, D, 4 * n, 0, EPI_NONE, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, slab, se));
+        if (use_b) SAT_TRY(gemm_bb_nn(st, w.DHCb + A + D, HCW, w.Wz_b, D, w.dXZ, D, N, D, 4 * n, 0, slab, se));
+        else SAT_TRY(gemm(st, A_ROW, B_KMAJOR, dhc + A + D, HCW, p.w_ih + m, m + D, w.dXZ, D, N, D, 4 * n, 0, EPI_NONE, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, slab, se));
         if (!att_fused) {
             SAT_TRY(attention_bwd_split(d.R < ATT_RMAX ? d.R : ATT_RMAX, st, b.ann, w.U, hc, HCW, p.att_f, b.lengths, t, alphas, dalphas, T1, w.Z + (long)t * N * D,
-                                        w.dZout + (long)t * N * D, w.dXZ, w.DZ + (long)t * N * D, dhc, HCW, w.dU, w.dwf_part, w.DA, d.B, d.R, d.L, D, A));
+                                        w.dZout + (long)t * N * D, w.dXZ, w.DZ + (long)t * N * D, dhc, HCW, w.dU, w.dwf_part, w.DA, d.B, d.R, d.L, D, A,
+                                        use_b ? w.DHCb : nullptr));
         } else
         hipLaunchKernelGGL(attb, dim3(d.B), dim3(ATTB_THREADS), lds_b, st, b.ann, w.U, hc, HCW, p.att_f, b.lengths, t, alphas,
                            dalphas, T1, w.Z + (long)t * N * D, w.dZout + (long)t * N * D, w.dXZ, w.DZ + (long)t * N * D, dhc, HCW, w.dU, w.dwf_part,
                            d.R, d.L, D, A);
         SAT_TRY(launch_ok("attention_bwd"));
         // dh_{t-1} += [dq | dbeta_pre | dG] * Wcat
-        if (NL == 1) {
+        if (use_b) {
+            SAT_TRY(gemm_bb_nn(st, w.DHCb, HCW, w.Wcat_b, n, w.dHc, n, N, n, HCW, 1, slab, se));
+        } else if (NL == 1) {
             SAT_TRY(gemm(st, A_ROW, B_KMAJOR, dhc, HCW, w.Wcat, n, w.dHc, n, N, n, HCW, 1, EPI_NONE, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, slab, se));
         } else {
             SAT_TRY(gemm(st, A_ROW, B_KMAJOR, dhc, HCW, w.Wcat, n, dHcs(top), n, N, n, A + D, 1, EPI_NONE, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, slab, se));

@@ -446,21 +446,25 @@ __global__ void lstm_cell_bwd_kernel(const float* __restrict__ gates, int g_ld, 
                                      const float* __restrict__ c_new, const float* __restrict__ dh_out,
                                      float* __restrict__ dh_carry, float* __restrict__ dc_carry,
                                      float* __restrict__ dgates, int dg_ld,
-                                     const int* __restrict__ lengths, int step, int N, int n) {
+                                     const int* __restrict__ lengths, int step, int N, int n, __bf16* __restrict__ dgb = nullptr) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)N * n) return;
     int i = (int)(idx / n), j = (int)(idx - (long)i * n);
     float* dg = dgates + (long)i * dg_ld;
-    if (lengths[i] <= step) { dg[j] = 0.f; dg[n + j] = 0.f; dg[2 * n + j] = 0.f; dg[3 * n + j] = 0.f; return; }
+    __bf16* db = dgb ? dgb + (long)i * dg_ld : nullptr;            // bf16 copy with the same row stride (operand of this step's GEMMs)
+    if (lengths[i] <= step) {
+        dg[j] = 0.f; dg[n + j] = 0.f; dg[2 * n + j] = 0.f; dg[3 * n + j] = 0.f;
+        if (db) { db[j] = (__bf16)0.f; db[n + j] = (__bf16)0.f; db[2 * n + j] = (__bf16)0.f; db[3 * n + j] = (__bf16)0.f; }
+        return;
+    }
     const float* g = gates + (long)i * g_ld;
     float gi = g[j], gf = g[n + j], gg = g[2 * n + j], go = g[3 * n + j];
     float dh = dh_carry[idx] + (dh_out ? dh_out[idx] : 0.f);
     float tc = fast_tanh(c_new[idx]);
     float dc = dc_carry[idx] + dh * go * (1.f - tc * tc);
-    dg[j] = dc * gg * gi * (1.f - gi);
-    dg[n + j] = dc * c_prev[idx] * gf * (1.f - gf);
-    dg[2 * n + j] = dc * gi * (1.f - gg * gg);
-    dg[3 * n + j] = dh * tc * go * (1.f - go);
+    const float d0 = dc * gg * gi * (1.f - gi), d1 = dc * c_prev[idx] * gf * (1.f - gf), d2 = dc * gi * (1.f - gg * gg), d3 = dh * tc * go * (1.f - go);
+    dg[j] = d0; dg[n + j] = d1; dg[2 * n + j] = d2; dg[3 * n + j] = d3;
+    if (db) { db[j] = (__bf16)d0; db[n + j] = (__bf16)d1; db[2 * n + j] = (__bf16)d2; db[3 * n + j] = (__bf16)d3; }
     dc_carry[idx] = dc * gf;
     dh_carry[idx] = 0.f;
 }
@@ -594,7 +598,7 @@ template <int RN>
 __global__ __launch_bounds__(1024) void attention_bwd_dalpha_kernel(const float* __restrict__ ann, const float* __restrict__ hc, int hc_ld,
         const int* __restrict__ lengths, int step, const float* __restrict__ dalphas_ext, int T1, const float* __restrict__ Zs,
         const float* __restrict__ dZ_out, const float* __restrict__ dXZ, float* __restrict__ DZ, float* __restrict__ dhc, int dhc_ld,
-        float* __restrict__ da, int R, int L, int D, int A) {
+        float* __restrict__ da, int R, int L, int D, int A, __bf16* __restrict__ dhcb) {
     extern __shared__ __attribute__((aligned(16))) float s_dz[];          // [RN][D]
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l = blockIdx.y * 16 + wave;
@@ -612,7 +616,7 @@ __global__ __launch_bounds__(1024) void attention_bwd_dalpha_kernel(const float*
                 dbp = dx * z * beta * (1.f - beta);
             }
             s_dz[e] = dz;
-            if (blockIdx.y == 0 && r < rn) { DZ[row * D + d] = dz; dhc[row * dhc_ld + A + d] = dbp; }
+            if (blockIdx.y == 0 && r < rn) { DZ[row * D + d] = dz; dhc[row * dhc_ld + A + d] = dbp; if (dhcb) dhcb[row * dhc_ld + A + d] = (__bf16)dbp; }
         }
         __syncthreads();
         if (l < L) {
@@ -639,7 +643,7 @@ constexpr int ATTB_KCH = 32;
 template <int RN>
 __global__ __launch_bounds__(1024) void attention_bwd_tanh_kernel(const float* __restrict__ U, const float* __restrict__ hc, int hc_ld, const float* __restrict__ wf,
         const int* __restrict__ lengths, int step, const float* __restrict__ alphas, int T1, const float* __restrict__ da, float* __restrict__ dhc,
-        int dhc_ld, float* __restrict__ dU, float* __restrict__ dwf_part, int R, int L, int A) {
+        int dhc_ld, float* __restrict__ dU, float* __restrict__ dwf_part, int R, int L, int A, __bf16* __restrict__ dhcb) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* s_ds = sm;                               // [RN][L]
     float* s_q = s_ds + RN * L;                     // [RN][KCH]
@@ -695,7 +699,7 @@ __global__ __launch_bounds__(1024) void attention_bwd_tanh_kernel(const float* _
             float sacc = 0.f;
             for (int g2 = 0; g2 < 32; ++g2) sacc += s_red[(g2 * (RN + 1) + r) * ATTB_KCH + k2];
             if (kg < A) {
-                if (r < RN) { if (r < rn) dhc[(long)(i0 + r) * dhc_ld + kg] = sacc; }
+                if (r < RN) { if (r < rn) { dhc[(long)(i0 + r) * dhc_ld + kg] = sacc; if (dhcb) dhcb[(long)(i0 + r) * dhc_ld + kg] = (__bf16)sacc; } }
                 else s_q[k2] = sacc;                 // dw of this pass (s_q is free until the next pass reloads it)
             }
         }
