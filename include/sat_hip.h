@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SAT_HIP_ABI_VERSION 10
+#define SAT_HIP_ABI_VERSION 11
 
 int sat_abi_version(void);
 const char* sat_last_error(void);
@@ -301,6 +301,29 @@ int sat_grad_clip_coef(const sat_opt_tensor* tensors, const sat_opt_chunk* chunk
 /* p, m, v updated in place from g * clip_coef[0] (clip_coef NULL = 1) */
 int sat_optimizer_step(const sat_opt_tensor* tensors, const sat_opt_chunk* chunks, int32_t n_chunks, const sat_opt_hyper* hyper,
                        const float* clip_coef, void* stream);
+
+/* ---- input pipeline on device ------------------------------------------------------------------------
+ * Replaces, per batch, the per-sample PIL / torchvision chain of train.py:208-233: T.RandomResizedCrop | T.Resize +
+ * T.CenterCrop (Pillow's antialiased BILINEAR Image.resize, bit exact), T.RandomHorizontalFlip, T.ToTensor, and
+ * util.py:121-130 AddGaussianNoise.  Input: the decoded pictures of one batch, uint8 RGB (height, width, 3), concatenated
+ * in one device buffer; one descriptor per picture (the random draws are the caller's: torch RNG on the host).
+ * Output: (n, 3, out_h, out_w) fp32 in [0, 1] (+ noise * std) - the `img` of the reference's batch (util.py:40-45).      */
+typedef struct sat_image_desc {
+    int64_t offset;                                    /* byte offset of the picture in `pixels`                        */
+    int32_t height, width;
+    int32_t crop_top, crop_left, crop_h, crop_w;       /* box cut out first (PIL crop)                                  */
+    int32_t resized_h, resized_w;                      /* size the box is resampled to (PIL resize, BILINEAR)           */
+    int32_t out_top, out_left;                         /* (out_h, out_w) window of the resampled picture (T.CenterCrop) */
+    int32_t flip;                                      /* mirror left-right                                             */
+    int32_t reserved;
+} sat_image_desc;
+size_t sat_image_batch_workspace_bytes(const sat_image_desc* desc_host, int32_t n, int32_t out_h, int32_t out_w);
+/* desc_host / desc_dev: the same n descriptors in host memory (validated, sizes the launch) and in device memory (read by
+ * the kernels).  noise: (n, 3, out_h, out_w) standard normal draws or NULL.  out_u8 (optional): the (n, out_h, out_w, 3)
+ * bytes before ToTensor, i.e. what PIL would hold.  At least one of out_nchw / out_u8.  pixels_bytes bounds the offsets. */
+int sat_image_batch_transform(const uint8_t* pixels, int64_t pixels_bytes, const sat_image_desc* desc_host, const sat_image_desc* desc_dev,
+                              int32_t n, int32_t out_h, int32_t out_w, const float* noise, float noise_std, float* out_nchw,
+                              uint8_t* out_u8, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

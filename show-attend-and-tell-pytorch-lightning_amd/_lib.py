@@ -72,6 +72,11 @@ class OptHyper(C.Structure):
                 ("clip_value", C.c_float)]
 
 
+class ImageDesc(C.Structure):
+    _fields_ = [("offset", C.c_int64)] + [(k, C.c_int32) for k in ("height", "width", "crop_top", "crop_left", "crop_h", "crop_w", "resized_h",
+                                                                  "resized_w", "out_top", "out_left", "flip", "reserved")]
+
+
 class DecoderBatch(C.Structure):
     _fields_ = [("ann", C.c_void_p), ("caps", C.c_void_p), ("lengths", C.c_void_p), ("prow", C.c_void_p), ("src_row", C.c_void_p),
                 ("step_offsets_host", C.c_void_p), ("teacher_host", C.c_void_p)]
@@ -164,6 +169,8 @@ SYMBOLS.update({
 SYMBOLS.update({"sat_optimizer_chunk_elems": (C.c_int32, []),
                 "sat_grad_clip_coef": (C.c_int, [_vp, _vp, _i32, _f, _vp, _vp, _vp]),
                 "sat_optimizer_step": (C.c_int, [_vp, _vp, _i32, C.POINTER(OptHyper), _vp, _vp])})
+SYMBOLS.update({"sat_image_batch_workspace_bytes": (C.c_size_t, [_vp, _i32, _i32, _i32]),
+                "sat_image_batch_transform": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _f, _vp, _vp, _vp, C.c_size_t, _vp])})
 SYMBOLS.update({"sat_profile_start": (C.c_int, []),
                 "sat_profile_stop": (C.c_int, [C.POINTER(ProfileEntry), _i32, C.POINTER(C.c_int32)])})
 
@@ -195,8 +202,8 @@ def lib():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(handle, name)          # AttributeError if the export is missing
             fn.restype, fn.argtypes = res, args
-        if handle.sat_abi_version() != 10:
-            raise SatHipError("libsat_hip.so ABI version %d != 10 (rebuild: make -C csrc)" % handle.sat_abi_version())
+        if handle.sat_abi_version() != 11:
+            raise SatHipError("libsat_hip.so ABI version %d != 11 (rebuild: make -C csrc)" % handle.sat_abi_version())
         _lib = handle
     return _lib
 

@@ -256,6 +256,51 @@ def g10():
         arrs[name + "_token_bleu"] = np.array([float(mod.token_bleu(refs, caps, list(w))) for w in weights])
     save("g10_metrics", **arrs)
 
+# ---------------------------------------------------------------- G11 (input pipeline)
+def g11():
+    """Pillow's BILINEAR ``Image.resize`` (what torchvision's Resize / RandomResizedCrop call on PIL images, train.py:208-218)
+    on seeded byte images, and the reference's own util.py helpers: BucketSampler order under np.random.seed (util.py:48-84),
+    AddGaussianNoise under torch.manual_seed (util.py:121-130), crop_max_square (util.py:154-164)."""
+    from PIL import Image
+    import util as ref_util       # the reference's util.py (already imported by its model.py through ref_shim)
+    rng = np.random.default_rng(1100)
+    arrs = {}
+    cases = [(37, 53, 16, 16), (48, 64, 24, 24), (50, 40, 64, 64), (61, 97, 32, 48), (32, 32, 32, 32), (100, 7, 9, 30), (5, 5, 17, 3), (120, 160, 56, 56)]
+    arrs["resize_cases"] = np.array(cases, np.int64)
+    for i, (h, w, oh, ow) in enumerate(cases):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        if i == 7:      # a smooth picture: neighbouring pixels correlated like a photograph
+            yy, xx = np.mgrid[0:h, 0:w]
+            img = np.stack([yy * 255 // (h - 1), xx * 255 // (w - 1), (yy * 3 + xx * 2) % 256], -1).astype(np.uint8)
+        arrs["resize_in%d" % i] = img
+        arrs["resize_out%d" % i] = np.asarray(Image.fromarray(img).resize((ow, oh), Image.BILINEAR))
+    # crop then resize, as torchvision's resized_crop does on a PIL image
+    img = rng.integers(0, 256, (90, 120, 3), dtype=np.uint8)
+    boxes = [(3, 5, 80, 100), (0, 0, 90, 120), (10, 60, 33, 47)]
+    arrs["crop_in"], arrs["crop_boxes"] = img, np.array(boxes, np.int64)
+    for i, (t, l, h, w) in enumerate(boxes):
+        arrs["crop_out%d" % i] = np.asarray(Image.fromarray(img).crop((l, t, l + w, t + h)).resize((28, 28), Image.BILINEAR))
+    # crop_max_square (util.py:154-164; its resize uses Pillow's default filter for Image.resize = BICUBIC, not restated: size=None only)
+    for i, (h, w) in enumerate([(30, 41), (41, 30), (17, 17)]):
+        im = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        arrs["square_in%d" % i] = im
+        arrs["square_out%d" % i] = np.asarray(ref_util.crop_max_square(Image.fromarray(im), None))
+    # BucketSampler
+    rs = np.random.RandomState(5)
+    lengths = [[int(v) for v in rs.randint(3, 9, size=3)] for _ in range(57)]
+    arrs["bucket_lengths"] = np.array(lengths, np.int64)
+    sampler = ref_util.BucketSampler(lengths, 8)
+    np.random.seed(77)
+    arrs["bucket_epoch0"] = np.array(list(iter(sampler)), np.int64)
+    arrs["bucket_epoch1"] = np.array(list(iter(sampler)), np.int64)      # groups stay shuffled in place between epochs
+    arrs["bucket_len"] = np.int64(len(sampler))
+    # AddGaussianNoise
+    x = torch.from_numpy(rng.random((3, 6, 5), dtype=np.float32))
+    torch.manual_seed(9)
+    arrs["noise_in"], arrs["noise_out"] = x.numpy(), ref_util.AddGaussianNoise(std=0.01)(x).numpy()
+    save("g11_input_pipeline", **arrs)
+
+
 # ---------------------------------------------------------------- G8 (C1 decoder shapes)
 def g8():
     hp = O.default_hparams(vocab_size=6400, encoder_dim=256, embed_dim=256, attention_dim=128, decoder_dim=512, input_size=64)
@@ -314,4 +359,4 @@ if __name__ == "__main__":
     g4("layers2", 1.0, 46, decoder_layers=2)
     g4("embnorm", 1.0, 47, embed_norm=0.3)
     g4("gamma", 0.0, 48, att_gamma=0.5, B=4, R=3, T=9, H=3, W=3)
-    g6(); g7(); g8(); g9(); g10(); g_encoder()
+    g6(); g7(); g8(); g9(); g10(); g11(); g_encoder()
