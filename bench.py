@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--ragged", action="store_true", help="lengths ~ U{8..T-1} instead of all T-1")
+    ap.add_argument("--decoder-tf", default="always", choices=["always", "none"],
+                    help="teacher forcing: always (epsilon = 1, the headline) or none (train.py:63 default: argmax feedback after step 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=None, help="override images per GPU")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
@@ -148,6 +150,8 @@ def main():
     hp, T, B, R = hparams(args.config)
     if args.batch:
         B = args.batch
+    if args.decoder_tf == "none":
+        hp["decoder_tf"] = None
     torch.manual_seed(42)
     model = M.SAT(**hp).to(dev).train()
     model.set_precision(args.precision)
@@ -240,9 +244,9 @@ def main():
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_steps_run": warm_done, "ms_per_step": round(ms, 3), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
                 "config": {"workload": "%s: %s encoder_size=%s encoder_dim=%d vocab=%d T=%d, %d images/GPU x R=%d captions, "
-                                       "trainable encoder, Adam, %s lengths" % (args.config.upper(), CONFIGS[args.config][0],
+                                       "trainable encoder, Adam, %s lengths, decoder_tf=%s" % (args.config.upper(), CONFIGS[args.config][0],
                                                                                CONFIGS[args.config][1], CONFIGS[args.config][2],
-                                                                               hp["vocab_size"], T, B, R, "ragged" if args.ragged else "full"),
+                                                                               hp["vocab_size"], T, B, R, "ragged" if args.ragged else "full", args.decoder_tf),
                            "global_batch_images": world * B, "captions_per_step": world * B * R, "parallelism": "dp%d" % world,
                            "images_per_s": round(world * B / (dt / args.steps), 1), "final_loss": round(loss_val, 4)},
                 "roofline": roof}

@@ -264,6 +264,34 @@ __global__ void bn_fwd_finalize_kernel(const double* __restrict__ part0, const d
         }
     }
 }
+// Few row tiles (the 16x16 and 8x8 stages): tile reduce and finalize in ONE launch - block = 32 channels x 8 tile lanes, the
+// lanes' double sums combined in a fixed order, then the channel's thread writes mean / invstd / running statistics.
+__global__ __launch_bounds__(256) void bn_tile_finalize_kernel(const float* __restrict__ tiles, int ntiles, int C, long rows, float eps, float momentum,
+                                                               float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ running_mean,
+                                                               float* __restrict__ running_var) {
+    __shared__ double sh[2][8][32];
+    const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int t = pl; t < ntiles; t += 8) { const float2 v = reinterpret_cast<const float2*>(tiles)[(long)t * C + c]; s += (double)v.x; q += (double)v.y; }
+    sh[0][pl][cl] = s; sh[1][pl][cl] = q;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+        double ss = 0.0, qq = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { ss += sh[0][k][cl]; qq += sh[1][k][cl]; }
+        const double n = (double)rows;
+        double var = (qq - ss * ss / n) / n; if (var < 0.0) var = 0.0;
+        const double mu = ss / n;
+        mean[c] = (float)mu;
+        invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (running_mean) {
+            const double unb = rows > 1 ? var * n / (n - 1.0) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+        }
+    }
+}
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part0, const double* __restrict__ part1, int nparts, int C,
                                        float* __restrict__ dbeta, float* __restrict__ dgamma) {
     const int lane = threadIdx.x & 63, c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -399,6 +427,64 @@ __global__ void maxpool3x3s2_bwd_kernel(const T* __restrict__ dy, const unsigned
         }
     }
     st4<T>(dx, e, acc);
+}
+
+// 16 bytes per lane (E = 4 fp32 / 8 bf16 channels): the forms the ResNet stem takes (C = 64).  Same arithmetic as above.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool3x3s2_fwd_v_kernel(const T* __restrict__ x, T* __restrict__ y, unsigned char* __restrict__ amax,
+                                                                 int H, int W, int CV, int P, int Q, long totalv) {
+    constexpr int E = EPT<T>::n;
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= totalv) return;
+    int cv = (int)(e % CV); long t = e / CV; int q = (int)(t % Q); t /= Q; int p = (int)(t % P); long n = t / P;
+    float best[E]; unsigned bk[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) { best[i] = -INFINITY; bk[i] = 0; }
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int h = p * 2 - 1 + kh; if ((unsigned)h >= (unsigned)H) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int w = q * 2 - 1 + kw; if ((unsigned)w >= (unsigned)W) continue;
+            float v[E];
+            unpack<T, E>(reinterpret_cast<const uint4*>(x)[((n * H + h) * W + w) * CV + cv], v);
+            const unsigned k = kh * 3 + kw;
+#pragma unroll
+            for (int i = 0; i < E; ++i) if (v[i] > best[i]) { best[i] = v[i]; bk[i] = k; }
+        }
+    }
+    reinterpret_cast<uint4*>(y)[e] = pack<T, E>(best);
+    if (E == 8) reinterpret_cast<uint2*>(amax)[e] = make_uint2(bk[0] | (bk[1] << 8) | (bk[2] << 16) | (bk[3] << 24), bk[4 % E] | (bk[5 % E] << 8) | (bk[6 % E] << 16) | (bk[7 % E] << 24));
+    else reinterpret_cast<unsigned*>(amax)[e] = bk[0] | (bk[1] << 8) | (bk[2] << 16) | (bk[3] << 24);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_v_kernel(const T* __restrict__ dy, const unsigned char* __restrict__ amax, T* __restrict__ dx,
+                                                                 int H, int W, int CV, int P, int Q, long totalv) {
+    constexpr int E = EPT<T>::n;
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= totalv) return;
+    int cv = (int)(e % CV); long t = e / CV; int w = (int)(t % W); t /= W; int h = (int)(t % H); long n = t / H;
+    float acc[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int ph = h + 1 - kh; if (ph < 0 || (ph & 1)) continue; const int p = ph >> 1; if (p >= P) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int pw = w + 1 - kw; if (pw < 0 || (pw & 1)) continue; const int q = pw >> 1; if (q >= Q) continue;
+            const long o = ((n * P + p) * Q + q) * CV + cv;
+            unsigned a0, a1 = 0;
+            if (E == 8) { const uint2 a = reinterpret_cast<const uint2*>(amax)[o]; a0 = a.x; a1 = a.y; }
+            else a0 = reinterpret_cast<const unsigned*>(amax)[o];
+            float g[E];
+            unpack<T, E>(reinterpret_cast<const uint4*>(dy)[o], g);
+            const unsigned k = kh * 3 + kw;
+#pragma unroll
+            for (int i = 0; i < E; ++i) { const unsigned a = ((i < 4 ? a0 : a1) >> ((i & 3) * 8)) & 0xffu; if (a == k) acc[i] += g[i]; }
+        }
+    }
+    reinterpret_cast<uint4*>(dx)[e] = pack<T, E>(acc);
 }
 
 // ------------------------------------------------------------------ encoder_size resize on the final map (readme.md:118-121)
@@ -622,6 +708,16 @@ static int bn_train_fwd_t(const T* x, int64_t rows, int32_t C, const float* gamm
     if (tile_stats) {        // statistics came out of the convolution's epilogue: combine the row tiles, no pass over x
         SAT_REQUIRE(tile_rows > 0, "bn_train_fwd: tile_rows=%d", tile_rows);
         const int ntiles = (int)cdiv(rows, (long)tile_rows);
+        static const int fuse_upto = getenv("SAT_BN_FUSE_TILES") ? atoi(getenv("SAT_BN_FUSE_TILES")) : 256;
+        if (ntiles <= fuse_upto) {
+            hipLaunchKernelGGL(bn_tile_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, tile_stats, ntiles, C, (long)rows, eps, momentum, save_mean, save_invstd,
+                               running_mean, running_var);
+            SAT_TRY(launch_ok("bn_tile_finalize"));
+            long totalv = rows * (C / E);
+            ProfScope prof("bn_apply_fwd", 0.0, (double)rows * C * (sizeof(T) * (residual ? 3 : 2) + (relu_mask ? 0.125 : 0.0)), st);
+            hipLaunchKernelGGL((bn_apply_kernel<T, false>), dim3(cdiv(totalv, 256)), dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta, residual, relu, y, relu_mask, totalv, C / E, -1.0f);
+            return launch_ok("bn_apply");
+        }
         int np = cdiv(ntiles, 64); if (np > nparts) np = nparts; if (np < 1) np = 1;          // partials fit the scratch sized for nparts
         const int per = cdiv(ntiles, np); np = cdiv(ntiles, per);
         p1 = p0 + (long)np * C;
@@ -686,6 +782,12 @@ static int maxpool_fwd_t(const T* x, T* y, uint8_t* argmax, int32_t N, int32_t H
     SAT_REQUIRE(C % 4 == 0, "maxpool: C must be a multiple of 4");
     int P = (H + 2 - 3) / 2 + 1, Q = (W + 2 - 3) / 2 + 1;
     long total4 = (long)N * P * Q * (C / 4);
+    constexpr int E = EPT<T>::n;
+    if (C % E == 0) {
+        const long totalv = total4 * 4 / E;
+        hipLaunchKernelGGL(maxpool3x3s2_fwd_v_kernel<T>, dim3(cdiv(totalv, 256)), dim3(256), 0, st, x, y, argmax, H, W, C / E, P, Q, totalv);
+        return launch_ok("maxpool_fwd");
+    }
     hipLaunchKernelGGL(maxpool3x3s2_fwd_kernel<T>, dim3(cdiv(total4, 256)), dim3(256), 0, st, x, y, argmax, H, W, C / 4, P, Q, total4);
     return launch_ok("maxpool_fwd");
 }
@@ -695,6 +797,12 @@ static int maxpool_bwd_t(const T* dy, const uint8_t* argmax, T* dx, int32_t N, i
     SAT_REQUIRE(C % 4 == 0, "maxpool: C must be a multiple of 4");
     int P = (H + 2 - 3) / 2 + 1, Q = (W + 2 - 3) / 2 + 1;
     long total4 = (long)N * H * W * (C / 4);
+    constexpr int E = EPT<T>::n;
+    if (C % E == 0) {
+        const long totalv = total4 * 4 / E;
+        hipLaunchKernelGGL(maxpool3x3s2_bwd_v_kernel<T>, dim3(cdiv(totalv, 256)), dim3(256), 0, st, dy, argmax, dx, H, W, C / E, P, Q, totalv);
+        return launch_ok("maxpool_bwd");
+    }
     hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel<T>, dim3(cdiv(total4, 256)), dim3(256), 0, st, dy, argmax, dx, H, W, C / 4, P, Q, total4);
     return launch_ok("maxpool_bwd");
 }
