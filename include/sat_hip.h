@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SAT_HIP_ABI_VERSION 11
+#define SAT_HIP_ABI_VERSION 12
 
 int sat_abi_version(void);
 const char* sat_last_error(void);
@@ -220,6 +220,15 @@ int sat_bn_train_fwd_tiles_bf16(const void* x, int64_t rows, int32_t C, const fl
                                 float* save_invstd, const void* residual, int32_t relu, void* y, uint8_t* relu_mask, float* scratch, void* stream);
 int sat_conv2d_dgrad_bf16(const void* dy, const void* w, void* dx, const sat_conv_geom* g, int32_t accumulate, void* stream);
 int sat_conv2d_wgrad_bf16(const void* dy, const void* x, float* dw, const sat_conv_geom* g, float* slab, int64_t slab_elems, void* stream);
+/* ResNet stem tail in one pass (model.py:19-29 keeps torchvision's bn1 -> relu -> maxpool): BatchNorm(train statistics already in
+ * mean / invstd: sat_bn_train_fwd_t with y = NULL computes them and updates the running statistics) + ReLU + MaxPool2d(3, 2, 1)
+ * of the NHWC convolution output x (N, H, W, C) -> y_pool (N, P, Q, C), argmax (same shape, bytes: window position of the first
+ * maximum).  The backward takes the pooled gradient and returns dx, dgamma, dbeta; the full-size BatchNorm output, its sign
+ * mask and the dense pre-pool gradient are never materialised.  scratch: sat_bn_scratch_bytes(N * H * W, C). */
+int sat_stem_tail_fwd_t(int32_t dtype, const void* x, int32_t N, int32_t H, int32_t W, int32_t C, const float* mean, const float* invstd, const float* gamma,
+                        const float* beta, void* y_pool, uint8_t* argmax, void* stream);
+int sat_stem_tail_bwd_t(int32_t dtype, const void* dy_pool, const uint8_t* argmax, const void* x, int32_t N, int32_t H, int32_t W, int32_t C, const float* mean,
+                        const float* invstd, const float* gamma, const float* beta, void* dx, float* dgamma, float* dbeta, float* scratch, void* stream);
 /* torchvision Normalize(mean, std) (model.py:59) fused with NCHW -> NHWC and 3 -> 4 channel padding */
 int sat_image_normalize_nhwc4(const float* img_nchw, float* out_nhwc4, int32_t N, int32_t H, int32_t W,
                               const float* mean3_host, const float* std3_host, void* stream);

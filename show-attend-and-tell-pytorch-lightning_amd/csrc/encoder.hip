@@ -434,9 +434,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void maxpool3x3s2_fwd_v_kernel(const T* __restrict__ x, T* __restrict__ y, unsigned char* __restrict__ amax,
                                                                  int H, int W, int CV, int P, int Q, long totalv) {
     constexpr int E = EPT<T>::n;
-    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned e = blockIdx.x * 256u + threadIdx.x;             // 32-bit index math (the launcher checks totalv < 2^31): 64-bit divisions cost more than the loads
     if (e >= totalv) return;
-    int cv = (int)(e % CV); long t = e / CV; int q = (int)(t % Q); t /= Q; int p = (int)(t % P); long n = t / P;
+    const unsigned cv = e % CV; unsigned t = e / CV; const int q = (int)(t % Q); t /= Q; const int p = (int)(t % P); const long n = t / P;
     float best[E]; unsigned bk[E];
 #pragma unroll
     for (int i = 0; i < E; ++i) { best[i] = -INFINITY; bk[i] = 0; }
@@ -461,9 +461,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_v_kernel(const T* __restrict__ dy, const unsigned char* __restrict__ amax, T* __restrict__ dx,
                                                                  int H, int W, int CV, int P, int Q, long totalv) {
     constexpr int E = EPT<T>::n;
-    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned e = blockIdx.x * 256u + threadIdx.x;
     if (e >= totalv) return;
-    int cv = (int)(e % CV); long t = e / CV; int w = (int)(t % W); t /= W; int h = (int)(t % H); long n = t / H;
+    const unsigned cv = e % CV; unsigned t = e / CV; const int w = (int)(t % W); t /= W; const int h = (int)(t % H); const long n = t / H;
     float acc[E];
 #pragma unroll
     for (int i = 0; i < E; ++i) acc[i] = 0.f;
@@ -485,6 +485,186 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_v_kernel(const T* __rest
         }
     }
     reinterpret_cast<uint4*>(dx)[e] = pack<T, E>(acc);
+}
+
+// ------------------------------------------------------------------ ResNet stem tail in one pass: BatchNorm + ReLU + max pool
+// The stem's BatchNorm output (N x 128 x 128 x 64 at 256 px: the largest activation of the network) is only ever read by the
+// max pool.  Forward: normalise + ReLU the 3x3 window on the fly and keep the pooled map and the argmax; the full-size
+// activation and its sign mask are never written.  Backward: the pooled gradient is gathered through the argmax and the ReLU
+// sign recomputed from the convolution output (v > 0 for v = (x - mean) * invstd * gamma + beta, the forward's own test), so
+// the dense pre-pool gradient is never materialised either.  Values and the first-maximum rule are those of bn_apply_kernel
+// followed by maxpool3x3s2_fwd_kernel (the comparison runs on the values rounded to the storage type, as there).
+template <typename T> __device__ __forceinline__ float round_to(float v);
+template <> __device__ __forceinline__ float round_to<float>(float v) { return v; }
+template <> __device__ __forceinline__ float round_to<__bf16>(float v) { return (float)(__bf16)v; }
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ y,
+                                                                  unsigned char* __restrict__ amax, int H, int W, int CV, int P, int Q, long totalv) {
+    constexpr int E = EPT<T>::n;
+    const unsigned e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= totalv) return;
+    const unsigned cv = e % CV; unsigned t = e / CV; const int q = (int)(t % Q); t /= Q; const int p = (int)(t % P); const long n = t / P;
+    float mu[E], is[E], ga[E], be[E], best[E]; unsigned bk[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) { mu[i] = mean[cv * E + i]; is[i] = invstd[cv * E + i]; ga[i] = gamma[cv * E + i]; be[i] = beta[cv * E + i]; best[i] = -INFINITY; bk[i] = 0; }
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int h = p * 2 - 1 + kh; if ((unsigned)h >= (unsigned)H) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int w = q * 2 - 1 + kw; if ((unsigned)w >= (unsigned)W) continue;
+            float xv[E];
+            unpack<T, E>(reinterpret_cast<const uint4*>(x)[((n * H + h) * W + w) * CV + cv], xv);
+            const unsigned k = kh * 3 + kw;
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                const float v = round_to<T>(fmaxf((xv[i] - mu[i]) * is[i] * ga[i] + be[i], 0.f));
+                if (v > best[i]) { best[i] = v; bk[i] = k; }
+            }
+        }
+    }
+    reinterpret_cast<uint4*>(y)[e] = pack<T, E>(best);
+    if (E == 8) reinterpret_cast<uint2*>(amax)[e] = make_uint2(bk[0] | (bk[1] << 8) | (bk[2] << 16) | (bk[3] << 24), bk[4 % E] | (bk[5 % E] << 8) | (bk[6 % E] << 16) | (bk[7 % E] << 24));
+    else reinterpret_cast<unsigned*>(amax)[e] = bk[0] | (bk[1] << 8) | (bk[2] << 16) | (bk[3] << 24);
+}
+
+// Backward, by 2x2 blocks of pre-pool positions: block (p, q) = rows 2p, 2p+1 x columns 2q, 2q+1 is reached by exactly the four
+// windows (p, q), (p, q+1), (p+1, q), (p+1, q+1) - eight loads for four positions, no lane divergence (a per-position gather
+// walks nine window candidates under divergent parity tests).  The contributions are added in maxpool3x3s2_bwd's order, the sum
+// is rounded to the storage type where the separate path stores it, and the ReLU sign is recomputed from x.
+template <typename T, int E>
+struct StemWin { float d[E]; unsigned a0, a1; };
+template <typename T, int E>
+__device__ __forceinline__ void stem_load_win(const T* __restrict__ dy, const unsigned char* __restrict__ amax, long n, int p, int q, int cv, int CV, int P, int Q,
+                                              StemWin<T, E>& w) {
+    if (p < P && q < Q) {
+        const long o = ((n * P + p) * Q + q) * CV + cv;
+        if (E == 8) { const uint2 a = reinterpret_cast<const uint2*>(amax)[o]; w.a0 = a.x; w.a1 = a.y; }
+        else { w.a0 = reinterpret_cast<const unsigned*>(amax)[o]; w.a1 = 0; }
+        unpack<T, E>(reinterpret_cast<const uint4*>(dy)[o], w.d);
+    } else {
+        w.a0 = w.a1 = 0xffffffffu;                   // no window position is 255: contributes nothing
+#pragma unroll
+        for (int i = 0; i < E; ++i) w.d[i] = 0.f;
+    }
+}
+template <typename T, int E>
+__device__ __forceinline__ float stem_pick(const StemWin<T, E>& w, int i, unsigned k) {
+    const unsigned a = ((i < 4 ? w.a0 : w.a1) >> ((i & 3) * 8)) & 0xffu;
+    return a == k ? w.d[i] : 0.f;
+}
+// g of the block's position (dh, dw) in {0,1}^2; w00 = window (p, q), w01 = (p, q+1), w10 = (p+1, q), w11 = (p+1, q+1)
+template <typename T, int E>
+__device__ __forceinline__ void stem_block_grad(int dh, int dw, const StemWin<T, E>& w00, const StemWin<T, E>& w01, const StemWin<T, E>& w10, const StemWin<T, E>& w11,
+                                                const float (&xv)[E], const float (&mu)[E], const float (&is)[E], const float (&ga)[E], const float (&be)[E], float (&g)[E]) {
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        float s = 0.f;
+        if (!dh && !dw) s += stem_pick<T, E>(w00, i, 4);
+        else if (!dh) { s += stem_pick<T, E>(w01, i, 3); s += stem_pick<T, E>(w00, i, 5); }
+        else if (!dw) { s += stem_pick<T, E>(w10, i, 1); s += stem_pick<T, E>(w00, i, 7); }
+        else { s += stem_pick<T, E>(w11, i, 0); s += stem_pick<T, E>(w10, i, 2); s += stem_pick<T, E>(w01, i, 6); s += stem_pick<T, E>(w00, i, 8); }
+        s = round_to<T>(s);
+        g[i] = ((xv[i] - mu[i]) * is[i] * ga[i] + be[i] > 0.f) ? s : 0.f;
+    }
+}
+
+// per-channel sums of g and g * xhat over a slice of the 2x2 blocks -> the partial layout of bn_colstats_kernel<1>
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_stats_kernel(const T* __restrict__ x, const T* __restrict__ dy, const unsigned char* __restrict__ amax,
+                                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                        const float* __restrict__ gamma, const float* __restrict__ beta, int H, int W, int P, int Q,
+                                                                        long blocks, int C, int CV, long blocks_per, double* __restrict__ part0, double* __restrict__ part1) {
+    constexpr int E = EPT<T>::n;
+    __shared__ double sh[2][256][E > 4 ? 4 : E];
+    const int tid = threadIdx.x, tc = tid % CV, tr = tid / CV, RL = 256 / CV;
+    const int cv = blockIdx.x * CV + tc, CVT = C / E;
+    double a0[E], a1[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) { a0[i] = 0.0; a1[i] = 0.0; }
+    if (cv < CVT && tr < RL) {
+        float mu[E], is[E], ga[E], be[E];
+#pragma unroll
+        for (int i = 0; i < E; ++i) { mu[i] = mean[cv * E + i]; is[i] = invstd[cv * E + i]; ga[i] = gamma[cv * E + i]; be[i] = beta[cv * E + i]; }
+        long r0 = (long)blockIdx.y * blocks_per, r1 = r0 + blocks_per; if (r1 > blocks) r1 = blocks;
+        for (long r = r0 + tr; r < r1; r += RL) {
+            const unsigned ru = (unsigned)r; const int q = (int)(ru % Q); const unsigned t = ru / Q; const int p = (int)(t % P); const long n = t / P;
+            StemWin<T, E> w00, w01, w10, w11;
+            stem_load_win<T, E>(dy, amax, n, p, q, cv, CVT, P, Q, w00); stem_load_win<T, E>(dy, amax, n, p, q + 1, cv, CVT, P, Q, w01);
+            stem_load_win<T, E>(dy, amax, n, p + 1, q, cv, CVT, P, Q, w10); stem_load_win<T, E>(dy, amax, n, p + 1, q + 1, cv, CVT, P, Q, w11);
+            float s0[E], s1[E];
+#pragma unroll
+            for (int i = 0; i < E; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+                for (int dw = 0; dw < 2; ++dw) {
+                    const int h = 2 * p + dh, w = 2 * q + dw;
+                    if (h >= H || w >= W) continue;
+                    float xv[E], g[E];
+                    unpack<T, E>(reinterpret_cast<const uint4*>(x)[((n * H + h) * W + w) * CVT + cv], xv);
+                    stem_block_grad<T, E>(dh, dw, w00, w01, w10, w11, xv, mu, is, ga, be, g);
+#pragma unroll
+                    for (int i = 0; i < E; ++i) { s0[i] += g[i]; s1[i] = fmaf(g[i], (xv[i] - mu[i]) * is[i], s1[i]); }       // four terms in fp32, the blocks in double
+                }
+#pragma unroll
+            for (int i = 0; i < E; ++i) { a0[i] += (double)s0[i]; a1[i] += (double)s1[i]; }
+        }
+    }
+#pragma unroll
+    for (int hh = 0; hh < E; hh += 4) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sh[0][tid][i] = a0[hh + i]; sh[1][tid][i] = a1[hh + i]; }
+        __syncthreads();
+        if (tr == 0 && cv < CVT) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                double s0 = 0.0, s1 = 0.0;
+                for (int k = 0; k < RL; ++k) { s0 += sh[0][k * CV + tc][i]; s1 += sh[1][k * CV + tc][i]; }
+                part0[(long)blockIdx.y * C + cv * E + hh + i] = s0;
+                part1[(long)blockIdx.y * C + cv * E + hh + i] = s1;
+            }
+        }
+    }
+}
+// dx = gamma * invstd * (g - dbeta/M - xhat * dgamma/M), one thread per 2x2 block and vector column
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const unsigned char* __restrict__ amax,
+                                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                        const float* __restrict__ dbeta, const float* __restrict__ dgamma, float inv_rows,
+                                                                        T* __restrict__ dx, int H, int W, int P, int Q, long totalb, int CV) {
+    constexpr int E = EPT<T>::n;
+    const unsigned e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= totalb) return;
+    const int cv = (int)(e % CV); unsigned t = e / CV;
+    const int q = (int)(t % Q); t /= Q; const int p = (int)(t % P); const long n = t / P;
+    float mu[E], is[E], ga[E], be[E], db[E], dg[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        mu[i] = mean[cv * E + i]; is[i] = invstd[cv * E + i]; ga[i] = gamma[cv * E + i]; be[i] = beta[cv * E + i];
+        db[i] = dbeta[cv * E + i] * inv_rows; dg[i] = dgamma[cv * E + i] * inv_rows;
+    }
+    StemWin<T, E> w00, w01, w10, w11;
+    stem_load_win<T, E>(dy, amax, n, p, q, cv, CV, P, Q, w00); stem_load_win<T, E>(dy, amax, n, p, q + 1, cv, CV, P, Q, w01);
+    stem_load_win<T, E>(dy, amax, n, p + 1, q, cv, CV, P, Q, w10); stem_load_win<T, E>(dy, amax, n, p + 1, q + 1, cv, CV, P, Q, w11);
+#pragma unroll
+    for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+        for (int dw = 0; dw < 2; ++dw) {
+            const int h = 2 * p + dh, w = 2 * q + dw;
+            if (h >= H || w >= W) continue;
+            const long iv = ((n * H + h) * W + w) * CV + cv;
+            float xv[E], g[E], o[E];
+            unpack<T, E>(reinterpret_cast<const uint4*>(x)[iv], xv);
+            stem_block_grad<T, E>(dh, dw, w00, w01, w10, w11, xv, mu, is, ga, be, g);
+#pragma unroll
+            for (int i = 0; i < E; ++i) o[i] = ga[i] * is[i] * (g[i] - db[i] - (xv[i] - mu[i]) * is[i] * dg[i]);
+            reinterpret_cast<uint4*>(dx)[iv] = pack<T, E>(o);
+        }
 }
 
 // ------------------------------------------------------------------ encoder_size resize on the final map (readme.md:118-121)
@@ -697,7 +877,8 @@ template <typename T>
 static int bn_train_fwd_t(const T* x, int64_t rows, int32_t C, const float* gamma, const float* beta, float eps, float momentum,
                           float* running_mean, float* running_var, float* save_mean, float* save_invstd, const T* residual, int32_t relu,
                           T* y, uint8_t* relu_mask, float* scratch, hipStream_t st, const float* tile_stats = nullptr, int tile_rows = 0) {
-    if (!x || !gamma || !beta || !save_mean || !save_invstd || !y || !scratch) return fail(SAT_EINVAL, "bn_train_fwd: null pointer");
+    if (!x || !gamma || !beta || !save_mean || !save_invstd || !scratch) return fail(SAT_EINVAL, "bn_train_fwd: null pointer");
+    SAT_REQUIRE(y || (!residual && !relu_mask), "bn_train_fwd: statistics only (y = NULL) takes no residual / mask");
     SAT_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, "bn_train_fwd: rows=%ld C=%d (C must be a multiple of 4)", (long)rows, C);
     constexpr int E = EPT<T>::n;
     SAT_REQUIRE(C % E == 0, "bn_train_fwd: C=%d must be a multiple of %d for this storage type", C, E);
@@ -713,6 +894,7 @@ static int bn_train_fwd_t(const T* x, int64_t rows, int32_t C, const float* gamm
             hipLaunchKernelGGL(bn_tile_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, tile_stats, ntiles, C, (long)rows, eps, momentum, save_mean, save_invstd,
                                running_mean, running_var);
             SAT_TRY(launch_ok("bn_tile_finalize"));
+            if (!y) return SAT_OK;                   // statistics only: the caller normalises inside its own kernel (stem tail)
             long totalv = rows * (C / E);
             ProfScope prof("bn_apply_fwd", 0.0, (double)rows * C * (sizeof(T) * (residual ? 3 : 2) + (relu_mask ? 0.125 : 0.0)), st);
             hipLaunchKernelGGL((bn_apply_kernel<T, false>), dim3(cdiv(totalv, 256)), dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta, residual, relu, y, relu_mask, totalv, C / E, -1.0f);
@@ -732,6 +914,7 @@ static int bn_train_fwd_t(const T* x, int64_t rows, int32_t C, const float* gamm
     }
     hipLaunchKernelGGL(bn_fwd_finalize_kernel<T>, dim3(cdiv(C, 4)), dim3(256), 0, st, p0, p1, shift_src, nparts, C, (long)rows, eps, momentum, save_mean, save_invstd, running_mean, running_var);
     SAT_TRY(launch_ok("bn_fwd_finalize"));
+    if (!y) return SAT_OK;
     long totalv = rows * (C / E);
     ProfScope prof("bn_apply_fwd", 0.0, (double)rows * C * (sizeof(T) * (residual ? 3 : 2) + (relu_mask ? 0.125 : 0.0)), st);
     hipLaunchKernelGGL((bn_apply_kernel<T, false>), dim3(cdiv(totalv, 256)), dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta, residual, relu, y, relu_mask, totalv, C / E, -1.0f);
@@ -777,13 +960,52 @@ static int bn_train_bwd_t(const T* dy, const T* x, const T* y, int64_t rows, int
 }
 
 template <typename T>
+static int stem_tail_fwd_t(const T* x, int32_t N, int32_t H, int32_t W, int32_t C, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                           T* y, uint8_t* argmax, hipStream_t st) {
+    if (!x || !mean || !invstd || !gamma || !beta || !y || !argmax) return fail(SAT_EINVAL, "stem_tail_fwd: null pointer");
+    constexpr int E = EPT<T>::n;
+    SAT_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % E == 0, "stem_tail_fwd: N=%d H=%d W=%d C=%d (C must be a multiple of %d)", N, H, W, C, E);
+    SAT_REQUIRE((long)N * H * W * (C / E) < (1L << 31), "stem_tail_fwd: more than 2^31 vectors");
+    const int P = (H + 2 - 3) / 2 + 1, Q = (W + 2 - 3) / 2 + 1;
+    const long totalv = (long)N * P * Q * (C / E);
+    ProfScope prof("stem_tail_fwd", 0.0, (double)N * H * W * C * sizeof(T) + (double)N * P * Q * C * (sizeof(T) + 1), st);
+    hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel<T>, dim3(cdiv(totalv, 256)), dim3(256), 0, st, x, mean, invstd, gamma, beta, y, argmax, H, W, C / E, P, Q, totalv);
+    return launch_ok("bn_relu_maxpool_fwd");
+}
+template <typename T>
+static int stem_tail_bwd_t(const T* dy, const uint8_t* argmax, const T* x, int32_t N, int32_t H, int32_t W, int32_t C, const float* mean, const float* invstd,
+                           const float* gamma, const float* beta, T* dx, float* dgamma, float* dbeta, float* scratch, hipStream_t st) {
+    if (!dy || !argmax || !x || !mean || !invstd || !gamma || !beta || !dx || !dgamma || !dbeta || !scratch) return fail(SAT_EINVAL, "stem_tail_bwd: null pointer");
+    constexpr int E = EPT<T>::n;
+    SAT_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % E == 0, "stem_tail_bwd: N=%d H=%d W=%d C=%d (C must be a multiple of %d)", N, H, W, C, E);
+    SAT_REQUIRE((long)N * H * W * (C / E) < (1L << 31), "stem_tail_bwd: more than 2^31 vectors");
+    const int P = (H + 2 - 3) / 2 + 1, Q = (W + 2 - 3) / 2 + 1;
+    const long rows = (long)N * H * W, blocks = (long)N * P * Q;             // P, Q = ceil(H / 2), ceil(W / 2): the 2x2 blocks tile the map
+    int CV, nparts; long bp; bn_grid(blocks, C, E, CV, bp, nparts, 1);
+    double* p0 = reinterpret_cast<double*>(scratch); double* p1 = p0 + (long)nparts * C;
+    {
+        ProfScope prof("stem_tail_bwd_stats", 0.0, (double)rows * C * sizeof(T) + (double)N * P * Q * C * (sizeof(T) + 1), st);
+        hipLaunchKernelGGL(bn_relu_maxpool_bwd_stats_kernel<T>, dim3(cdiv(C / E, CV), nparts), dim3(256), 0, st, x, dy, argmax, mean, invstd, gamma, beta, H, W, P, Q,
+                           blocks, C, CV, bp, p0, p1);
+        SAT_TRY(launch_ok("bn_relu_maxpool_bwd_stats"));
+    }
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, p0, p1, nparts, C, dbeta, dgamma);
+    SAT_TRY(launch_ok("bn_bwd_finalize"));
+    const long totalb = blocks * (C / E);
+    ProfScope prof("stem_tail_bwd_apply", 0.0, (double)rows * C * sizeof(T) * 2 + (double)N * P * Q * C * (sizeof(T) + 1), st);
+    hipLaunchKernelGGL(bn_relu_maxpool_bwd_apply_kernel<T>, dim3(cdiv(totalb, 256)), dim3(256), 0, st, x, dy, argmax, mean, invstd, gamma, beta, dbeta, dgamma,
+                       1.0f / (float)rows, dx, H, W, P, Q, totalb, C / E);
+    return launch_ok("bn_relu_maxpool_bwd_apply");
+}
+
+template <typename T>
 static int maxpool_fwd_t(const T* x, T* y, uint8_t* argmax, int32_t N, int32_t H, int32_t W, int32_t C, hipStream_t st) {
     if (!x || !y || !argmax) return fail(SAT_EINVAL, "maxpool_fwd: null pointer");
     SAT_REQUIRE(C % 4 == 0, "maxpool: C must be a multiple of 4");
     int P = (H + 2 - 3) / 2 + 1, Q = (W + 2 - 3) / 2 + 1;
     long total4 = (long)N * P * Q * (C / 4);
     constexpr int E = EPT<T>::n;
-    if (C % E == 0) {
+    if (C % E == 0 && (long)N * H * W * (C / E) < (1L << 31)) {
         const long totalv = total4 * 4 / E;
         hipLaunchKernelGGL(maxpool3x3s2_fwd_v_kernel<T>, dim3(cdiv(totalv, 256)), dim3(256), 0, st, x, y, argmax, H, W, C / E, P, Q, totalv);
         return launch_ok("maxpool_fwd");
@@ -798,7 +1020,7 @@ static int maxpool_bwd_t(const T* dy, const uint8_t* argmax, T* dx, int32_t N, i
     int P = (H + 2 - 3) / 2 + 1, Q = (W + 2 - 3) / 2 + 1;
     long total4 = (long)N * H * W * (C / 4);
     constexpr int E = EPT<T>::n;
-    if (C % E == 0) {
+    if (C % E == 0 && total4 * 4 / E < (1L << 31)) {
         const long totalv = total4 * 4 / E;
         hipLaunchKernelGGL(maxpool3x3s2_bwd_v_kernel<T>, dim3(cdiv(totalv, 256)), dim3(256), 0, st, dy, argmax, dx, H, W, C / E, P, Q, totalv);
         return launch_ok("maxpool_bwd");
@@ -857,6 +1079,16 @@ int sat_bn_train_bwd(const float* dy, const float* x, const float* y, int64_t ro
                      const float* gamma, int32_t relu, float* dx, float* dgamma, float* dbeta, float* dres, int32_t dres_accumulate,
                      float* scratch, void* stream) {
     return sat_bn_train_bwd_t(0, dy, x, y, rows, C, save_mean, save_invstd, gamma, relu, dx, dgamma, dbeta, dres, dres_accumulate, nullptr, scratch, stream);
+}
+int sat_stem_tail_fwd_t(int32_t dtype, const void* x, int32_t N, int32_t H, int32_t W, int32_t C, const float* mean, const float* invstd, const float* gamma,
+                        const float* beta, void* y_pool, uint8_t* argmax, void* stream) {
+    SAT_BY_DTYPE(dtype, stem_tail_fwd_t<float>((const float*)x, N, H, W, C, mean, invstd, gamma, beta, (float*)y_pool, argmax, (hipStream_t)stream),
+                 stem_tail_fwd_t<bf>((const bf*)x, N, H, W, C, mean, invstd, gamma, beta, (bf*)y_pool, argmax, (hipStream_t)stream));
+}
+int sat_stem_tail_bwd_t(int32_t dtype, const void* dy_pool, const uint8_t* argmax, const void* x, int32_t N, int32_t H, int32_t W, int32_t C, const float* mean,
+                        const float* invstd, const float* gamma, const float* beta, void* dx, float* dgamma, float* dbeta, float* scratch, void* stream) {
+    SAT_BY_DTYPE(dtype, stem_tail_bwd_t<float>((const float*)dy_pool, argmax, (const float*)x, N, H, W, C, mean, invstd, gamma, beta, (float*)dx, dgamma, dbeta, scratch, (hipStream_t)stream),
+                 stem_tail_bwd_t<bf>((const bf*)dy_pool, argmax, (const bf*)x, N, H, W, C, mean, invstd, gamma, beta, (bf*)dx, dgamma, dbeta, scratch, (hipStream_t)stream));
 }
 int sat_maxpool3x3s2_fwd_t(int32_t dtype, const void* x, void* y, uint8_t* argmax, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
     SAT_BY_DTYPE(dtype, maxpool_fwd_t<float>((const float*)x, (float*)y, argmax, N, H, W, C, (hipStream_t)stream),

@@ -7,6 +7,7 @@ match.  The children only hold parameters; ``forward`` runs the HIP 
 annotations as a (B, D, h, w) tensor in channels-last memory, i.e. (B, h*w, D) row-major underneath.
 """
 import ctypes as C
+import os
 
 import torch
 from torch import nn
@@ -158,6 +159,9 @@ def conv_wgrad(dy, x, w, stride, pad):
     return dw.permute(0, 3, 1, 2)                                             # (K,C,R,S) view, channels_last memory
 
 
+#: the stem's bn1 -> relu -> maxpool as one pass (tests switch it off to compare with the three separate kernels)
+_FUSED_STEM_TAIL = os.environ.get("SAT_STEM_TAIL", "1") != "0"
+
 _tracked = []      # num_batches_tracked buffers touched by the running whole-encoder forward (bumped once, together)
 _defer = [False]
 
@@ -202,6 +206,49 @@ def bn_bwd(dy, x, y, stats, bn, relu, dres=None, dres_accumulate=False):
     L.check(lib.sat_bn_train_bwd_t(int(_is_bf(x)), L.ptr(dy), L.ptr(x), L.ptr(y), rows, Cc, L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(bn.weight),
                                    int(relu), L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dres), int(dres_accumulate),
                                    L.ptr(stats[2] if len(stats) > 2 else None), L.ptr(scratch), L.stream_ptr()), "sat_bn_train_bwd")
+    return dx, dgamma, dbeta
+
+
+def stem_tail_fwd(x, bn, tiles=None):
+    """Training-mode bn1 -> relu -> maxpool(3, 2, 1) of the stem convolution's NHWC output in one pass over x
+    (``sat_stem_tail_fwd_t``): returns (pooled, (mean, invstd, argmax)).  The statistics come from the convolution's
+    epilogue tiles when given, else from a pass over x; running statistics are updated like nn.BatchNorm2d."""
+    lib = L.lib()
+    N, H, W, Cc = x.shape
+    rows = N * H * W
+    dt = int(_is_bf(x))
+    mean = torch.empty(Cc, dtype=torch.float32, device=x.device); invstd = torch.empty_like(mean)
+    scratch = torch.empty(lib.sat_bn_scratch_bytes(rows, Cc) // 8 + 1, dtype=torch.float64, device=x.device)
+    mom = 0.1 if bn.momentum is None else float(bn.momentum)
+    if tiles is not None and dt == 1:
+        L.check(lib.sat_bn_train_fwd_tiles_bf16(L.ptr(x), rows, Cc, L.ptr(tiles[0]), int(tiles[1]), L.ptr(bn.weight), L.ptr(bn.bias), float(bn.eps),
+                                                mom, L.ptr(bn.running_mean), L.ptr(bn.running_var), L.ptr(mean), L.ptr(invstd), None, 1, None, None,
+                                                L.ptr(scratch), L.stream_ptr()), "sat_bn_train_fwd_tiles (statistics)")
+    else:
+        L.check(lib.sat_bn_train_fwd_t(dt, L.ptr(x), rows, Cc, L.ptr(bn.weight), L.ptr(bn.bias), float(bn.eps), mom, L.ptr(bn.running_mean),
+                                       L.ptr(bn.running_var), L.ptr(mean), L.ptr(invstd), None, 1, None, None, L.ptr(scratch), L.stream_ptr()),
+                "sat_bn_train_fwd (statistics)")
+    if _defer[0]:
+        _tracked.append(bn.num_batches_tracked)
+    else:
+        bn.num_batches_tracked += 1
+    P, Q = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = torch.empty(N, P, Q, Cc, dtype=x.dtype, device=x.device)
+    amax = torch.empty(N, P, Q, Cc, dtype=torch.uint8, device=x.device)
+    L.check(lib.sat_stem_tail_fwd_t(dt, L.ptr(x), N, H, W, Cc, L.ptr(mean), L.ptr(invstd), L.ptr(bn.weight), L.ptr(bn.bias), L.ptr(y), L.ptr(amax),
+                                    L.stream_ptr()), "sat_stem_tail_fwd")
+    return y, (mean, invstd, amax)
+
+
+def stem_tail_bwd(dy_pool, x, stats, bn):
+    """gradient of ``stem_tail_fwd``: (dx, dgamma, dbeta) from the pooled gradient"""
+    lib = L.lib()
+    N, H, W, Cc = x.shape
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device); dbeta = torch.empty_like(dgamma)
+    scratch = torch.empty(lib.sat_bn_scratch_bytes(N * H * W, Cc) // 8 + 1, dtype=torch.float64, device=x.device)
+    L.check(lib.sat_stem_tail_bwd_t(int(_is_bf(x)), L.ptr(dy_pool), L.ptr(stats[2]), L.ptr(x), N, H, W, Cc, L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(bn.weight),
+                                    L.ptr(bn.bias), L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), L.ptr(scratch), L.stream_ptr()), "sat_stem_tail_bwd")
     return dx, dgamma, dbeta
 
 
@@ -330,12 +377,15 @@ class EncoderFn(torch.autograd.Function):
             L.check(lib.sat_pad_channels_3to4(L.ptr(w3), L.ptr(wp), conv1.out_channels * 49, 0, st), "sat_pad_channels_3to4")
         t["x0"], t["wp"] = x0, wp
         t["c0"], tl = conv_fwd_stats(x0, wp, 2, 3) if training else (conv_fwd(x0, wp, 2, 3), None)
-        t["a0"], t["s0"] = bn_fwd(t["c0"], enc[2], None, True, training, want_mask=True, tiles=tl)
-        Nn, Hh, Ww, Cc = t["a0"].shape
-        P, Q = (Hh + 2 - 3) // 2 + 1, (Ww + 2 - 3) // 2 + 1
-        t["p0"] = torch.empty(Nn, P, Q, Cc, dtype=adt, device=img.device)
-        t["amax"] = torch.empty(Nn, P, Q, Cc, dtype=torch.uint8, device=img.device)
-        L.check(lib.sat_maxpool3x3s2_fwd_t(int(bf), L.ptr(t["a0"]), L.ptr(t["p0"]), L.ptr(t["amax"]), Nn, Hh, Ww, Cc, st), "sat_maxpool3x3s2_fwd")
+        if training and _FUSED_STEM_TAIL:      # bn1 + relu + maxpool in one pass: the full-size activation is never written
+            t["p0"], t["s0"] = stem_tail_fwd(t["c0"], enc[2], tiles=tl)
+        else:
+            t["a0"], t["s0"] = bn_fwd(t["c0"], enc[2], None, True, training, want_mask=True, tiles=tl)
+            Nn, Hh, Ww, Cc = t["a0"].shape
+            P, Q = (Hh + 2 - 3) // 2 + 1, (Ww + 2 - 3) // 2 + 1
+            t["p0"] = torch.empty(Nn, P, Q, Cc, dtype=adt, device=img.device)
+            t["amax"] = torch.empty(Nn, P, Q, Cc, dtype=torch.uint8, device=img.device)
+            L.check(lib.sat_maxpool3x3s2_fwd_t(int(bf), L.ptr(t["a0"]), L.ptr(t["p0"]), L.ptr(t["amax"]), Nn, Hh, Ww, Cc, st), "sat_maxpool3x3s2_fwd")
         x = t["p0"]
         recs = []
         for li in (5, 6, 7, 8):
@@ -407,10 +457,13 @@ class EncoderFn(torch.autograd.Function):
                 d = _block_bwd(recs[idx], d, grads, True, Wt)
                 if cb is not None and idx in (bounds[2], bounds[1], bounds[0]):      # a ResNet stage just finished
                     cb(dict(grads))
-            Nn, Hh, Ww, Cc = t["a0"].shape
-            da0 = torch.empty_like(t["a0"])
-            L.check(lib.sat_maxpool3x3s2_bwd_t(int(bf), L.ptr(d), L.ptr(t["amax"]), L.ptr(da0), Nn, Hh, Ww, Cc, st), "sat_maxpool3x3s2_bwd")
-            dc0, grads[enc[2].weight], grads[enc[2].bias] = bn_bwd(da0, t["c0"], t["a0"], t["s0"], enc[2], True)
+            if "a0" not in t:
+                dc0, grads[enc[2].weight], grads[enc[2].bias] = stem_tail_bwd(d, t["c0"], t["s0"], enc[2])
+            else:
+                Nn, Hh, Ww, Cc = t["a0"].shape
+                da0 = torch.empty_like(t["a0"])
+                L.check(lib.sat_maxpool3x3s2_bwd_t(int(bf), L.ptr(d), L.ptr(t["amax"]), L.ptr(da0), Nn, Hh, Ww, Cc, st), "sat_maxpool3x3s2_bwd")
+                dc0, grads[enc[2].weight], grads[enc[2].bias] = bn_bwd(da0, t["c0"], t["a0"], t["s0"], enc[2], True)
             dwp = conv_wgrad(dc0, t["x0"], t["wp"], 2, 3)                          # (64,cpad,7,7) view of KRS{4,8} fp32 memory
             dw3 = torch.empty_like(_krsc(enc[1].weight))
             if bf:

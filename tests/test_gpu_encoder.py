@@ -129,6 +129,53 @@ def test_maxpool_fwd_bwd_with_ties(E):
     close(nchw(dx), x.grad, 1e-6, "maxpool bwd (first-max tie rule)")
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 11, 12, 16), (3, 16, 16, 64), (1, 7, 9, 8)])
+def test_stem_tail_one_pass_equals_bn_relu_maxpool(E, dtype, shape):
+    """bn1 -> relu -> maxpool as one pass (forward and backward): fp32 against torch autograd; both storage types against the
+    three separate kernels - the pooled map, the argmax and the input gradient bit for bit (the same values are compared and
+    the gathered gradient is rounded where the separate path stores it), dgamma / dbeta within summation-order noise."""
+    N, H, W, Cc = shape
+    g = torch.Generator().manual_seed(N * 100 + H)
+    x = torch.randn(N, Cc, H, W, generator=g) * 1.5 + 0.2
+    bn = torch.nn.BatchNorm2d(Cc)
+    with torch.no_grad():
+        bn.weight.copy_(torch.randn(Cc, generator=g)); bn.bias.copy_(torch.randn(Cc, generator=g) * 0.3)      # negative gammas too
+    import copy
+    bnd1, bnd2 = copy.deepcopy(bn).cuda(), copy.deepcopy(bn).cuda()
+    adt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    xd = nhwc(x).cuda().to(adt).contiguous()
+    # separate kernels
+    a0, s0 = E.bn_fwd(xd, bnd1, None, True, True, want_mask=(Cc % 8 == 0))
+    from sat_amd import _lib as L
+    P, Q = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    p0 = torch.empty(N, P, Q, Cc, dtype=adt, device="cuda"); am = torch.empty(N, P, Q, Cc, dtype=torch.uint8, device="cuda")
+    L.check(L.lib().sat_maxpool3x3s2_fwd_t(int(dtype == "bf16"), L.ptr(a0), L.ptr(p0), L.ptr(am), N, H, W, Cc, L.stream_ptr()), "maxpool")
+    # one pass
+    p1, s1 = E.stem_tail_fwd(xd, bnd2)
+    assert torch.equal(p1, p0) and torch.equal(s1[2], am)
+    assert torch.equal(s1[0], s0[0]) and torch.equal(s1[1], s0[1])
+    assert torch.equal(bnd1.running_mean, bnd2.running_mean) and torch.equal(bnd1.running_var, bnd2.running_var) and int(bnd2.num_batches_tracked) == 1
+    dy = torch.randn(N, P, Q, Cc, generator=g)
+    dyd = dy.cuda().to(adt)
+    da0 = torch.empty_like(a0)
+    L.check(L.lib().sat_maxpool3x3s2_bwd_t(int(dtype == "bf16"), L.ptr(dyd), L.ptr(am), L.ptr(da0), N, H, W, Cc, L.stream_ptr()), "maxpool bwd")
+    dx0, dg0, db0 = E.bn_bwd(da0, xd, a0, s0, bnd1, True)
+    dx1, dg1, db1 = E.stem_tail_bwd(dyd, xd, s1, bnd2)
+    close(dg1, dg0, 1e-5, "dgamma vs separate kernels"); close(db1, db0, 1e-5, "dbeta vs separate kernels")
+    if dtype == "fp32":
+        close(dx1, dx0, 1e-5, "dx vs separate kernels")
+        xr = x.clone().requires_grad_()
+        bn.train()
+        y = F.max_pool2d(F.relu(bn(xr)), 3, 2, 1)
+        y.backward(dy.permute(0, 3, 1, 2))
+        close(nchw(p1), y, 1e-5, "pooled vs torch"); close(nchw(dx1), xr.grad, 3e-5, "dx vs torch")
+        close(dg1, bn.weight.grad, 3e-5, "dgamma vs torch"); close(db1, bn.bias.grad, 3e-5, "dbeta vs torch")
+    else:
+        diff = (dx1.float() - dx0.float()).abs()
+        assert float(diff.max()) <= 0.02 * float(dx0.float().abs().max()) + 1e-6, "dx differs beyond a bf16 rounding of the statistics: %g" % float(diff.max())
+
+
 @pytest.mark.parametrize("out", [7, 14, 5])
 def test_resize_fwd_bwd(E, out):
     import sat_amd  # noqa
