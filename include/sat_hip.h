@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SAT_HIP_ABI_VERSION 12
+#define SAT_HIP_ABI_VERSION 13
 
 int sat_abi_version(void);
 const char* sat_last_error(void);
@@ -174,6 +174,30 @@ int sat_decoder_infer_step(const sat_decoder_dims* d, const sat_decoder_params* 
 size_t sat_beam_search_workspace_bytes(const sat_decoder_dims* d, int32_t beamk);
 int sat_beam_search_batched(const sat_decoder_dims* d, const sat_decoder_params* w, const float* ann /* (B, L, D) */, int32_t beamk,
                             int32_t max_gen_length, const float* temperatures_host, int32_t n_temperatures, const int32_t* special_ids_host,
+                            int32_t* tok_in, int32_t* prev_row, float* alpha_hist, int32_t* fin_count, int32_t* fin_step, int32_t* fin_row,
+                            float* fin_score, float* fin_mean, void* workspace, size_t workspace_bytes, void* stream);
+/* The same search with the continuing hypotheses DRAWN instead of taken (SAT.forward sample_method, model.py:360-379) and / or
+ * decoder noise (model.py:322-324).  torch.multinomial(p, k) without replacement is an ordered Plackett-Luce sample; it is drawn
+ * here as the top k of log p + Gumbel noise.  The variates come from a counter-based hash of (seed, step, row, candidate) or
+ * from the caller's tables (tests):
+ *   gumbel  : method 1: (max_gen_length + 1, B * beamk, V)            Gumbel(0, 1) variate of candidate word v of a row
+ *             method 2: (max_gen_length + 1, B * beamk, sample_topk)  ... of the row's t-th best candidate (torch.topk order)
+ *   normals : (max_gen_length + 1, layers, B * beamk, n) standard normals of the state noise
+ * rows are the compacted beam rows of that step (image b owns rows b * beamk ...).  sampling = NULL is sat_beam_search_batched. */
+#define SAT_SAMPLE_BEAM 0
+#define SAT_SAMPLE_MULTINOMIAL 1
+#define SAT_SAMPLE_TOPK 2
+typedef struct sat_beam_sampling {
+    int32_t method;            /* SAT_SAMPLE_*                                                  */
+    int32_t sample_topk;       /* candidates per hypothesis, method 2                            */
+    uint64_t seed;
+    const float* gumbel;       /* device pointer or NULL                                         */
+    float decoder_noise;       /* 0 = off; step s adds N(0,1) * decoder_noise / (s + 1) to h     */
+    int32_t reserved;
+    const float* normals;      /* device pointer or NULL                                         */
+} sat_beam_sampling;
+int sat_beam_search_sampled(const sat_decoder_dims* d, const sat_decoder_params* w, const float* ann, int32_t beamk, int32_t max_gen_length,
+                            const float* temperatures_host, int32_t n_temperatures, const int32_t* special_ids_host, const sat_beam_sampling* sampling,
                             int32_t* tok_in, int32_t* prev_row, float* alpha_hist, int32_t* fin_count, int32_t* fin_step, int32_t* fin_row,
                             float* fin_score, float* fin_mean, void* workspace, size_t workspace_bytes, void* stream);
 int sat_beam_scores(const float* logits, int32_t beams, int32_t V, float temperature, const int32_t* masked_ids /* device */,

@@ -455,6 +455,14 @@ class OracleSAT:
 # a11. Inference: SAT.forward / caption (model.py:237-472): beam search, the two sampled variants, decoder noise.
 # --------------------------------------------------------------------------
 
+def gumbel_topk(probs, k, gumbel):
+    """An ordered sample of k distinct categories from the (unnormalised) distribution ``probs`` - what
+    ``torch.multinomial(probs, k)`` (without replacement) draws, model.py:364,377 - taken as the top k of
+    log p + Gumbel(0,1) noise (the Gumbel-top-k / Plackett-Luce identity).  ``gumbel``: one variate per category.
+    The batched HIP search draws this way; tests/test_oracle_golden.py checks the identity against torch.multinomial."""
+    return torch.topk(torch.log(probs) + gumbel, k).indices
+
+
 def beam_search(sd, hp, ann_img, beamk=3, max_gen_length=32, temperature=1.0, rescore_method=None, rescore_reward=0.5,
                 return_all=False, lstm_fn=lstm_step, sample_method="beam", sample_topk=3, decoder_noise=None,
                 multinomial=torch.multinomial, randn=torch.randn):

@@ -72,6 +72,11 @@ class OptHyper(C.Structure):
                 ("clip_value", C.c_float)]
 
 
+class BeamSampling(C.Structure):
+    _fields_ = [("method", C.c_int32), ("sample_topk", C.c_int32), ("seed", C.c_uint64), ("gumbel", C.c_void_p), ("decoder_noise", C.c_float),
+                ("reserved", C.c_int32), ("normals", C.c_void_p)]
+
+
 class ImageDesc(C.Structure):
     _fields_ = [("offset", C.c_int64)] + [(k, C.c_int32) for k in ("height", "width", "crop_top", "crop_left", "crop_h", "crop_w", "resized_h",
                                                                   "resized_w", "out_top", "out_left", "flip", "reserved")]
@@ -163,6 +168,8 @@ SYMBOLS.update({
     "sat_beam_search_workspace_bytes": (C.c_size_t, [C.POINTER(DecoderDims), _i32]),
     "sat_beam_search_batched": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), _vp, _i32, _i32, C.POINTER(C.c_float), _i32, C.POINTER(C.c_int32),
                                           _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "sat_beam_search_sampled": (C.c_int, [C.POINTER(DecoderDims), C.POINTER(DecoderParams), _vp, _i32, _i32, C.POINTER(C.c_float), _i32, C.POINTER(C.c_int32),
+                                          C.POINTER(BeamSampling), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "sat_beam_scores": (C.c_int, [_vp, _i32, _i32, _f, _vp, _i32, _vp, _vp, _vp]),
     "sat_topk": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
 })
@@ -204,8 +211,8 @@ def lib():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(handle, name)          # AttributeError if the export is missing
             fn.restype, fn.argtypes = res, args
-        if handle.sat_abi_version() != 12:
-            raise SatHipError("libsat_hip.so ABI version %d != 12 (rebuild: make -C csrc)" % handle.sat_abi_version())
+        if handle.sat_abi_version() != 13:
+            raise SatHipError("libsat_hip.so ABI version %d != 13 (rebuild: make -C csrc)" % handle.sat_abi_version())
         _lib = handle
     return _lib
 

@@ -125,7 +125,18 @@ int sat_beam_search_batched(const sat_decoder_dims* d, const sat_decoder_params*
         return fail(SAT_EINVAL, "beam_search_batched: null pointer");
     for (int i = 0; i < n_temperatures; ++i) if (!(temperatures_host[i] > 0.f)) return fail(SAT_EINVAL, "beam_search_batched: temperature %g", temperatures_host[i]);
     return decoder_beam_batched(*d, *w, ann, beamk, max_gen_length, temperatures_host, n_temperatures, special_ids_host, tok_in, prev_row, alpha_hist, fin_count,
-                                fin_step, fin_row, fin_score, fin_mean, (char*)workspace, workspace_bytes, (hipStream_t)stream);
+                                fin_step, fin_row, fin_score, fin_mean, (char*)workspace, workspace_bytes, (hipStream_t)stream, nullptr);
+}
+int sat_beam_search_sampled(const sat_decoder_dims* d, const sat_decoder_params* w, const float* ann, int32_t beamk, int32_t max_gen_length,
+                            const float* temperatures_host, int32_t n_temperatures, const int32_t* special_ids_host, const sat_beam_sampling* sampling,
+                            int32_t* tok_in, int32_t* prev_row, float* alpha_hist, int32_t* fin_count, int32_t* fin_step, int32_t* fin_row, float* fin_score,
+                            float* fin_mean, void* workspace, size_t workspace_bytes, void* stream) {
+    SAT_TRY(check_dims(d)); SAT_TRY(check_params(d, w, "beam_search_sampled"));
+    if (!ann || !temperatures_host || !special_ids_host || !tok_in || !prev_row || !alpha_hist || !fin_count || !fin_step || !fin_row || !fin_score || !fin_mean || !workspace)
+        return fail(SAT_EINVAL, "beam_search_sampled: null pointer");
+    for (int i = 0; i < n_temperatures; ++i) if (!(temperatures_host[i] > 0.f)) return fail(SAT_EINVAL, "beam_search_sampled: temperature %g", temperatures_host[i]);
+    return decoder_beam_batched(*d, *w, ann, beamk, max_gen_length, temperatures_host, n_temperatures, special_ids_host, tok_in, prev_row, alpha_hist, fin_count,
+                                fin_step, fin_row, fin_score, fin_mean, (char*)workspace, workspace_bytes, (hipStream_t)stream, sampling);
 }
 int sat_beam_scores(const float* logits, int32_t beams, int32_t V, float temperature, const int32_t* masked_ids, int32_t n_masked,
                     const float* parent_scores, float* scores, void* stream) {

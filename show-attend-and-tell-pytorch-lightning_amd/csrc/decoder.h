@@ -21,7 +21,7 @@ int decoder_infer_step(const sat_decoder_dims& d, const sat_decoder_params& p, c
 size_t decoder_beam_workspace_bytes(const sat_decoder_dims& d, int K);
 int decoder_beam_batched(const sat_decoder_dims& d, const sat_decoder_params& p, const float* ann, int K, int max_gen_length, const float* temps_host,
                          int n_temps, const int* special_host, int* tok_in, int* prev_row, float* alpha_hist, int* fin_count, int* fin_step, int* fin_row,
-                         float* fin_score, float* fin_mean, char* ws, size_t ws_bytes, hipStream_t st);
+                         float* fin_score, float* fin_mean, char* ws, size_t ws_bytes, hipStream_t st, const sat_beam_sampling* sampling);
 int beam_scores(const float* logits, int K, int V, float temperature, const int* masked, int n_masked, const float* parent, float* scores, hipStream_t st);
 int topk(const float* x, float* work, long n, int k, float* values, int* indices, hipStream_t st);
 int colsum_public(const float* x, long ld, long rows, int cols, float* out, float* scratch, hipStream_t st);

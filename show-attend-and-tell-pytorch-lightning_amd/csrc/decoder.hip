@@ -702,7 +702,7 @@ int decoder_infer_step(const sat_decoder_dims& d, const sat_decoder_params& p, c
 // those of model.py:262-448; the whole loop is enqueued without a host round trip and leaves a back-trace
 // (token and parent row of every step, attention maps, finished list) for the host to read once.
 struct BeamWs {
-    size_t total; float *U, *Wcat, *bcat, *mean, *f, *init_img, *hc, *Z, *XZ, *Y, *u, *gu, *bup, *h, *c, *h2, *c2, *logits, *scores, *work, *vals, *top, *sc;
+    size_t total; float *U, *Wcat, *bcat, *mean, *f, *init_img, *hc, *Z, *XZ, *Y, *u, *gu, *bup, *h, *c, *h2, *c2, *logits, *scores, *work, *keys, *noise, *vals, *top, *sc;
     int *live, *klive, *inds, *gmap, *mask_first, *mask_rest;
 };
 static BeamWs beam_layout(const sat_decoder_dims& d, int K, char* base) {
@@ -716,7 +716,7 @@ static BeamWs beam_layout(const sat_decoder_dims& d, int K, char* base) {
     w.Y = (float*)take((size_t)N * d.m); w.u = (float*)take((size_t)N * d.m);
     w.h = (float*)take((size_t)d.layers * N * d.n); w.c = (float*)take((size_t)d.layers * N * d.n);
     w.h2 = (float*)take((size_t)d.layers * N * d.n); w.c2 = (float*)take((size_t)d.layers * N * d.n);
-    w.logits = (float*)take((size_t)N * d.V); w.scores = (float*)take((size_t)N * d.V); w.work = (float*)take((size_t)N * d.V);
+    w.logits = (float*)take((size_t)N * d.V); w.scores = (float*)take((size_t)N * d.V); w.work = (float*)take((size_t)N * d.V); w.keys = (float*)take((size_t)N * d.V); w.noise = (float*)take((size_t)d.layers * N * d.n);
     w.vals = (float*)take(N); w.top = (float*)take(N); w.sc = (float*)take((size_t)N * d.L);
     w.live = (int*)take(N); w.klive = (int*)take(d.B); w.inds = (int*)take(N); w.gmap = (int*)take(N); w.mask_first = (int*)take(4); w.mask_rest = (int*)take(4);
     w.total = off;
@@ -726,8 +726,11 @@ size_t decoder_beam_workspace_bytes(const sat_decoder_dims& d, int K) { return b
 
 int decoder_beam_batched(const sat_decoder_dims& d, const sat_decoder_params& p, const float* ann, int K, int max_gen_length, const float* temps_host,
                          int n_temps, const int* special_host /* START, PAD, END, UNK */, int* tok_in, int* prev_row, float* alpha_hist, int* fin_count,
-                         int* fin_step, int* fin_row, float* fin_score, float* fin_mean, char* ws, size_t ws_bytes, hipStream_t st) {
+                         int* fin_step, int* fin_row, float* fin_score, float* fin_mean, char* ws, size_t ws_bytes, hipStream_t st, const sat_beam_sampling* smp) {
     BeamWs w = beam_layout(d, K, ws);
+    const int method = smp ? smp->method : 0;
+    SAT_REQUIRE(method >= 0 && method <= 2 && (method != 2 || (smp->sample_topk >= 1 && smp->sample_topk <= d.V)), "beam_batched: sampling method %d, sample_topk %d",
+                method, smp ? smp->sample_topk : 0);
     SAT_REQUIRE(ws_bytes >= w.total && K >= 1 && max_gen_length >= 0 && n_temps >= 1, "beam_batched: workspace %zu < %zu, K=%d, max_gen_length=%d", ws_bytes, w.total, K, max_gen_length);
     t_bf16_mfma = d.precision ? 1 : 0;
     const int B = d.B, N = B * K, n = d.n, A = d.A, D = d.D, m = d.m, V = d.V, NL = d.layers, HCW = A + D + 4 * n;
@@ -776,6 +779,13 @@ int decoder_beam_batched(const sat_decoder_dims& d, const sat_decoder_params& p,
         // ---- model.py:298-327 for all rows (dead rows: zero attention, state carried, ignored below)
         hipLaunchKernelGGL(gather_rows_kernel, dim3(N), dim3(64), 0, st, p.embedding, tok, w.Y, N, m, 0.f, 0ull, 0L);
         SAT_TRY(launch_ok("embedding gather"));
+        const bool noisy = smp && smp->decoder_noise != 0.f;
+        if (noisy) {        // model.py:322-324: randn * decoder_noise / (step + 1) joins h of every layer before the LSTM
+            const long tot = (long)NL * N * n;
+            hipLaunchKernelGGL(beam_state_noise_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, st, w.noise, w.live, (long)N, n, NL, smp->decoder_noise / (float)(step + 1),
+                               (unsigned long long)smp->seed, 0x1000ull + step, smp->normals ? smp->normals + (long)step * tot : (const float*)nullptr);
+            SAT_TRY(launch_ok("beam_state_noise"));
+        }
         if (NL == 1) {
             SAT_TRY(gemm(st, A_ROW, B_ROW, h, n, w.Wcat, n, w.hc, HCW, N, HCW, n, 0, EPI_BIAS_SIGMOID_RANGE, w.bcat, nullptr, nullptr, nullptr, 0, A, A + D));
         } else {
@@ -783,6 +793,7 @@ int decoder_beam_batched(const sat_decoder_dims& d, const sat_decoder_params& p,
             SAT_TRY(gemm(st, A_ROW, B_ROW, h, n, w.Wcat + (long)(A + D) * n, n, w.hc + A + D, HCW, N, 4 * n, n, 0, EPI_BIAS, w.bcat + A + D));
         }
         SAT_TRY(launch_attention_fwd(st, ann, w.U, w.hc, HCW, p.att_f, w.live, 0, alpha, 1, w.Z, w.XZ, B, K, d.L, D, A, w.sc));
+        if (noisy) SAT_TRY(gemm(st, A_ROW, B_ROW, w.noise, n, w.Wcat + (long)(A + D) * n, n, w.hc + A + D, HCW, N, 4 * n, n, 1));
         SAT_TRY(gemm(st, A_ROW, B_ROW, w.Y, m, p.w_ih, m + D, w.hc + A + D, HCW, N, 4 * n, m, 1));
         SAT_TRY(gemm(st, A_ROW, B_ROW, w.XZ, D, p.w_ih + m, m + D, w.hc + A + D, HCW, N, 4 * n, D, 1));
         hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(cdiv((long)N * n, 256)), dim3(256), 0, st, w.hc + A + D, HCW, (const float*)nullptr, c, h, c, h, w.live, 0, N, n);
@@ -791,6 +802,7 @@ int decoder_beam_batched(const sat_decoder_dims& d, const sat_decoder_params& p,
             float* hl = h + l * KS; float* cl = c + l * KS;
             SAT_TRY(gemm(st, A_ROW, B_ROW, hl - KS, n, p.up_w_ih[l - 1], n, w.gu, 4 * n, N, 4 * n, n, 0, EPI_BIAS, w.bup + (long)(l - 1) * 4 * n));
             SAT_TRY(gemm(st, A_ROW, B_ROW, hl, n, p.up_w_hh[l - 1], n, w.gu, 4 * n, N, 4 * n, n, 1));
+            if (noisy) SAT_TRY(gemm(st, A_ROW, B_ROW, w.noise + l * KS, n, p.up_w_hh[l - 1], n, w.gu, 4 * n, N, 4 * n, n, 1));
             hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(cdiv((long)N * n, 256)), dim3(256), 0, st, w.gu, 4 * n, (const float*)nullptr, cl, hl, cl, hl, w.live, 0, N, n);
             SAT_TRY(launch_ok("lstm_cell_fwd (stacked layer)"));
         }
@@ -802,8 +814,20 @@ int decoder_beam_batched(const sat_decoder_dims& d, const sat_decoder_params& p,
         hipLaunchKernelGGL(beam_scores_kernel, dim3(N), dim3(256), 0, st, w.logits, V, 1.0f / T, step == 0 ? w.mask_first : w.mask_rest, step == 0 ? 4 : 2,
                            step == 0 ? (const float*)nullptr : w.top, w.scores);
         SAT_TRY(launch_ok("beam_scores"));
-        hipLaunchKernelGGL(beam_topk_kernel, dim3(B), dim3(1024), 0, st, w.scores, w.work, w.klive, K, V, step == 0 ? 1 : 0, w.vals, w.inds);
-        SAT_TRY(launch_ok("beam_topk"));
+        if (method == 0 || step == 0) {                // the first step always takes the top beamk words (model.py:343)
+            hipLaunchKernelGGL(beam_topk_kernel, dim3(B), dim3(1024), 0, st, w.scores, w.work, w.klive, K, V, step == 0 ? 1 : 0, w.vals, w.inds);
+            SAT_TRY(launch_ok("beam_topk"));
+        } else {                                       // model.py:360-379: draw the continuing hypotheses (Gumbel-top-k == multinomial without replacement)
+            const int gstride = method == 1 ? V : smp->sample_topk;
+            hipLaunchKernelGGL(beam_sample_keys_kernel, dim3(N), dim3(256), 0, st, w.scores, w.klive, K, V, method, smp->sample_topk, (float)step,
+                               (unsigned long long)smp->seed, (unsigned long long)step, smp->gumbel ? smp->gumbel + (long)step * N * gstride : (const float*)nullptr,
+                               gstride, w.keys);
+            SAT_TRY(launch_ok("beam_sample_keys"));
+            hipLaunchKernelGGL(beam_topk_kernel, dim3(B), dim3(1024), 0, st, w.keys, w.work, w.klive, K, V, 0, w.vals, w.inds);
+            SAT_TRY(launch_ok("beam_topk (keys)"));
+            hipLaunchKernelGGL(beam_take_scores_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, w.scores, w.inds, w.klive, B, K, V, w.vals);
+            SAT_TRY(launch_ok("beam_take_scores"));
+        }
         hipLaunchKernelGGL(beam_update_kernel, dim3(cdiv(B, 64)), dim3(64), 0, st, w.vals, w.inds, w.klive, B, K, V, step, max_gen_length, END,
                            tok_in + (long)(step + 1) * N, prev_row + (long)(step + 1) * N, w.top, w.gmap, fin_count, fin_step, fin_row, fin_score, fin_mean);
         SAT_TRY(launch_ok("beam_update"));

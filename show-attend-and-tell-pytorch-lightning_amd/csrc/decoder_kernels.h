@@ -1148,6 +1148,107 @@ __global__ __launch_bounds__(1024) void beam_topk_kernel(const float* __restrict
         __syncthreads();
     }
 }
+// ---- sampled continuation of the beams (model.py:360-379) for all images at once.
+// torch.multinomial(p, k) without replacement draws an ordered sample from the Plackett-Luce distribution of p; so does
+// "top-k of log p + Gumbel noise" (Gumbel-top-k), which needs no sequential renormalisation and reuses the per-image top-k
+// kernel.  The draws are therefore not torch's: they come from a counter-based hash of (seed, step, row, candidate), or from a
+// caller-supplied table of Gumbel variates (tests).
+__device__ __forceinline__ float hash_uniform(unsigned long long seed, unsigned long long stream, unsigned long long idx) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (stream + 1) + idx * 0xD1342543DE82EF95ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return ((float)(z >> 40) + 0.5f) * (1.0f / 16777216.0f);       // 24 bits -> (0, 1)
+}
+__device__ __forceinline__ float gumbel_of(float u) { return -__logf(-__logf(u)); }
+// keys[i, :] for live row i = (b, j):  method 1 ("multinomial", model.py:360-364): log softmax_v(20 * s / step) + G
+//                                      method 2 ("topk", model.py:365-379): s / step + G for the row's sample_topk best
+//                                      candidates (torch.topk order; the Gumbel variate belongs to the candidate's RANK t), else -inf
+// gumbel: optional table (B*K rows, gstride floats per row) of this step: method 1 reads [v], method 2 reads [t].
+__global__ __launch_bounds__(256) void beam_sample_keys_kernel(const float* __restrict__ scores, const int* __restrict__ klive, int K, int V, int method,
+                                                               int sample_topk, float step, unsigned long long seed, unsigned long long stream,
+                                                               const float* __restrict__ gumbel, int gstride, float* __restrict__ keys) {
+    const int i = blockIdx.x, b = i / K, j = i - b * K, tid = threadIdx.x;
+    if (j >= klive[b]) return;
+    const float* s = scores + (long)i * V; float* key = keys + (long)i * V;
+    __shared__ float s_v[4]; __shared__ int s_i[4]; __shared__ float s_b; __shared__ int s_bi;
+    if (method == 1) {
+        const float sc = 20.0f / step;
+        float mx = -INFINITY;
+        for (int v = tid; v < V; v += 256) mx = fmaxf(mx, s[v] * sc);
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if ((tid & 63) == 0) s_v[tid >> 6] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(s_v[0], s_v[1]), fmaxf(s_v[2], s_v[3]));
+        __syncthreads();
+        float sum = 0.f;
+        for (int v = tid; v < V; v += 256) sum += __expf(s[v] * sc - mx);
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        if ((tid & 63) == 0) s_v[tid >> 6] = sum;
+        __syncthreads();
+        const float lse = mx + __logf(s_v[0] + s_v[1] + s_v[2] + s_v[3]);
+        for (int v = tid; v < V; v += 256) {
+            const float g = gumbel ? gumbel[(long)i * gstride + v] : gumbel_of(hash_uniform(seed, stream, (unsigned long long)i * V + v));
+            key[v] = s[v] * sc - lse + g;                 // -inf scores (masked tokens) stay -inf: probability zero
+        }
+    } else {
+        for (int v = tid; v < V; v += 256) key[v] = -INFINITY;
+        __syncthreads();
+        // the row's best sample_topk candidates, one per pass: descending value, ties to the lowest index
+        float lastv = INFINITY; int lasti = -1;
+        for (int t = 0; t < sample_topk; ++t) {
+            float bv = -INFINITY; int bi = 0x7fffffff;
+            for (int v = tid; v < V; v += 256) {
+                const float x = s[v];
+                const bool after = x < lastv || (x == lastv && v > lasti);      // strictly after the previous pick in (value desc, index asc) order
+                if (after && (x > bv || (x == bv && v < bi))) { bv = x; bi = v; }
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            if ((tid & 63) == 0) { s_v[tid >> 6] = bv; s_i[tid >> 6] = bi; }
+            __syncthreads();
+            if (tid == 0) {
+                for (int w = 1; w < 4; ++w) if (s_v[w] > bv || (s_v[w] == bv && s_i[w] < bi)) { bv = s_v[w]; bi = s_i[w]; }
+                s_b = bv; s_bi = bi;
+                if (bi < V) {
+                    const float g = gumbel ? gumbel[(long)i * gstride + t] : gumbel_of(hash_uniform(seed, stream, (unsigned long long)i * V + t));
+                    key[bi] = bv / step + g;
+                }
+            }
+            __syncthreads();
+            lastv = s_b; lasti = s_bi;
+            if (lasti >= V) break;                        // fewer than sample_topk finite candidates
+        }
+    }
+}
+// after the top-k over the keys: the kept hypotheses carry their SCORES (model.py:382 top_scores = seq_scores.reshape(-1)[pred_idx])
+__global__ void beam_take_scores_kernel(const float* __restrict__ scores, const int* __restrict__ inds, const int* __restrict__ klive, int B, int K, int V,
+                                        float* __restrict__ values) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * K) return;
+    const int b = i / K, j = i - b * K;
+    if (j < klive[b]) { const int ind = inds[i]; if (ind >= 0 && ind < K * V) values[i] = scores[(long)b * K * V + ind]; }
+}
+// decoder noise (model.py:322-324): out = N(0, 1) * scale for every layer and live row (0 for dead rows); normals from the table
+// or the hash (Box-Muller).  The noise joins h after attention and the gate were taken from the clean state, so it reaches the
+// step through the recurrent products only: the caller adds out * W_hh^T to the gate pre-activations.
+__global__ void beam_state_noise_kernel(float* __restrict__ out, const int* __restrict__ live, long N, int n, int layers, float scale,
+                                        unsigned long long seed, unsigned long long stream, const float* __restrict__ normals) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)layers * N * n) return;
+    const long i = (e / n) % N;
+    float z = 0.f;
+    if (live[i]) {
+        if (normals) z = normals[e];
+        else {
+            const float u1 = hash_uniform(seed, stream, 2ull * e), u2 = hash_uniform(seed, stream, 2ull * e + 1);
+            z = sqrtf(-2.0f * __logf(u1)) * __cosf(6.28318530718f * u2);
+        }
+    }
+    out[e] = z * scale;
+}
 // Beam bookkeeping of one step for every image (model.py:343-447), one thread per image, in the reference's order:
 // extend each kept hypothesis (parent row, word), record the completed ones (word == END) in index order, drop them from the
 // beam, and at the last step record whatever is left.  Writes the next step's inputs: token, parent row (for the back-trace

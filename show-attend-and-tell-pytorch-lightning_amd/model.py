@@ -271,13 +271,18 @@ class SATDecoder(nn.Module):
 
     @torch.no_grad()
     def beam_decode_batched(self, ann_bld, hw, beamk=3, max_gen_length=32, temperature=1.0, rescore_method=None, rescore_reward=0.5,
-                            return_all=False):
+                            return_all=False, sample_method="beam", sample_topk=3, decoder_noise=None, seed=None, gumbel=None, normals=None):
         """The same beam search as ``beam_decode`` ("beam" sampling, no decoder noise) for ALL images of the batch at once
         (SURVEY 8f row 2): one library call enqueues every decode step for the (B, beamk) hypothesis rows -- per-image top-k,
         completed hypotheses leaving their image's beam, cut at ``max_gen_length`` -- without a host round trip; the host reads
-        the back-trace once and rebuilds the reference's four lists (model.py:449-472)."""
+        the back-trace once and rebuilds the reference's four lists (model.py:449-472).
+        ``sample_method`` "multinomial" / "topk" (model.py:360-379) and ``decoder_noise`` (model.py:322-324) run in the same call:
+        the hypotheses are drawn on the device as the top k of log p + Gumbel noise (an ordered sample without replacement, like
+        ``torch.multinomial``) from a counter-based generator seeded by ``seed`` (default: one draw from torch's CPU generator);
+        ``gumbel`` / ``normals`` replace the generator by tables (layouts: include/sat_hip.h, sat_beam_sampling)."""
         import ctypes as C
         import numpy as np
+        assert sample_method in ("beam", "multinomial", "topk")
         lib = L.lib()
         L.require_gpu(ann_bld)
         hp = self.hp
@@ -302,9 +307,20 @@ class SATDecoder(nn.Module):
         alpha_hist = torch.empty(S + 1, B, K, Lc, **f32)
         fin_count = torch.empty(B, **i32); fin_step = torch.empty(B, K, **i32); fin_row = torch.empty(B, K, **i32)
         fin_score = torch.empty(B, K, **f32); fin_mean = torch.empty(B, K, **f32)
-        L.check(lib.sat_beam_search_batched(C.byref(dims), C.byref(w), L.ptr(ann_bld), K, S, tarr, len(temps), ids, L.ptr(tok_in), L.ptr(prev_row),
-                                            L.ptr(alpha_hist), L.ptr(fin_count), L.ptr(fin_step), L.ptr(fin_row), L.ptr(fin_score), L.ptr(fin_mean),
-                                            L.ptr(ws), ws_bytes, L.stream_ptr()), "sat_beam_search_batched")
+        smp = None
+        if sample_method != "beam" or decoder_noise:
+            if seed is None:
+                seed = int(torch.randint(0, 2 ** 62, (1,)))
+            for t in (gumbel, normals):
+                if t is not None:
+                    L.require_gpu(t)
+                    assert t.dtype == torch.float32 and t.is_contiguous()
+            smp = L.BeamSampling(method={"beam": 0, "multinomial": 1, "topk": 2}[sample_method], sample_topk=int(sample_topk), seed=int(seed),
+                                 gumbel=(gumbel.data_ptr() if gumbel is not None else None), decoder_noise=float(decoder_noise or 0.0),
+                                 normals=(normals.data_ptr() if normals is not None else None))
+        L.check(lib.sat_beam_search_sampled(C.byref(dims), C.byref(w), L.ptr(ann_bld), K, S, tarr, len(temps), ids, C.byref(smp) if smp is not None else None,
+                                            L.ptr(tok_in), L.ptr(prev_row), L.ptr(alpha_hist), L.ptr(fin_count), L.ptr(fin_step), L.ptr(fin_row),
+                                            L.ptr(fin_score), L.ptr(fin_mean), L.ptr(ws), ws_bytes, L.stream_ptr()), "sat_beam_search_sampled")
         tok_in, prev_row = tok_in.cpu().numpy(), prev_row.cpu().numpy()
         alpha_np = alpha_hist.cpu().numpy()
         fin_count, fin_step, fin_row = fin_count.cpu().numpy(), fin_step.cpu().numpy(), fin_row.cpu().numpy()
@@ -461,8 +477,9 @@ class SAT(SATDecoder, _Base):
         assert sample_method in ["beam", "multinomial", "topk"]
         with torch.no_grad():
             ann_bld, hw = self.encode(img)
-            if sample_method == "beam" and not decoder_noise and max_gen_length >= 1:        # every image at once
-                return self.beam_decode_batched(ann_bld.contiguous(), hw, beamk, max_gen_length, temperature, rescore_method, rescore_reward, return_all)
+            if max_gen_length >= 1:        # every image at once; sampled continuations and decoder noise draw from the device generator
+                return self.beam_decode_batched(ann_bld.contiguous(), hw, beamk, max_gen_length, temperature, rescore_method, rescore_reward, return_all,
+                                                sample_method=sample_method, sample_topk=sample_topk, decoder_noise=decoder_noise)
             return self.beam_decode(ann_bld.contiguous(), hw, beamk, max_gen_length, temperature, sample_method, sample_topk,
                                     decoder_noise, rescore_method, rescore_reward, return_all)
 

@@ -175,3 +175,76 @@ def test_batched_beam_search_equals_the_per_image_loop(layers):
             assert u.shape == v.shape and float((u - v).abs().max()) <= 1e-5
         for u, v in zip(flat(a[3]), flat(b[3])):
             assert abs(u - v) <= 1e-5 * max(1.0, abs(u))
+
+
+@pytest.mark.parametrize("method", ["multinomial", "topk"])
+def test_batched_sampled_search_equals_the_per_image_loop_on_the_same_draws(method):
+    """sample_method multinomial / topk (+ decoder noise) for all images at once: with the Gumbel / normal variates supplied as
+    tables, the batched search returns what the per-image HIP loop returns when its ``multinomial`` hook draws by the same rule
+    (top k of log p + the same variates; oracle.gumbel_topk, statistically identical to torch.multinomial) and its ``randn`` hook
+    reads the same normals.  The per-image loop with torch's own samplers is pinned to the reference by G9."""
+    import sat_amd  # noqa: F401
+    from sat_amd import model as M
+    from oracle import prng, sat_oracle as O
+    hp = O.default_hparams(vocab_size=83, encoder_dim=32, embed_dim=24, attention_dim=16, decoder_dim=40, decoder_layers=2)
+    torch.manual_seed(21)
+    dec = M.SATDecoder(hp).cuda().eval()
+    B, K, S, V, st, n, NL = 5, 4, 8, 83, 3, 40, 2
+    ann = torch.from_numpy(prng.uniform((B, 12, 32), 91, 0.0, 1.0)).cuda()
+    g = torch.Generator().manual_seed(5)
+    width = V if method == "multinomial" else st
+    u = torch.rand(S + 1, B * K, width, generator=g).clamp_(1e-9, 1 - 1e-7)
+    gum = (-torch.log(-torch.log(u))).cuda().contiguous()
+    normals = torch.randn(S + 1, NL, B * K, n, generator=g).cuda().contiguous()
+    noise = 0.3
+    kw = dict(beamk=K, max_gen_length=S, temperature=[1.0, 0.8], rescore_method="LN", return_all=True, sample_method=method, sample_topk=st, decoder_noise=noise)
+    got = dec.beam_decode_batched(ann, (3, 4), gumbel=gum, normals=normals, **kw)
+    for b in range(B):
+        state = {"step": 0, "nstep": 0}
+
+        def draw(probs, k, b=b, state=state):
+            state["step"] += 1                                            # called once per step >= 1
+            s_ = state["step"]
+            if method == "multinomial":
+                rows = probs.numel() // V
+                gv = gum[s_, b * K:b * K + rows, :].reshape(-1)
+            else:
+                rows = probs.numel() // st
+                gv = gum[s_, b * K:b * K + rows, :].reshape(-1)
+            return O.gumbel_topk(probs, k, gv)
+
+        def randn(shape, b=b, state=state):
+            s_ = state["nstep"]; state["nstep"] += 1                      # called once per step >= 0
+            return normals[s_, :, b * K:b * K + shape[1], :]
+
+        one = dec.beam_decode(ann[b:b + 1], (3, 4), multinomial=draw, randn=randn, **kw)
+        assert one[0][0] == got[0][b], (method, b, one[0][0], got[0][b])
+        for x, y in zip(one[1][0], got[1][b]):
+            assert abs(x - y) <= 2e-5 * max(1.0, abs(x))
+        for x, y in zip(one[2][0], got[2][b]):
+            assert x.shape == y.shape and float((x - y).abs().max()) <= 2e-5
+
+
+def test_batched_sampled_search_with_the_device_generator():
+    """no tables: the counter-based generator.  Same seed -> same captions, another seed -> other draws; every hypothesis is
+    well formed; forward() routes sampled decoding through the batched search."""
+    import sat_amd  # noqa: F401
+    from sat_amd import model as M
+    from oracle import prng, sat_oracle as O
+    hp = O.default_hparams(vocab_size=83, encoder_dim=32, embed_dim=24, attention_dim=16, decoder_dim=40)
+    torch.manual_seed(22)
+    dec = M.SATDecoder(hp).cuda().eval()
+    ann = torch.from_numpy(prng.uniform((7, 12, 32), 92, 0.0, 1.0)).cuda()
+    END = hp.vocab_stoi["<END>"]
+    for method in ("multinomial", "topk"):
+        kw = dict(beamk=4, max_gen_length=10, temperature=1.0, return_all=True, sample_method=method, sample_topk=3, decoder_noise=0.2)
+        a = dec.beam_decode_batched(ann, (3, 4), seed=7, **kw)
+        b = dec.beam_decode_batched(ann, (3, 4), seed=7, **kw)
+        c = dec.beam_decode_batched(ann, (3, 4), seed=8, **kw)
+        assert a[0] == b[0] and a[1] == b[1]
+        assert a[0] != c[0]
+        for caps, scores, alphas in zip(a[0], a[1], a[2]):
+            assert len(caps) == 4 and len(scores) == 4
+            for cap, sc, al in zip(caps, scores, alphas):
+                assert 0 < len(cap) <= 11 and all(0 <= t < 83 for t in cap) and END not in cap[:-1] and sc == sc
+                assert al.shape[0] == len(cap) and float((al.sum((1, 2)) - 1).abs().max()) < 1e-4
