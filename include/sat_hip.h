@@ -29,6 +29,9 @@ extern "C" {
 #define SAT_HIP_ABI_VERSION 13
 
 int sat_abi_version(void);
+/* dev aid: after every kernel launch wait for the device and print the launch's name to stderr (a device fault then points at the
+ * launch after the last printed line).  Also switched on by SAT_TRACE_LAUNCH=1.  Not for captured streams. */
+int sat_debug_trace_launches(int32_t on);
 const char* sat_last_error(void);
 
 /* ------------------------------------------------------------------ kernel timing for the roofline report

@@ -7,6 +7,7 @@
 
 namespace sat {
 static thread_local char g_err[512] = {0};
+int& trace_launches() { static int on = getenv("SAT_TRACE_LAUNCH") ? 1 : 0; return on; }
 char* last_error_buf() { return g_err; }
 int fail(int code, const char* fmt, ...) {
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
@@ -19,6 +20,7 @@ using namespace sat;
 extern "C" {
 
 int sat_abi_version(void) { return SAT_HIP_ABI_VERSION; }
+int sat_debug_trace_launches(int32_t on) { sat::trace_launches() = on ? 1 : 0; return SAT_OK; }
 const char* sat_last_error(void) { return last_error_buf(); }
 
 static int gemm_from_desc(const sat_gemm_desc* d, const sat_gemm_types* t, void* stream);

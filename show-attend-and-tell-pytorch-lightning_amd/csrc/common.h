@@ -1,5 +1,6 @@
 // Shared helpers for the SAT HIP library (gfx950 / MI355X only).
 #pragma once
+#include <cstdio>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -30,7 +31,12 @@ int fail(int code, const char* fmt, ...);
         if (_rc != 0) return _rc;    \
     } while (0)
 
+int& trace_launches();      // api.hip: sat_debug_trace_launches
 inline int launch_ok(const char* what) {
+    if (trace_launches()) {        // dev: wait for the kernel and name it, so that a device fault points at the launch after the last line
+        hipError_t s = hipDeviceSynchronize();
+        fprintf(stderr, "[sat] %s: %s\n", what, hipGetErrorString(s));
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SAT_EHIP, "launch %s -> %s", what, hipGetErrorString(e));
     return SAT_OK;

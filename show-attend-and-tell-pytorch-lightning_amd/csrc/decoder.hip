@@ -736,11 +736,16 @@ int decoder_beam_batched(const sat_decoder_dims& d, const sat_decoder_params& p,
     const int B = d.B, N = B * K, n = d.n, A = d.A, D = d.D, m = d.m, V = d.V, NL = d.layers, HCW = A + D + 4 * n;
     const int START = special_host[0], PAD = special_host[1], END = special_host[2], UNK = special_host[3];
     // ---- once per batch: stacked step weights, att_enc, initial states of the K copies of every image
-    SAT_CHECK_HIP(hipMemcpyAsync(w.Wcat, p.att_dec, (size_t)A * n * 4, hipMemcpyDeviceToDevice, st));
-    SAT_CHECK_HIP(hipMemcpyAsync(w.Wcat + (long)A * n, p.beta_w, (size_t)D * n * 4, hipMemcpyDeviceToDevice, st));
-    SAT_CHECK_HIP(hipMemcpyAsync(w.Wcat + (long)(A + D) * n, p.w_hh, (size_t)4 * n * n * 4, hipMemcpyDeviceToDevice, st));
-    SAT_CHECK_HIP(hipMemsetAsync(w.bcat, 0, (size_t)A * 4, st));
-    SAT_CHECK_HIP(hipMemcpyAsync(w.bcat + A, p.beta_b, (size_t)D * 4, hipMemcpyDeviceToDevice, st));
+    auto copy_f = [&](float* dst, const float* src, long n_) {
+        hipLaunchKernelGGL(copy_words_kernel, dim3(cdiv(n_, 256)), dim3(256), 0, st, reinterpret_cast<unsigned*>(dst), reinterpret_cast<const unsigned*>(src), n_);
+    };
+    auto zero_w = [&](void* dst, long n_) { hipLaunchKernelGGL(fill_int_kernel, dim3(cdiv(n_, 256)), dim3(256), 0, st, reinterpret_cast<int*>(dst), n_, 0); };
+    copy_f(w.Wcat, p.att_dec, (long)A * n);
+    copy_f(w.Wcat + (long)A * n, p.beta_w, (long)D * n);
+    copy_f(w.Wcat + (long)(A + D) * n, p.w_hh, 4L * n * n);
+    zero_w(w.bcat, A);
+    copy_f(w.bcat + A, p.beta_b, D);
+    SAT_TRY(launch_ok("beam: step weights"));
     hipLaunchKernelGGL(add_kernel, dim3(cdiv(4 * n, 256)), dim3(256), 0, st, w.bcat + A + D, p.b_ih, p.b_hh, (long)4 * n);
     SAT_TRY(launch_ok("bias add"));
     for (int l = 1; l < NL; ++l) {
@@ -759,14 +764,15 @@ int decoder_beam_batched(const sat_decoder_dims& d, const sat_decoder_params& p,
     SAT_TRY(launch_ok("init_expand_images"));
     hipLaunchKernelGGL(fill_int_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, w.klive, (long)B, K);
     SAT_TRY(launch_ok("fill klive"));
-    SAT_CHECK_HIP(hipMemsetAsync(tok_in, 0, (size_t)(max_gen_length + 2) * N * 4, st));       // rows that are not live still index the embedding table
-    SAT_CHECK_HIP(hipMemsetAsync(prev_row, 0, (size_t)(max_gen_length + 2) * N * 4, st));
+    zero_w(tok_in, (long)(max_gen_length + 2) * N);       // rows that are not live still index the embedding table
+    zero_w(prev_row, (long)(max_gen_length + 2) * N);
     hipLaunchKernelGGL(fill_int_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, tok_in, (long)N, START);
     SAT_TRY(launch_ok("fill start tokens"));
-    SAT_CHECK_HIP(hipMemsetAsync(w.h2, 0, (size_t)NL * N * n * 4, st));
-    SAT_CHECK_HIP(hipMemsetAsync(w.c2, 0, (size_t)NL * N * n * 4, st));
-    SAT_CHECK_HIP(hipMemsetAsync(w.top, 0, (size_t)N * 4, st));
-    SAT_CHECK_HIP(hipMemsetAsync(fin_count, 0, (size_t)B * 4, st));
+    zero_w(w.h2, (long)NL * N * n);
+    zero_w(w.c2, (long)NL * N * n);
+    zero_w(w.top, N);
+    zero_w(fin_count, B);
+    SAT_TRY(launch_ok("beam: clears"));
 
     float *h = w.h, *c = w.c, *h2 = w.h2, *c2 = w.c2;
     for (int step = 0; step <= max_gen_length; ++step) {

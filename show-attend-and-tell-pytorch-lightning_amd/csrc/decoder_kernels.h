@@ -46,6 +46,12 @@ __global__ void cast_block_bf16_kernel(const float* __restrict__ src, long ld, _
     *reinterpret_cast<b4*>(dst + r * cols + c) = o;
 }
 __global__ void set4_int_kernel(int* p, int a, int b, int c, int d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
+// plain copies / clears as kernels: the batched beam search enqueues nothing but kernel launches, so that a captured stream
+// (hipGraph) is one linear chain of kernel nodes (memset / memcpy nodes were seen to run out of order inside a replayed graph)
+__global__ void copy_words_kernel(unsigned* __restrict__ dst, const unsigned* __restrict__ src, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
 __global__ void fill_int_kernel(int* p, long n, int v) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;

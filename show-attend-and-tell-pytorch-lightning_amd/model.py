@@ -271,7 +271,7 @@ class SATDecoder(nn.Module):
 
     @torch.no_grad()
     def beam_decode_batched(self, ann_bld, hw, beamk=3, max_gen_length=32, temperature=1.0, rescore_method=None, rescore_reward=0.5,
-                            return_all=False, sample_method="beam", sample_topk=3, decoder_noise=None, seed=None, gumbel=None, normals=None):
+                            return_all=False, sample_method="beam", sample_topk=3, decoder_noise=None, seed=None, gumbel=None, normals=None, graph=False):
         """The same beam search as ``beam_decode`` ("beam" sampling, no decoder noise) for ALL images of the batch at once
         (SURVEY 8f row 2): one library call enqueues every decode step for the (B, beamk) hypothesis rows -- per-image top-k,
         completed hypotheses leaving their image's beam, cut at ``max_gen_length`` -- without a host round trip; the host reads
@@ -279,7 +279,10 @@ class SATDecoder(nn.Module):
         ``sample_method`` "multinomial" / "topk" (model.py:360-379) and ``decoder_noise`` (model.py:322-324) run in the same call:
         the hypotheses are drawn on the device as the top k of log p + Gumbel noise (an ordered sample without replacement, like
         ``torch.multinomial``) from a counter-based generator seeded by ``seed`` (default: one draw from torch's CPU generator);
-        ``gumbel`` / ``normals`` replace the generator by tables (layouts: include/sat_hip.h, sat_beam_sampling)."""
+        ``gumbel`` / ``normals`` replace the generator by tables (layouts: include/sat_hip.h, sat_beam_sampling).
+        ``graph=True`` ("beam" sampling without noise): the call's ~25 launches per decode step are captured once per (batch
+        shape, beam, length, temperatures, weights) into a hipGraph over static buffers and replayed - the same kernels with the
+        same arguments, one submission."""
         import ctypes as C
         import numpy as np
         assert sample_method in ("beam", "multinomial", "topk")
@@ -301,12 +304,7 @@ class SATDecoder(nn.Module):
                                layers=int(hp.decoder_layers))
         w, _keep = self._params_struct()
         ws_bytes = lib.sat_beam_search_workspace_bytes(C.byref(dims), K)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         i32 = dict(dtype=torch.int32, device=dev); f32 = dict(dtype=torch.float32, device=dev)
-        tok_in = torch.empty(S + 2, B, K, **i32); prev_row = torch.empty(S + 2, B, K, **i32)
-        alpha_hist = torch.empty(S + 1, B, K, Lc, **f32)
-        fin_count = torch.empty(B, **i32); fin_step = torch.empty(B, K, **i32); fin_row = torch.empty(B, K, **i32)
-        fin_score = torch.empty(B, K, **f32); fin_mean = torch.empty(B, K, **f32)
         smp = None
         if sample_method != "beam" or decoder_noise:
             if seed is None:
@@ -318,9 +316,42 @@ class SATDecoder(nn.Module):
             smp = L.BeamSampling(method={"beam": 0, "multinomial": 1, "topk": 2}[sample_method], sample_topk=int(sample_topk), seed=int(seed),
                                  gumbel=(gumbel.data_ptr() if gumbel is not None else None), decoder_noise=float(decoder_noise or 0.0),
                                  normals=(normals.data_ptr() if normals is not None else None))
-        L.check(lib.sat_beam_search_sampled(C.byref(dims), C.byref(w), L.ptr(ann_bld), K, S, tarr, len(temps), ids, C.byref(smp) if smp is not None else None,
-                                            L.ptr(tok_in), L.ptr(prev_row), L.ptr(alpha_hist), L.ptr(fin_count), L.ptr(fin_step), L.ptr(fin_row),
-                                            L.ptr(fin_score), L.ptr(fin_mean), L.ptr(ws), ws_bytes, L.stream_ptr()), "sat_beam_search_sampled")
+
+        def buffers():
+            return dict(ws=torch.empty(ws_bytes, dtype=torch.uint8, device=dev), tok_in=torch.empty(S + 2, B, K, **i32),
+                        prev_row=torch.empty(S + 2, B, K, **i32), alpha_hist=torch.empty(S + 1, B, K, Lc, **f32), fin_count=torch.empty(B, **i32),
+                        fin_step=torch.empty(B, K, **i32), fin_row=torch.empty(B, K, **i32), fin_score=torch.empty(B, K, **f32),
+                        fin_mean=torch.empty(B, K, **f32))
+
+        def enqueue(ann, o):
+            L.check(lib.sat_beam_search_sampled(C.byref(dims), C.byref(w), L.ptr(ann), K, S, tarr, len(temps), ids, C.byref(smp) if smp is not None else None,
+                                                L.ptr(o["tok_in"]), L.ptr(o["prev_row"]), L.ptr(o["alpha_hist"]), L.ptr(o["fin_count"]), L.ptr(o["fin_step"]),
+                                                L.ptr(o["fin_row"]), L.ptr(o["fin_score"]), L.ptr(o["fin_mean"]), L.ptr(o["ws"]), ws_bytes, L.stream_ptr()),
+                    "sat_beam_search_sampled")
+
+        if graph and smp is None:
+            cache = self.__dict__.setdefault("_beam_graphs", {})
+            key = (B, Lc, D, K, S, tuple(float(t) for t in temps), int(dims.precision), str(dev), tuple(t.data_ptr() for t in _keep.values() if torch.is_tensor(t)))
+            ent = cache.get(key)
+            if ent is None:
+                o = buffers()
+                ann_s = ann_bld.clone()
+                enqueue(ann_s, o)                       # eager once: validates the arguments and sets the kernel attributes before the capture
+                torch.cuda.synchronize(dev)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    enqueue(ann_s, o)
+                while len(cache) >= 4:                  # a few shapes at most: every entry pins its buffers
+                    cache.pop(next(iter(cache)))
+                ent = cache[key] = (g, ann_s, o, _keep)
+            g, ann_s, o = ent[0], ent[1], ent[2]
+            ann_s.copy_(ann_bld)
+            g.replay()
+        else:
+            o = buffers()
+            enqueue(ann_bld, o)
+        tok_in, prev_row, alpha_hist = o["tok_in"], o["prev_row"], o["alpha_hist"]
+        fin_count, fin_step, fin_row, fin_score, fin_mean = o["fin_count"], o["fin_step"], o["fin_row"], o["fin_score"], o["fin_mean"]
         tok_in, prev_row = tok_in.cpu().numpy(), prev_row.cpu().numpy()
         alpha_np = alpha_hist.cpu().numpy()
         fin_count, fin_step, fin_row = fin_count.cpu().numpy(), fin_step.cpu().numpy(), fin_row.cpu().numpy()

@@ -248,3 +248,33 @@ def test_batched_sampled_search_with_the_device_generator():
             for cap, sc, al in zip(caps, scores, alphas):
                 assert 0 < len(cap) <= 11 and all(0 <= t < 83 for t in cap) and END not in cap[:-1] and sc == sc
                 assert al.shape[0] == len(cap) and float((al.sum((1, 2)) - 1).abs().max()) < 1e-4
+
+
+def test_batched_beam_search_replayed_from_a_hipgraph():
+    """graph=True captures the search once and replays it: identical output to the eager call, also for new annotations in the
+    static buffer, after an in-place weight update (the graph reads the live parameters), and for a second shape."""
+    import sat_amd  # noqa: F401
+    from sat_amd import model as M
+    from oracle import prng, sat_oracle as O
+    hp = O.default_hparams(vocab_size=83, encoder_dim=32, embed_dim=24, attention_dim=16, decoder_dim=40)
+    torch.manual_seed(11)
+    dec = M.SATDecoder(hp).cuda().eval()
+    kw = dict(beamk=4, max_gen_length=9, temperature=[1.0, 0.7], rescore_method="BAR", return_all=True)
+
+    def same(a, b):
+        assert a[0] == b[0] and a[1] == b[1] and a[3] == b[3]
+        for u, v in zip([x for e in a[2] for x in e], [x for e in b[2] for x in e]):
+            assert torch.equal(u, v)
+
+    for seed in (55, 56, 57):
+        ann = torch.from_numpy(prng.uniform((9, 12, 32), seed, 0.0, 1.0)).cuda()
+        same(dec.beam_decode_batched(ann, (3, 4), **kw), dec.beam_decode_batched(ann, (3, 4), graph=True, **kw))
+    assert len(dec._beam_graphs) == 1
+    with torch.no_grad():
+        dec.output.output.weight.mul_(1.3); dec.lstm.weight_hh_l0.add_(0.01)
+    same(dec.beam_decode_batched(ann, (3, 4), **kw), dec.beam_decode_batched(ann, (3, 4), graph=True, **kw))
+    assert len(dec._beam_graphs) == 1
+    ann5 = torch.from_numpy(prng.uniform((5, 12, 32), 58, 0.0, 1.0)).cuda()
+    same(dec.beam_decode_batched(ann5, (3, 4), **kw), dec.beam_decode_batched(ann5, (3, 4), graph=True, **kw))
+    same(dec.beam_decode_batched(ann, (3, 4), **kw), dec.beam_decode_batched(ann, (3, 4), graph=True, **kw))
+    assert len(dec._beam_graphs) == 2

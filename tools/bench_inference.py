@@ -32,6 +32,14 @@ with torch.no_grad():
         assert capsb == caps
         print("beam %d: batched search, decode-only %.0f images/s (%.2f ms per 64 images incl. host back-trace), %.1fx the per-image loop"
               % (beamk, 64 / dtb, dtb * 1e3, dt / dtb))
+        for _ in range(2):
+            model.beam_decode_batched(ann, hw, beamk=beamk, max_gen_length=20, graph=True)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(5):
+            capsg, _, _, _ = model.beam_decode_batched(ann, hw, beamk=beamk, max_gen_length=20, graph=True)
+        torch.cuda.synchronize(); dtg = (time.perf_counter() - t0) / 5
+        assert capsg == caps
+        print("beam %d: batched search replayed from a hipGraph, decode-only %.0f images/s (%.2f ms per 64 images incl. host back-trace)" % (beamk, 64 / dtg, dtg * 1e3))
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(3):
             model.caption(img, beamk=beamk, max_gen_length=20)
