@@ -347,8 +347,13 @@ __global__ __launch_bounds__(NT) void gemm_glds_kernel(BArgs a) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
             }
             if (more) advance_tile();
+            if (S == 1 && it + 1 < T) {            // one-stage ring with several k-tiles: refill the only stage once every wave has read it
+                __syncthreads();
+                if (WG) { fill_tab(0, it + 1); __syncthreads(); }
+                issue(0, 0);
+            }
             // pixel table of tile it + S goes where tile it's was (consumed S - 1 iterations ago)
-            if (WG) fill_tab(cur, it + S);
+            if (WG && S > 1) fill_tab(cur, it + S);
             cur = (cur + 1 == S) ? 0 : cur + 1;
             nxt = (nxt + 1 == S) ? 0 : nxt + 1;
         }
@@ -414,7 +419,10 @@ int launch_gemm_glds(const BArgs& k0, int amode, int bmode, int c_bf16, int BMt,
     // on, one workgroup per CU with three tiles in flight hides the HBM / L2 latency that a cold operand costs
     const int ktiles = cdiv(k.kchunk < k.K ? k.kchunk : k.K, 64);
     // a single k-tile needs one stage: less LDS, a third workgroup per CU for the streaming 1x1 layers with 64 input channels
-    k.nstage = force_stages ? force_stages : (ktiles >= deep_from ? 4 : (ktiles == 1 ? 1 : 2));
+    // short reductions into a bf16 result (<= 168 VGPRs): one stage leaves room for a third workgroup per CU, which hides more of
+    // the launch / load / store phases of these latency-bound tiles than the second stage does
+    static const int s1_upto = getenv("SAT_GLDS_S1_UPTO") ? atoi(getenv("SAT_GLDS_S1_UPTO")) : 1;
+    k.nstage = force_stages ? force_stages : (ktiles >= deep_from ? 4 : ((ktiles == 1 || (c_bf16 && ktiles <= s1_upto)) ? 1 : 2));
     k.rotate = rotate;
     if (k.nstage < 1) k.nstage = 1;
     if (k.nstage > 4) k.nstage = 4;
