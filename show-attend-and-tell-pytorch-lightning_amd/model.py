@@ -510,7 +510,8 @@ class SAT(SATDecoder, _Base):
             ann_bld, hw = self.encode(img)
             if max_gen_length >= 1:        # every image at once; sampled continuations and decoder noise draw from the device generator
                 return self.beam_decode_batched(ann_bld.contiguous(), hw, beamk, max_gen_length, temperature, rescore_method, rescore_reward, return_all,
-                                                sample_method=sample_method, sample_topk=sample_topk, decoder_noise=decoder_noise)
+                                                sample_method=sample_method, sample_topk=sample_topk, decoder_noise=decoder_noise,
+                                                graph=bool(self.__dict__.get("beam_graph", False)))       # model.beam_graph = True: hipGraph replay
             return self.beam_decode(ann_bld.contiguous(), hw, beamk, max_gen_length, temperature, sample_method, sample_topk,
                                     decoder_noise, rescore_method, rescore_reward, return_all)
 
