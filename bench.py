@@ -186,9 +186,21 @@ def main():
         torch.cuda.synchronize(); warm_done += 1
         if warm_done <= 3 or warm_done % 10 == 0:
             log("warm-up step %d done" % warm_done)
+    # ---- which kernel family dominates: HIP events on the launch stream around every instrumented launch, two untimed steps
+    prof_steps = 2
+    _lib.profile_start()
+    for _ in range(prof_steps):
+        step()
+    torch.cuda.synchronize()
+    entries = sorted(_lib.profile_stop(), key=lambda e: -e["total_ms"])
+    dom_name = entries[0]["name"] if entries else None
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    # ---- the timed region; the dominant family alone stays instrumented inside it (an event pair per launch of that family)
+    if os.environ.get("SAT_BENCH_NO_INREGION") == "1":       # dev: A/B the cost of the in-region event pairs
+        dom_name = None
+    _lib.profile_start(only=dom_name) if dom_name else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -196,6 +208,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    timed = {e["name"]: e for e in _lib.profile_stop()} if dom_name else {}
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -203,20 +216,11 @@ def main():
     loss_val = float(out["loss"].item())
     log("timed region: %.1f ms/step" % (dt / args.steps * 1e3))
 
-    # ---- roofline of the dominant kernel: HIP events on the launch stream, two instrumented steps
-    prof_steps = 2
-    _lib.profile_start()
-    for _ in range(prof_steps):
-        step()
-    torch.cuda.synchronize()
-    entries = sorted(_lib.profile_stop(), key=lambda e: -e["total_ms"])
-    if world > 1:
-        dist.barrier()
-
     if rank == 0:
         ms = dt / args.steps * 1e3
         caps_per_s = world * B * R / (dt / args.steps)
-        dom = entries[0] if entries else None
+        dom = timed.get(dom_name) or (entries[0] if entries else None)          # the dominant family as measured INSIDE the timed region
+        dom_steps = args.steps if dom_name in timed else prof_steps
         roof = None
         if dom:
             hbm_bound = dom["flops"] == 0           # streaming kernels (BatchNorm passes) are instrumented with bytes only
@@ -233,9 +237,10 @@ def main():
                     "achieved": round(gbs if hbm_bound else tf, 2), "peak": PEAK_HBM_GBS if hbm_bound else peak,
                     "unit": "GB/s" if hbm_bound else "TFLOP/s",
                     "frac": round((gbs / PEAK_HBM_GBS) if hbm_bound else (tf / peak), 4), "traffic": traffic,
-                    "avg_launch_us": round(dom["total_ms"] * 1e3 / dom["launches"], 2), "launches_per_step": dom["launches"] // prof_steps,
+                    "avg_launch_us": round(dom["total_ms"] * 1e3 / dom["launches"], 2), "launches_per_step": dom["launches"] // dom_steps,
                     "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"], "flops_per_launch": dom["flops"] / dom["launches"],
-                    "measured_on": "%d instrumented steps right after the timed region (events add launch overhead)" % prof_steps,
+                    "measured_on": ("HIP events on the launch stream around every launch of this family inside the timed region (%d steps); "
+                                    "`top`: every instrumented family over %d untimed steps before it" % (dom_steps, prof_steps)),
                     "top": [{"kernel": e["name"], "ms_per_step": round(e["total_ms"] / prof_steps, 3),
                              "tflops": round(e["flops"] / (e["total_ms"] * 1e-3) / 1e12, 2) if e["total_ms"] > 0 else None,
                              "gbytes_per_s": round(e["bytes"] / (e["total_ms"] * 1e-3) / 1e9, 1) if e["total_ms"] > 0 else None}

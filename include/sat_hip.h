@@ -45,6 +45,8 @@ typedef struct sat_profile_entry {
     double bytes;         /* algorithmic bytes of those launches       */
 } sat_profile_entry;
 int sat_profile_start(void);
+/* the same, recording only the scopes of one family (negligible overhead: used inside bench.py's timed region) */
+int sat_profile_start_only(const char* name);
 int sat_profile_stop(sat_profile_entry* out, int32_t max_entries, int32_t* n_out);
 
 /* ------------------------------------------------------------------ GEMM family

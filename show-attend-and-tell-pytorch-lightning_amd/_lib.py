@@ -182,11 +182,16 @@ SYMBOLS.update({"sat_stem_tail_fwd_t": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _
 SYMBOLS.update({"sat_image_batch_workspace_bytes": (C.c_size_t, [_vp, _i32, _i32, _i32]),
                 "sat_image_batch_transform": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _f, _vp, _vp, _vp, C.c_size_t, _vp])})
 SYMBOLS.update({"sat_profile_start": (C.c_int, []),
+                "sat_profile_start_only": (C.c_int, [C.c_char_p]),
                 "sat_profile_stop": (C.c_int, [C.POINTER(ProfileEntry), _i32, C.POINTER(C.c_int32)])})
 
 
-def profile_start():
-    check(lib().sat_profile_start(), "sat_profile_start")
+def profile_start(only=None):
+    """record every instrumented scope, or only the family ``only``"""
+    if only:
+        check(lib().sat_profile_start_only(only.encode()), "sat_profile_start_only")
+    else:
+        check(lib().sat_profile_start(), "sat_profile_start")
 
 
 def profile_stop(max_entries=256):

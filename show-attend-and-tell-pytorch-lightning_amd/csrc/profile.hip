@@ -12,6 +12,7 @@ namespace {
 struct Rec { std::string name; hipEvent_t e0, e1; double flops, bytes; };
 std::mutex g_mu;
 bool g_on = false;
+std::string g_only;          // non-empty: only scopes of this name are recorded
 std::vector<Rec> g_recs;
 }  // namespace
 
@@ -20,6 +21,7 @@ bool profile_enabled() { return g_on; }
 ProfScope::ProfScope(const char* name, double flops, double bytes, hipStream_t stream) : slot(-1), st(stream) {
     if (!g_on) return;
     std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_only.empty() && g_only != name) return;
     Rec r; r.name = name; r.flops = flops; r.bytes = bytes;
     if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
     hipEventRecord(r.e0, st);
@@ -36,8 +38,16 @@ ProfScope::~ProfScope() {
 using namespace sat;
 
 extern "C" {
+int sat_profile_start_only(const char* name) {
+    if (!name || !*name) return sat_profile_start();
+    sat_profile_start();
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_only = name;
+    return 0;
+}
 int sat_profile_start(void) {
     std::lock_guard<std::mutex> lk(g_mu);
+    g_only.clear();
     for (auto& r : g_recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
     g_recs.clear();
     g_on = true;
