@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SAT_HIP_ABI_VERSION 13
+#define SAT_HIP_ABI_VERSION 14
 
 int sat_abi_version(void);
 /* dev aid: after every kernel launch wait for the device and print the launch's name to stderr (a device fault then points at the
@@ -229,6 +229,7 @@ typedef struct sat_conv_geom {
     int32_t N, H, W, C;     /* input  (N, H, W, C), C % 4 == 0                    */
     int32_t K, R, S;        /* filter (K, R, S, C), K % 4 == 0                    */
     int32_t stride, pad;    /* output (N, P, Q, K), P = (H + 2 pad - R)/stride + 1 */
+    int32_t stride_w;       /* 0: = stride.  Otherwise the horizontal stride (bf16 forward / weight gradient only): the stem's tap-pair view */
 } sat_conv_geom;
 /* nn.Conv2d forward / autograd (input gradient, weight gradient) as implicit GEMMs on MFMA */
 int sat_conv2d_fwd(const float* x, const float* w, const float* bias /* or NULL */, float* y, const sat_conv_geom* g, void* stream);
@@ -261,6 +262,15 @@ int sat_stem_tail_bwd_t(int32_t dtype, const void* dy_pool, const uint8_t* argma
 /* torchvision Normalize(mean, std) (model.py:59) fused with NCHW -> NHWC and 3 -> 4 channel padding */
 int sat_image_normalize_nhwc4(const float* img_nchw, float* out_nhwc4, int32_t N, int32_t H, int32_t W,
                               const float* mean3_host, const float* std3_host, void* stream);
+/* bf16 stem as a 7 x 4 convolution over PAIRS of pixels (model.py:19-29 keeps torchvision's conv1: 7x7, stride 2, pad 3, 3 channels).
+ * With 4 stored channels a pixel is 8 bytes, so the 16 bytes one lane gathers hold two horizontally adjacent pixels = two filter
+ * taps.  The normalised image is written zero-padded by 3 on every side, (N, H + 6, W + 6, 4) bf16; viewed as (N, H + 6, (W + 6) / 2, 8)
+ * the stem is R = 7, S = 4, C = 8, stride 2 vertically and 1 horizontally (stride_w), no padding: 224 products per output instead
+ * of the 392 of an 8-channel layout (5 of 8 channels zero).  W must be even.  filter_pairs: (K, 7, 7, 3) fp32 -> (K, 7, 4, 8) bf16
+ * (tap 2s in slots 0-2, tap 2s + 1 in slots 4-6, the eighth tap and slots 3 / 7 zero); grad_unpairs: its fp32 gradient back. */
+int sat_image_normalize_nhwc4_padded_bf16(const float* img_nchw, void* out, int32_t N, int32_t H, int32_t W, const float* mean3_host, const float* std3_host, void* stream);
+int sat_stem_filter_pairs(const float* w3, void* w_pairs_bf16, int32_t K, void* stream);
+int sat_stem_filter_grad_unpairs(const float* dw_pairs, float* dw3, int32_t K, void* stream);
 /* (pixels, 3) <-> (pixels, 4) zero padded; used for the stem filters */
 int sat_pad_channels_3to4(const float* src, float* dst, int64_t pixels, int32_t inverse, void* stream);
 /* nn.BatchNorm2d in training mode over a (rows, C) NHWC view, fused with the residual add and ReLU of the

@@ -118,7 +118,7 @@ class GemmTypes(C.Structure):
 
 
 class ConvGeom(C.Structure):
-    _fields_ = [(k, C.c_int32) for k in ("N", "H", "W", "C", "K", "R", "S", "stride", "pad")]
+    _fields_ = [(k, C.c_int32) for k in ("N", "H", "W", "C", "K", "R", "S", "stride", "pad", "stride_w")]
 
 
 _vp, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -148,6 +148,9 @@ SYMBOLS.update({
     "sat_maxpool3x3s2_bwd_t": (C.c_int, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "sat_cast_f32_to_bf16": (C.c_int, [_vp, _vp, _i64, _vp]),
     "sat_image_normalize_nhwc8_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp]),
+    "sat_image_normalize_nhwc4_padded_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp]),
+    "sat_stem_filter_pairs": (C.c_int, [_vp, _vp, _i32, _vp]),
+    "sat_stem_filter_grad_unpairs": (C.c_int, [_vp, _vp, _i32, _vp]),
     "sat_stem_filter_pad": (C.c_int, [_vp, _vp, _i64, _vp]),
     "sat_stem_filter_grad_unpad": (C.c_int, [_vp, _vp, _i64, _vp]),
     "sat_maxpool3x3s2_fwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
@@ -217,8 +220,8 @@ def lib():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(handle, name)          # AttributeError if the export is missing
             fn.restype, fn.argtypes = res, args
-        if handle.sat_abi_version() != 13:
-            raise SatHipError("libsat_hip.so ABI version %d != 13 (rebuild: make -C csrc)" % handle.sat_abi_version())
+        if handle.sat_abi_version() != 14:
+            raise SatHipError("libsat_hip.so ABI version %d != 14 (rebuild: make -C csrc)" % handle.sat_abi_version())
         _lib = handle
     return _lib
 

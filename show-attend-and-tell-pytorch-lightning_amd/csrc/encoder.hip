@@ -53,6 +53,37 @@ __global__ void unpad_c8_to_c3_kernel(const float* __restrict__ w8, float* __res
     w3[3 * e] = w8[8 * e]; w3[3 * e + 1] = w8[8 * e + 1]; w3[3 * e + 2] = w8[8 * e + 2];
 }
 
+// bf16 stem, tap-pair layout (include/sat_hip.h): normalised image zero-padded by 3, 4 stored channels
+__global__ void normalize_nhwc4_padded_bf16_kernel(const float* __restrict__ img, __bf16* __restrict__ out, int H, int W, long total,
+                                                   float m0, float m1, float m2, float s0, float s1, float s2) {
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;          // over padded pixels
+    if (e >= total) return;
+    const int Wp = W + 6, Hp = H + 6;
+    const int xp = (int)(e % Wp); const long t = e / Wp; const int yp = (int)(t % Hp); const long n = t / Hp;
+    const int x = xp - 3, y = yp - 3;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H) {
+        const long hw = (long)H * W; const float* src = img + n * 3 * hw + (long)y * W + x;
+        v = make_float4((src[0] - m0) / s0, (src[hw] - m1) / s1, (src[2 * hw] - m2) / s2, 0.f);
+    }
+    st4<__bf16>(out, e, v);
+}
+__global__ void stem_filter_pairs_kernel(const float* __restrict__ w3, __bf16* __restrict__ wp, long n) {      // n = K * 7 * 4 pairs
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int sp = (int)(e % 4); const long kr = e / 4;            // (k, r) row of seven taps
+    const float* a = w3 + (kr * 7 + 2 * sp) * 3;
+    st4<__bf16>(wp, 2 * e, make_float4(a[0], a[1], a[2], 0.f));
+    st4<__bf16>(wp, 2 * e + 1, sp < 3 ? make_float4(a[3], a[4], a[5], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f));
+}
+__global__ void stem_filter_grad_unpairs_kernel(const float* __restrict__ dwp, float* __restrict__ dw3, long n) {   // n = K * 7 * 7 taps
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int s = (int)(e % 7); const long kr = e / 7;
+    const float* a = dwp + ((kr * 4 + (s >> 1)) * 8 + (s & 1) * 4);
+    dw3[3 * e] = a[0]; dw3[3 * e + 1] = a[1]; dw3[3 * e + 2] = a[2];
+}
+
 // ------------------------------------------------------------------ input: NCHW [0,1] -> normalised NHWC, C padded 3 -> 4
 __global__ void normalize_nhwc4_kernel(const float* __restrict__ img, float* __restrict__ out, int H, int W, long total,
                                        float m0, float m1, float m2, float s0, float s1, float s2) {
@@ -731,9 +762,9 @@ using namespace sat;
 
 static int conv_geom(const sat_conv_geom* g, ConvGeom& o, int vec = 4) {
     SAT_REQUIRE(g, "conv: null geometry");
-    o.N = g->N; o.H = g->H; o.W = g->W; o.C = g->C; o.K = g->K; o.R = g->R; o.S = g->S; o.stride = g->stride; o.pad = g->pad;
+    o.N = g->N; o.H = g->H; o.W = g->W; o.C = g->C; o.K = g->K; o.R = g->R; o.S = g->S; o.stride = g->stride; o.pad = g->pad; o.sw = (g->stride_w > 0 && g->stride_w != g->stride) ? g->stride_w : 0;
     SAT_REQUIRE(o.N > 0 && o.H > 0 && o.W > 0 && o.C > 0 && o.K > 0 && o.R > 0 && o.S > 0 && o.stride > 0 && o.pad >= 0, "conv: bad geometry");
-    o.P = (o.H + 2 * o.pad - o.R) / o.stride + 1; o.Q = (o.W + 2 * o.pad - o.S) / o.stride + 1;
+    o.P = (o.H + 2 * o.pad - o.R) / o.stride + 1; o.Q = (o.W + 2 * o.pad - o.S) / (o.sw ? o.sw : o.stride) + 1;
     SAT_REQUIRE(o.P > 0 && o.Q > 0, "conv: empty output");
     SAT_REQUIRE(o.C % vec == 0 && o.K % vec == 0, "conv: C=%d and K=%d must be multiples of %d (pad the stem channels)", o.C, o.K, vec);
     return SAT_OK;
@@ -1118,6 +1149,26 @@ int sat_image_normalize_nhwc8_bf16(const float* img_nchw, void* out_nhwc8, int32
     hipLaunchKernelGGL(normalize_nhwc8_bf16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, img_nchw, (bf*)out_nhwc8, H, W, total,
                        mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2]);
     return launch_ok("normalize_nhwc8_bf16");
+}
+int sat_image_normalize_nhwc4_padded_bf16(const float* img_nchw, void* out, int32_t N, int32_t H, int32_t W, const float* mean3_host, const float* std3_host, void* stream) {
+    if (!img_nchw || !out || !mean3_host || !std3_host) return fail(SAT_EINVAL, "image_normalize: null pointer");
+    SAT_REQUIRE(N > 0 && H > 0 && W > 0 && W % 2 == 0, "image_normalize (padded): N=%d H=%d W=%d (W must be even)", N, H, W);
+    const long total = (long)N * (H + 6) * (W + 6);
+    hipLaunchKernelGGL(normalize_nhwc4_padded_bf16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, img_nchw, (bf*)out, H, W, total,
+                       mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2]);
+    return launch_ok("normalize_nhwc4_padded_bf16");
+}
+int sat_stem_filter_pairs(const float* w3, void* w_pairs_bf16, int32_t K, void* stream) {
+    if (!w3 || !w_pairs_bf16 || K <= 0) return fail(SAT_EINVAL, "stem_filter_pairs: bad argument");
+    const long n = (long)K * 7 * 4;
+    hipLaunchKernelGGL(stem_filter_pairs_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, w3, (bf*)w_pairs_bf16, n);
+    return launch_ok("stem_filter_pairs");
+}
+int sat_stem_filter_grad_unpairs(const float* dw_pairs, float* dw3, int32_t K, void* stream) {
+    if (!dw_pairs || !dw3 || K <= 0) return fail(SAT_EINVAL, "stem_filter_grad_unpairs: bad argument");
+    const long n = (long)K * 7 * 7;
+    hipLaunchKernelGGL(stem_filter_grad_unpairs_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dw_pairs, dw3, n);
+    return launch_ok("stem_filter_grad_unpairs");
 }
 int sat_stem_filter_pad(const float* w3, void* w8_bf16, int64_t pixels, void* stream) {
     if (!w3 || !w8_bf16) return fail(SAT_EINVAL, "stem_filter_pad: null pointer");

@@ -34,6 +34,7 @@ struct ConvGeom {
     int K, R, S;         // filters KRSC
     int P, Q;            // output NPQK
     int stride, pad;
+    int sw = 0;          // horizontal stride when it differs from `stride` (0 = the same): the stem's tap-pair view, forward and weight gradient only
     // stride-2 data gradient by output parity class (bf16 kernel): rows are the input pixels with h % 2 == ph and
     // w % 2 == pw (Hc x Wc of them per image); only the filter taps of matching parity enter the reduction
     int cls = 0, ph = 0, pw = 0, Hc = 0, Wc = 0, r0 = 0, rc = 0, s0 = 0, sc = 0;

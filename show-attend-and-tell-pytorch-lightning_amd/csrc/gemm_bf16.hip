@@ -33,7 +33,7 @@ __device__ __forceinline__ void row_setup(const BArgs& a, int m, RowCtx& c) {
     } else if (AM == A_CONV_FWD) {
         const ConvGeom& g = a.g;
         int pq = g.P * g.Q; c.n = m / pq; int r = m - c.n * pq; int p = r / g.Q, q = r - p * g.Q;
-        c.y0 = p * g.stride - g.pad; c.x0 = q * g.stride - g.pad;
+        c.y0 = p * g.stride - g.pad; c.x0 = q * (g.sw ? g.sw : g.stride) - g.pad;
     } else {
         const ConvGeom& g = a.g;
         int h, w;
@@ -60,7 +60,7 @@ __device__ __forceinline__ KEnt k_decode(const BArgs& a, int k, int kend) {
     }
     else if (BMo == B_CONV_WGRAD) {
         int pq = g.P * g.Q; int img = k / pq; int rem = k - img * pq; int p = rem / g.Q, q = rem - p * g.Q;
-        t.e2 = img; t.e0 = p * g.stride - g.pad; t.e1 = q * g.stride - g.pad;
+        t.e2 = img; t.e0 = p * g.stride - g.pad; t.e1 = q * (g.sw ? g.sw : g.stride) - g.pad;
     }
     return t;
 }

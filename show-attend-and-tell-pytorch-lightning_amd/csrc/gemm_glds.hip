@@ -427,6 +427,7 @@ int launch_gemm_glds(const BArgs& k0, int amode, int bmode, int c_bf16, int BMt,
     if (k.nstage < 1) k.nstage = 1;
     if (k.nstage > 4) k.nstage = 4;
     const ConvGeom& g = k.g;
+    if (g.sw && g.sw != g.stride) return -1;          // anisotropic stride: register-staged kernel only
     if (k.K % 64 || k.kchunk % 64 || k.a_rows) return -1;
     if (amode == A_CONV_FWD && (g.C % 64 || g.R * g.S > 32)) return -1;
     if (amode == A_CONV_DGRAD && (g.K % 64 || g.R * g.S > 32 || (g.stride != 1 && !g.cls))) return -1;

@@ -60,8 +60,8 @@ def _channels_last_(module):
 
 
 # ----------------------------------------------------------------------------- raw layer calls
-def _geom(N, H, W, Cc, K, R, S, stride, pad):
-    return L.ConvGeom(N=N, H=H, W=W, C=Cc, K=K, R=R, S=S, stride=stride, pad=pad)
+def _geom(N, H, W, Cc, K, R, S, stride, pad, stride_w=0):
+    return L.ConvGeom(N=N, H=H, W=W, C=Cc, K=K, R=R, S=S, stride=stride, pad=pad, stride_w=int(stride_w or 0))
 
 
 def _krsc(w):
@@ -71,8 +71,8 @@ def _krsc(w):
     return w
 
 
-def _out_hw(H, W, R, S, stride, pad):
-    return (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+def _out_hw(H, W, R, S, stride, pad, stride_w=0):
+    return (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // (stride_w or stride) + 1
 
 
 BF16 = torch.bfloat16
@@ -92,19 +92,19 @@ def cast_bf16(t):
     return out
 
 
-def conv_fwd(x, w, stride, pad, bias=None):
-    """x NHWC (fp32 or bf16); w (K,C,R,S) in KRSC memory with x's dtype."""
+def conv_fwd(x, w, stride, pad, bias=None, stride_w=0):
+    """x NHWC (fp32 or bf16); w (K,C,R,S) in KRSC memory with x's dtype.  ``stride_w``: horizontal stride when it differs (bf16 stem)."""
     N, H, W, Cc = x.shape
     K, _, R, S = w.shape
-    P, Q = _out_hw(H, W, R, S, stride, pad)
+    P, Q = _out_hw(H, W, R, S, stride, pad, stride_w)
     y = torch.empty(N, P, Q, K, dtype=x.dtype, device=x.device)
-    g = _geom(N, H, W, Cc, K, R, S, stride, pad)
+    g = _geom(N, H, W, Cc, K, R, S, stride, pad, stride_w)
     fn = L.lib().sat_conv2d_fwd_bf16 if _is_bf(x) else L.lib().sat_conv2d_fwd
     L.check(fn(L.ptr(x), L.ptr(_krsc(w)), L.ptr(bias), L.ptr(y), C.byref(g), L.stream_ptr()), "sat_conv2d_fwd")
     return y
 
 
-def conv_fwd_stats(x, w, stride, pad):
+def conv_fwd_stats(x, w, stride, pad, stride_w=0):
     """bf16 convolution whose epilogue also leaves the BatchNorm statistics of its output per row tile.  Returns
     (y, tiles) where tiles = (tile_stats, tile_rows) for ``bn_fwd(..., tiles=tiles)``, or None when the launch took a kernel
     without that epilogue (fp32 storage, odd shapes)."""
@@ -113,9 +113,9 @@ def conv_fwd_stats(x, w, stride, pad):
     lib = L.lib()
     N, H, W, Cc = x.shape
     K, _, R, S = w.shape
-    P, Q = _out_hw(H, W, R, S, stride, pad)
+    P, Q = _out_hw(H, W, R, S, stride, pad, stride_w)
     y = torch.empty(N, P, Q, K, dtype=x.dtype, device=x.device)
-    g = _geom(N, H, W, Cc, K, R, S, stride, pad)
+    g = _geom(N, H, W, Cc, K, R, S, stride, pad, stride_w)
     stats = torch.empty(lib.sat_conv2d_fwd_stats_bytes(C.byref(g)) // 4, dtype=torch.float32, device=x.device)
     rows = C.c_int32(0)
     L.check(lib.sat_conv2d_fwd_bf16_stats(L.ptr(x), L.ptr(_krsc(w)), L.ptr(y), C.byref(g), L.ptr(stats), C.byref(rows), L.stream_ptr()),
@@ -145,11 +145,11 @@ def _slab(device, nbytes):
     return cur
 
 
-def conv_wgrad(dy, x, w, stride, pad):
+def conv_wgrad(dy, x, w, stride, pad, stride_w=0):
     """fp32 gradient of the (K,C,R,S) filter, whatever the activation storage."""
     N, H, W, Cc = x.shape
     K, _, R, S = w.shape
-    g = _geom(N, H, W, Cc, K, R, S, stride, pad)
+    g = _geom(N, H, W, Cc, K, R, S, stride, pad, stride_w)
     lib = L.lib()
     nbytes = max(lib.sat_conv2d_wgrad_slab_bytes(C.byref(g)), 128 << 20)
     slab = _slab(x.device, nbytes)
@@ -161,6 +161,8 @@ def conv_wgrad(dy, x, w, stride, pad):
 
 #: the stem's bn1 -> relu -> maxpool as one pass (tests switch it off to compare with the three separate kernels)
 _FUSED_STEM_TAIL = os.environ.get("SAT_STEM_TAIL", "1") != "0"
+#: bf16 stem as a 7x4 convolution over pixel pairs (include/sat_hip.h); off: the 8-channel layout with five zero channels
+_STEM_PAIRS = os.environ.get("SAT_STEM_PAIRS", "1") != "0"
 
 _tracked = []      # num_batches_tracked buffers touched by the running whole-encoder forward (bumped once, together)
 _defer = [False]
@@ -367,16 +369,29 @@ class EncoderFn(torch.autograd.Function):
         conv1 = enc[1]
         w3 = _krsc(conv1.weight)                                                   # (64,3,7,7), memory 64,7,7,3
         cpad = 8 if bf else 4
-        x0 = torch.empty(N, H, W, cpad, dtype=adt, device=img.device)
-        wp = torch.empty(conv1.out_channels, cpad, 7, 7, dtype=adt, device=img.device).contiguous(memory_format=torch.channels_last)
-        if bf:
-            L.check(lib.sat_image_normalize_nhwc8_bf16(L.ptr(img), L.ptr(x0), N, H, W, mean, std, st), "sat_image_normalize_nhwc8_bf16")
-            L.check(lib.sat_stem_filter_pad(L.ptr(w3), L.ptr(wp), conv1.out_channels * 49, st), "sat_stem_filter_pad")
+        pairs = bf and _STEM_PAIRS and W % 2 == 0 and tuple(conv1.weight.shape[1:]) == (3, 7, 7)
+        t["stem_pairs"] = pairs
+        if pairs:
+            # two horizontally adjacent pixels of the zero-padded 4-channel image = one 16-byte "pixel" of 8 channels: the 7x7
+            # stride-2 stem becomes a 7x4 convolution with strides (2, 1) and no padding - 224 products per output, not 392
+            x0 = torch.empty(N, H + 6, (W + 6) // 2, 8, dtype=adt, device=img.device)
+            wp = torch.empty(conv1.out_channels, 8, 7, 4, dtype=adt, device=img.device).contiguous(memory_format=torch.channels_last)
+            L.check(lib.sat_image_normalize_nhwc4_padded_bf16(L.ptr(img), L.ptr(x0), N, H, W, mean, std, st), "sat_image_normalize_nhwc4_padded_bf16")
+            L.check(lib.sat_stem_filter_pairs(L.ptr(w3), L.ptr(wp), conv1.out_channels, st), "sat_stem_filter_pairs")
+            stem = dict(stride=2, pad=0, stride_w=1)
         else:
-            L.check(lib.sat_image_normalize_nhwc4(L.ptr(img), L.ptr(x0), N, H, W, mean, std, st), "sat_image_normalize_nhwc4")
-            L.check(lib.sat_pad_channels_3to4(L.ptr(w3), L.ptr(wp), conv1.out_channels * 49, 0, st), "sat_pad_channels_3to4")
+            x0 = torch.empty(N, H, W, cpad, dtype=adt, device=img.device)
+            wp = torch.empty(conv1.out_channels, cpad, 7, 7, dtype=adt, device=img.device).contiguous(memory_format=torch.channels_last)
+            if bf:
+                L.check(lib.sat_image_normalize_nhwc8_bf16(L.ptr(img), L.ptr(x0), N, H, W, mean, std, st), "sat_image_normalize_nhwc8_bf16")
+                L.check(lib.sat_stem_filter_pad(L.ptr(w3), L.ptr(wp), conv1.out_channels * 49, st), "sat_stem_filter_pad")
+            else:
+                L.check(lib.sat_image_normalize_nhwc4(L.ptr(img), L.ptr(x0), N, H, W, mean, std, st), "sat_image_normalize_nhwc4")
+                L.check(lib.sat_pad_channels_3to4(L.ptr(w3), L.ptr(wp), conv1.out_channels * 49, 0, st), "sat_pad_channels_3to4")
+            stem = dict(stride=2, pad=3, stride_w=0)
         t["x0"], t["wp"] = x0, wp
-        t["c0"], tl = conv_fwd_stats(x0, wp, 2, 3) if training else (conv_fwd(x0, wp, 2, 3), None)
+        t["c0"], tl = (conv_fwd_stats(x0, wp, stem["stride"], stem["pad"], stride_w=stem["stride_w"]) if training
+                       else (conv_fwd(x0, wp, stem["stride"], stem["pad"], stride_w=stem["stride_w"]), None))
         if training and _FUSED_STEM_TAIL:      # bn1 + relu + maxpool in one pass: the full-size activation is never written
             t["p0"], t["s0"] = stem_tail_fwd(t["c0"], enc[2], tiles=tl)
         else:
@@ -464,9 +479,14 @@ class EncoderFn(torch.autograd.Function):
                 da0 = torch.empty_like(t["a0"])
                 L.check(lib.sat_maxpool3x3s2_bwd_t(int(bf), L.ptr(d), L.ptr(t["amax"]), L.ptr(da0), Nn, Hh, Ww, Cc, st), "sat_maxpool3x3s2_bwd")
                 dc0, grads[enc[2].weight], grads[enc[2].bias] = bn_bwd(da0, t["c0"], t["a0"], t["s0"], enc[2], True)
-            dwp = conv_wgrad(dc0, t["x0"], t["wp"], 2, 3)                          # (64,cpad,7,7) view of KRS{4,8} fp32 memory
+            if t.get("stem_pairs"):
+                dwp = conv_wgrad(dc0, t["x0"], t["wp"], 2, 0, stride_w=1)               # (64,8,7,4) view of K,7,4,8 fp32 memory
+            else:
+                dwp = conv_wgrad(dc0, t["x0"], t["wp"], 2, 3)                          # (64,cpad,7,7) view of KRS{4,8} fp32 memory
             dw3 = torch.empty_like(_krsc(enc[1].weight))
-            if bf:
+            if t.get("stem_pairs"):
+                L.check(lib.sat_stem_filter_grad_unpairs(L.ptr(dwp), L.ptr(dw3), enc[1].out_channels, st), "sat_stem_filter_grad_unpairs")
+            elif bf:
                 L.check(lib.sat_stem_filter_grad_unpad(L.ptr(dwp), L.ptr(dw3), enc[1].out_channels * 49, st), "sat_stem_filter_grad_unpad")
             else:
                 L.check(lib.sat_pad_channels_3to4(L.ptr(dwp), L.ptr(dw3), enc[1].out_channels * 49, 1, st), "sat_pad_channels_3to4")

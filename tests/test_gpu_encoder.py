@@ -369,3 +369,54 @@ def test_conv_epilogue_statistics_feed_batchnorm(E, N, H, W, C, K, R, stride, pa
     close(st_a[0], st_b[0], 1e-5, "mean from tiles"); close(st_a[1], st_b[1], 1e-4, "invstd from tiles")
     close(out_a.float(), out_b.float(), 1e-2, "bn output from tiles")
     close(bn_a.running_var, bn_b.running_var, 1e-5, "running_var from tiles")
+
+
+def test_bf16_stem_as_tap_pairs_equals_conv2d(E):
+    """bf16 stem in the tap-pair layout (zero-padded 4-channel image viewed as pixel pairs, 7x4 filter, strides (2, 1)): the helper
+    kernels are exact re-layouts, and forward / filter gradient equal F.conv2d(7x7, stride 2, pad 3) on the same bf16-rounded
+    operands up to fp32 accumulation order - and equal the 8-channel layout it replaces."""
+    from sat_amd import _lib as L
+    import ctypes as C
+    lib = L.lib()
+    g = torch.Generator().manual_seed(31)
+    N, H, W, K = 3, 20, 26, 64
+    img = torch.rand(N, 3, H, W, generator=g)
+    w = torch.randn(K, 3, 7, 7, generator=g) * 0.1
+    mean = (C.c_float * 3)(0.485, 0.456, 0.406); std = (C.c_float * 3)(0.229, 0.224, 0.225)
+    st = L.stream_ptr()
+    imgd = img.cuda()
+    x0 = torch.empty(N, H + 6, (W + 6) // 2, 8, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.sat_image_normalize_nhwc4_padded_bf16(L.ptr(imgd), L.ptr(x0), N, H, W, mean, std, st), "normalize padded")
+    xn = ((img - torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)) / torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1))
+    xpad = x0.view(N, H + 6, W + 6, 4).float().cpu()
+    assert float(xpad[:, :3].abs().max()) == 0 and float(xpad[:, -3:].abs().max()) == 0 and float(xpad[:, :, :3].abs().max()) == 0
+    assert float(xpad[:, :, -3:].abs().max()) == 0 and float(xpad[..., 3].abs().max()) == 0
+    xb = xn.bfloat16().float()                                         # what the kernel stores
+    assert float((xpad[:, 3:-3, 3:-3, :3].permute(0, 3, 1, 2) - xb).abs().max()) <= 2 ** -7 * float(xb.abs().max())       # division vs multiply: 1 bf16 ulp
+    w3 = w.permute(0, 2, 3, 1).contiguous().cuda()                     # (K, 7, 7, 3) memory
+    wp = torch.empty(K, 8, 7, 4, dtype=torch.bfloat16, device="cuda").contiguous(memory_format=torch.channels_last)
+    L.check(lib.sat_stem_filter_pairs(L.ptr(w3), L.ptr(wp), K, st), "filter pairs")
+    wpm = wp.permute(0, 2, 3, 1).float().cpu()                         # (K, 7, 4, 8)
+    wb = w.bfloat16().float()
+    for s_ in range(7):
+        assert torch.equal(wpm[:, :, s_ // 2, (s_ % 2) * 4:(s_ % 2) * 4 + 3], wb[:, :, :, s_].permute(0, 2, 1))
+    assert float(wpm[:, :, 3, 4:].abs().max()) == 0 and float(wpm[..., 3].abs().max()) == 0 and float(wpm[..., 7].abs().max()) == 0
+    y = E.conv_fwd(x0, wp, 2, 0, stride_w=1)
+    xin = xpad[:, 3:-3, 3:-3, :3].permute(0, 3, 1, 2).contiguous()      # the kernel's own bf16 input values
+    ref = F.conv2d(xin, wb, None, 2, 3)
+    assert y.shape == (N, H // 2, W // 2, K)
+    close(nchw(y.float()), ref, 1e-2, "stem forward (pairs)")
+    dy = torch.randn(N, H // 2, W // 2, K, generator=g).bfloat16().cuda()
+    dwp = E.conv_wgrad(dy, x0, wp, 2, 0, stride_w=1)
+    dw3 = torch.empty(K, 7, 7, 3, device="cuda")
+    L.check(lib.sat_stem_filter_grad_unpairs(L.ptr(dwp), L.ptr(dw3), K, st), "grad unpairs")
+    wr = wb.clone().requires_grad_()
+    F.conv2d(xin, wr, None, 2, 3).backward(dy.float().cpu().permute(0, 3, 1, 2))
+    close(dw3.permute(0, 3, 1, 2), wr.grad, 2e-3, "stem filter gradient (pairs)")
+    # the 8-channel layout it replaces
+    x8 = torch.empty(N, H, W, 8, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.sat_image_normalize_nhwc8_bf16(L.ptr(imgd), L.ptr(x8), N, H, W, mean, std, st), "normalize nhwc8")
+    w8 = torch.empty(K, 8, 7, 7, dtype=torch.bfloat16, device="cuda").contiguous(memory_format=torch.channels_last)
+    L.check(lib.sat_stem_filter_pad(L.ptr(w3), L.ptr(w8), K * 49, st), "filter pad")
+    y8 = E.conv_fwd(x8, w8, 2, 3)
+    close(y.float(), y8.float(), 1e-2, "pairs vs 8-channel layout")
