@@ -59,7 +59,8 @@ __global__ void normalize_nhwc4_padded_bf16_kernel(const float* __restrict__ img
     long e = (long)blockIdx.x * blockDim.x + threadIdx.x;          // over padded pixels
     if (e >= total) return;
     const int Wp = W + 6, Hp = H + 6;
-    const int xp = (int)(e % Wp); const long t = e / Wp; const int yp = (int)(t % Hp); const long n = t / Hp;
+    const unsigned eu = (unsigned)e;                    // total < 2^32 (checked by the launcher)
+    const int xp = (int)(eu % Wp); const unsigned t = eu / Wp; const int yp = (int)(t % Hp); const long n = t / Hp;
     const int x = xp - 3, y = yp - 3;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H) {
@@ -353,7 +354,7 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict
     constexpr int E = EPT<T>::n;
     long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= totalv) return;
-    const int c0 = (int)(e % CV) * E;
+    const int c0 = (totalv <= 0xffffffffL ? (int)((unsigned)e % (unsigned)CV) : (int)(e % CV)) * E;      // a 64-bit modulo costs ~100 instructions per lane
     float xv[E], rv[E], o[E];
     unpack<T, E>(reinterpret_cast<const uint4*>(x)[e], xv);
     if (res) unpack<T, E>(reinterpret_cast<const uint4*>(res)[e], rv);
@@ -386,7 +387,7 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict
     constexpr int E = EPT<T>::n;
     long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= totalv) return;
-    const int c0 = (int)(e % CV) * E;
+    const int c0 = (totalv <= 0xffffffffL ? (int)((unsigned)e % (unsigned)CV) : (int)(e % CV)) * E;      // a 64-bit modulo costs ~100 instructions per lane
     float xv[E], g[E], yv[E], o[E];
     unpack<T, E>(reinterpret_cast<const uint4*>(x)[e], xv);
     unpack<T, E>(reinterpret_cast<const uint4*>(dy)[e], g);
@@ -704,13 +705,13 @@ __global__ void adaptive_avgpool_kernel(const float* __restrict__ x, float* __re
     long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
     if (!backward) {      // e over outputs (n,p,q,c)
-        int c = (int)(e % C); long t = e / C; int q = (int)(t % Q); t /= Q; int p = (int)(t % P); long n = t / P;
+        const unsigned eu = (unsigned)e; int c = (int)(eu % C); unsigned t = eu / C; int q = (int)(t % Q); t /= Q; int p = (int)(t % P); long n = t / P;
         int h0 = (p * H) / P, h1 = ((p + 1) * H + P - 1) / P, w0 = (q * W) / Q, w1 = ((q + 1) * W + Q - 1) / Q;
         float s = 0.f;
         for (int h = h0; h < h1; ++h) for (int w = w0; w < w1; ++w) s += x[((n * H + h) * W + w) * C + c];
         y[e] = s / (float)((h1 - h0) * (w1 - w0));
     } else {              // e over inputs (n,h,w,c): x = dy (n,P,Q,c), y = dx
-        int c = (int)(e % C); long t = e / C; int w = (int)(t % W); t /= W; int h = (int)(t % H); long n = t / H;
+        const unsigned eu = (unsigned)e; int c = (int)(eu % C); unsigned t = eu / C; int w = (int)(t % W); t /= W; int h = (int)(t % H); long n = t / H;
         float s = 0.f;
         for (int p = 0; p < P; ++p) {
             int h0 = (p * H) / P, h1 = ((p + 1) * H + P - 1) / P; if (h < h0 || h >= h1) continue;
@@ -731,7 +732,7 @@ __device__ __forceinline__ void bilinear_src(int o, int in, int out, int& i0, in
 __global__ void bilinear_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C, int P, int Q, long total) {
     long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
-    int c = (int)(e % C); long t = e / C; int q = (int)(t % Q); t /= Q; int p = (int)(t % P); long n = t / P;
+    const unsigned eu = (unsigned)e; int c = (int)(eu % C); unsigned t = eu / C; int q = (int)(t % Q); t /= Q; int p = (int)(t % P); long n = t / P;
     int h0, h1, w0, w1; float lh, lw;
     bilinear_src(p, H, P, h0, h1, lh); bilinear_src(q, W, Q, w0, w1, lw);
     const float* b = x + n * H * W * C + c;
@@ -741,7 +742,7 @@ __global__ void bilinear_fwd_kernel(const float* __restrict__ x, float* __restri
 __global__ void bilinear_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int C, int P, int Q, long total) {
     long e = (long)blockIdx.x * blockDim.x + threadIdx.x;     // over inputs (n,h,w,c); gather over all outputs touching it
     if (e >= total) return;
-    int c = (int)(e % C); long t = e / C; int w = (int)(t % W); t /= W; int h = (int)(t % H); long n = t / H;
+    const unsigned eu = (unsigned)e; int c = (int)(eu % C); unsigned t = eu / C; int w = (int)(t % W); t /= W; int h = (int)(t % H); long n = t / H;
     float s = 0.f;
     for (int p = 0; p < P; ++p) {
         int h0, h1; float lh; bilinear_src(p, H, P, h0, h1, lh);
@@ -1184,6 +1185,7 @@ int sat_stem_filter_grad_unpad(const float* dw8, float* dw3, int64_t pixels, voi
 int sat_resize_fwd(const float* x, float* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t P, int32_t Q, void* stream) {
     if (!x || !y) return fail(SAT_EINVAL, "resize_fwd: null pointer");
     long total = (long)N * P * Q * C;
+    SAT_REQUIRE(total < (1L << 32) && (long)N * H * W * C < (1L << 32), "resize: more than 2^32 elements");
     if (P <= H) hipLaunchKernelGGL(adaptive_avgpool_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C, P, Q, total, 0);
     else hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C, P, Q, total);
     return launch_ok("resize_fwd");
@@ -1191,6 +1193,7 @@ int sat_resize_fwd(const float* x, float* y, int32_t N, int32_t H, int32_t W, in
 int sat_resize_bwd(const float* dy, float* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t P, int32_t Q, void* stream) {
     if (!dy || !dx) return fail(SAT_EINVAL, "resize_bwd: null pointer");
     long total = (long)N * H * W * C;
+    SAT_REQUIRE(total < (1L << 32) && (long)N * P * Q * C < (1L << 32), "resize: more than 2^32 elements");
     if (P <= H) hipLaunchKernelGGL(adaptive_avgpool_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, H, W, C, P, Q, total, 1);
     else hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, H, W, C, P, Q, total);
     return launch_ok("resize_bwd");
