@@ -305,7 +305,13 @@ __global__ __launch_bounds__(256) void bn_tile_finalize_kernel(const float* __re
     const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
     double s = 0.0, q = 0.0;
     if (c < C)
-        for (int t = pl; t < ntiles; t += 8) { const float2 v = reinterpret_cast<const float2*>(tiles)[(long)t * C + c]; s += (double)v.x; q += (double)v.y; }
+        for (int t0 = pl; t0 < ntiles; t0 += 32) {          // four tiles per lane in flight
+            float2 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int t = t0 + 8 * u; v[u] = t < ntiles ? reinterpret_cast<const float2*>(tiles)[(long)t * C + c] : make_float2(0.f, 0.f); }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s += (double)v[u].x; q += (double)v[u].y; }
+        }
     sh[0][pl][cl] = s; sh[1][pl][cl] = q;
     __syncthreads();
     if (pl == 0 && c < C) {
@@ -329,7 +335,15 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part0, const d
     const int lane = threadIdx.x & 63, c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (c >= C) return;
     double s = 0.0, q = 0.0;
-    for (int p = lane; p < nparts; p += 64) { s += part0[(long)p * C + c]; q += part1[(long)p * C + c]; }
+    for (int p0 = lane; p0 < nparts; p0 += 256) {          // four partials per lane in flight: the kernel is one load latency long, not twelve
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = p0 + 64 * u; const bool ok = p < nparts;
+            a[u] = ok ? part0[(long)p * C + c] : 0.0; b[u] = ok ? part1[(long)p * C + c] : 0.0;
+        }
+        s += (a[0] + a[1]) + (a[2] + a[3]); q += (b[0] + b[1]) + (b[2] + b[3]);
+    }
     s = wave_sum_d(s); q = wave_sum_d(q);
     if (lane == 0) { dbeta[c] = (float)s; dgamma[c] = (float)q; }
 }
