@@ -163,3 +163,41 @@ def test_device_loader_end_to_end(D, tmp_path):
             assert c[j].tolist() == caps[i] and l[j].tolist() == lens[i]
         seen += len(idxs)
     assert seen == n
+
+
+def test_loader_batches_feed_the_train_step(D, tmp_path):
+    """the README loop: DeviceLoader batches (img, caps, lengths on the device) go straight into SAT.training_step"""
+    Image = pytest.importorskip("PIL.Image")
+    import sat_amd  # noqa: F401
+    from sat_amd import model as M
+    from oracle import sat_oracle as O
+    rng = np.random.default_rng(9)
+    n, R, T, V = 8, 2, 7, 30
+    paths, caps, lens = [], [], []
+    for i in range(n):
+        Image.fromarray(rng.integers(0, 256, (int(rng.integers(70, 110)), int(rng.integers(70, 110)), 3), dtype=np.uint8)).save(tmp_path / ("q%d.png" % i))
+        paths.append("q%d.png" % i)
+        ls = rng.integers(2, T, size=R).tolist()                     # targets per caption (words + <END>), at most T - 1 (preprocess.ipynb cell 17)
+        lens.append(ls)
+        caps.append([[V - 2] + rng.integers(1, V - 3, size=l - 1).tolist() + [V - 1] + [0] * (T - 1 - l) for l in ls])
+    stoi = {"<PAD>": 0, "<UNK>": V - 3, "<START>": V - 2, "<END>": V - 1}
+    (tmp_path / "d.json").write_text(json.dumps({"vocab_stoi": stoi, "train": {"img_paths": paths, "encoded_captions": caps, "lengths": lens}}))
+    ds = D.CocoCaptionDataset(str(tmp_path / "d.json"), "train", root=str(tmp_path))
+    loader = D.DeviceLoader(ds, 4, D.BatchTransform(64, train=True), sampler=D.BucketSampler(ds.lengths, 4, seed=3), workers=2)
+    hp = O.default_hparams(encoder_arch="resnet18", encoder_dim=32, input_size=64, encoder_size=3, vocab_size=V, embed_dim=24, attention_dim=16,
+                           decoder_dim=40, decoder_tf="always", weight_decay=0.0, decoder_lr=1e-3, embedding_lr=1e-2, encoder_lr=1e-5, opt="adam",
+                           adam_b1=0.9, adam_b2=0.999, momentum=0.9, nesterov=False, scheduler=None)
+    hp.vocab_stoi = stoi; hp.vocab_itos = {v: k for k, v in stoi.items()}
+    torch.manual_seed(1)
+    model = M.SAT(**vars(hp)).cuda().train()
+    opt = model.configure_optimizers()
+    seen = 0
+    for batch in loader:
+        assert all(t.is_cuda for t in batch)
+        opt.zero_grad(set_to_none=True)
+        out = model.training_step(batch, 0)
+        out["loss"].backward()
+        opt.step()
+        assert bool(torch.isfinite(out["loss"]))
+        seen += batch[0].shape[0]
+    assert seen == n
