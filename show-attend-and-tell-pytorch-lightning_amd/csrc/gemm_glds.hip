@@ -338,7 +338,7 @@ __global__ __launch_bounds__(NT) void gemm_glds_kernel(BArgs a) {
                 // this k-step's share of the next tile's LDS-DMA pieces, issued under the MFMAs
                 if (more) {
 #pragma unroll
-                    for (int jj = ks * (G / 4); jj < (ks + 1) * (G / 4); ++jj) issue_piece(nxt, nxt, jj);
+                    for (int jj = (ks * G) / 4; jj < ((ks + 1) * G) / 4; ++jj) issue_piece(nxt, nxt, jj);          // G pieces spread over the four k-steps
                 }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -404,6 +404,10 @@ static int rung(const BArgs& k, hipStream_t st) {
 template <int AM, int BMo, typename TC>
 static int rung_tiles(const BArgs& k, int BMt, hipStream_t st) {
     if (BMt == 128) return rung<128, 128, AM, BMo, TC>(k, st);
+    // 64 output columns (the ResNet stage-1 layers) over many rows: 128-row tiles halve the workgroup count and the filter-tile
+    // re-reads of the 64x64 form (per k-tile 24 KB for 128x64 products instead of 2 x 16 KB)
+    static const int tall = getenv("SAT_GLDS_TALL") ? atoi(getenv("SAT_GLDS_TALL")) : 1;
+    if (tall && BMo != B_CONV_WGRAD && AM != A_KMAJOR && k.N <= 64 && k.M >= 8192) return rung<128, 64, AM, BMo, TC>(k, st);
     return rung<64, 64, AM, BMo, TC>(k, st);
 }
 
