@@ -406,8 +406,8 @@ static int rung_tiles(const BArgs& k, int BMt, hipStream_t st) {
     if (BMt == 128) return rung<128, 128, AM, BMo, TC>(k, st);
     // 64 output columns (the ResNet stage-1 layers) over many rows: 128-row tiles halve the workgroup count and the filter-tile
     // re-reads of the 64x64 form (per k-tile 24 KB for 128x64 products instead of 2 x 16 KB)
-    static const int tall = getenv("SAT_GLDS_TALL") ? atoi(getenv("SAT_GLDS_TALL")) : 1;
-    if (tall && BMo != B_CONV_WGRAD && AM != A_KMAJOR && k.N <= 64 && k.M >= 8192) return rung<128, 64, AM, BMo, TC>(k, st);
+    static const int tall = getenv("SAT_GLDS_TALL") ? atoi(getenv("SAT_GLDS_TALL")) : 2;      // 0 off, 1 row-major A only, 2 also k-major A (1x1 weight gradients)
+    if (tall && BMo != B_CONV_WGRAD && k.N <= 64 && (AM == A_KMAJOR ? (tall > 1 && k.M >= 128) : k.M >= 8192)) return rung<128, 64, AM, BMo, TC>(k, st);
     return rung<64, 64, AM, BMo, TC>(k, st);
 }
 
