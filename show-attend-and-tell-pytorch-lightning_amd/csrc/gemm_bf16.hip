@@ -366,8 +366,9 @@ int launch_gemm_bf16(const GemmArgs& g, hipStream_t st) {
 #define SAT_BCASE(AMV, BMV, TA, TB, TC) return runb_tiles<AMV, BMV, TA, TB, TC>(k, BMt, st);
     const bool ab = g.a_bf16, bb = g.b_bf16, cb = g.c_bf16;
     if (ab && bb) {         // bf16 operands in HBM: direct-to-LDS staging where the form allows it
-        const int r = launch_gemm_glds(k, g.amode, g.bmode, cb, BMt, st);
-        if (r != -1) return r;
+        int bm_used = BMt;
+        const int r = launch_gemm_glds(k, g.amode, g.bmode, cb, BMt, st, &bm_used);
+        if (r != -1) { if (k.tile_stats && g.tile_rows) *g.tile_rows = bm_used; return r; }
     }
     if (ab && bb) {         // encoder: bf16 activations / filters
         if (g.amode == A_CONV_FWD && g.bmode == B_ROW && cb) SAT_BCASE(A_CONV_FWD, B_ROW, __bf16, __bf16, __bf16)

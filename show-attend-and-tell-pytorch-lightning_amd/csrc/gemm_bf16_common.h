@@ -247,6 +247,7 @@ __device__ __forceinline__ void xcd_tile(int& bx, int& by, int& bz) {
 }
 
 // gemm_glds.hip: direct-to-LDS operand staging; returns -1 when the problem does not fit its forms (caller falls through)
-int launch_gemm_glds(const BArgs& k, int amode, int bmode, int c_bf16, int BMt, hipStream_t st);
+// *bm_used (if given): rows per tile of the kernel that ran (what the per-tile statistics are indexed by)
+int launch_gemm_glds(const BArgs& k, int amode, int bmode, int c_bf16, int BMt, hipStream_t st, int* bm_used = nullptr);
 
 }  // namespace sat

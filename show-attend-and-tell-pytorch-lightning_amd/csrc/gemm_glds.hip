@@ -402,17 +402,21 @@ static int rung(const BArgs& k, hipStream_t st) {
 }
 
 template <int AM, int BMo, typename TC>
-static int rung_tiles(const BArgs& k, int BMt, hipStream_t st) {
-    if (BMt == 128) return rung<128, 128, AM, BMo, TC>(k, st);
+static int rung_tiles(const BArgs& k, int BMt, hipStream_t st, int* bm_used) {
+    if (BMt == 128) { if (bm_used) *bm_used = 128; return rung<128, 128, AM, BMo, TC>(k, st); }
     // 64 output columns (the ResNet stage-1 layers) over many rows: 128-row tiles halve the workgroup count and the filter-tile
     // re-reads of the 64x64 form (per k-tile 24 KB for 128x64 products instead of 2 x 16 KB)
     static const int tall = getenv("SAT_GLDS_TALL") ? atoi(getenv("SAT_GLDS_TALL")) : 2;      // 0 off, 1 row-major A only, 2 also k-major A (1x1 weight gradients)
-    if (tall && BMo != B_CONV_WGRAD && k.N <= 64 && (AM == A_KMAJOR ? (tall > 1 && k.M >= 128) : k.M >= 8192)) return rung<128, 64, AM, BMo, TC>(k, st);
+    if (tall && BMo != B_CONV_WGRAD && k.N <= 64 && (AM == A_KMAJOR ? (tall > 1 && k.M >= 128) : k.M >= 8192)) {
+        if (bm_used) *bm_used = 128;
+        return rung<128, 64, AM, BMo, TC>(k, st);
+    }
+    if (bm_used) *bm_used = 64;
     return rung<64, 64, AM, BMo, TC>(k, st);
 }
 
 // -1: this problem does not fit the direct-to-LDS forms (caller keeps the register-staged kernel)
-int launch_gemm_glds(const BArgs& k0, int amode, int bmode, int c_bf16, int BMt, hipStream_t st) {
+int launch_gemm_glds(const BArgs& k0, int amode, int bmode, int c_bf16, int BMt, hipStream_t st, int* bm_used) {
     static const int off = getenv("SAT_NO_GLDS") ? atoi(getenv("SAT_NO_GLDS")) : 0;
     static const int force_stages = getenv("SAT_GLDS_STAGES") ? atoi(getenv("SAT_GLDS_STAGES")) : 0;
     static const int deep_from = getenv("SAT_GLDS_DEEP_FROM") ? atoi(getenv("SAT_GLDS_DEEP_FROM")) : 1 << 30;
@@ -453,7 +457,7 @@ int launch_gemm_glds(const BArgs& k0, int amode, int bmode, int c_bf16, int BMt,
     }
     if (a_el >= lim || b_el >= lim) return -1;
     if ((amode == A_KMAJOR && k.M < 8) || (bmode != B_ROW && k.N < 8)) return -1;
-#define SAT_GCASE(AMV, BMV, TC) return rung_tiles<AMV, BMV, TC>(k, BMt, st);
+#define SAT_GCASE(AMV, BMV, TC) return rung_tiles<AMV, BMV, TC>(k, BMt, st, bm_used);
     if (amode == A_CONV_FWD && bmode == B_ROW && c_bf16) SAT_GCASE(A_CONV_FWD, B_ROW, __bf16)
     if (amode == A_ROW && bmode == B_ROW && c_bf16) SAT_GCASE(A_ROW, B_ROW, __bf16)
     if (amode == A_ROW && bmode == B_ROW && !c_bf16) SAT_GCASE(A_ROW, B_ROW, float)
