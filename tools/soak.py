@@ -7,9 +7,14 @@ import sat_amd  # noqa
 from sat_amd import model as M
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-hp, T, B, R = bench.hparams("c2")
+cfg = sys.argv[2] if len(sys.argv) > 2 else "c2"
+prec = sys.argv[3] if len(sys.argv) > 3 else "bf16"
+hp, T, B, R = bench.hparams(cfg)
+if len(sys.argv) > 4 and sys.argv[4] == "none":
+    hp["decoder_tf"] = None
+print("soak", cfg, prec, "decoder_tf", hp["decoder_tf"], flush=True)
 torch.manual_seed(42)
-model = M.SAT(**hp).cuda().train(); model.set_precision("bf16")
+model = M.SAT(**hp).cuda().train(); model.set_precision(prec)
 model.__dict__["_sat_global_step"] = 2
 opt = model.configure_optimizers()
 img, caps, lengths = bench.synthetic_batch(B, R, T, hp["vocab_size"], 1234, True)
