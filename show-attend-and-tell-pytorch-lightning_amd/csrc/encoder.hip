@@ -380,7 +380,7 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict
         float v = (xv[i] - mean[c0 + i]) * is * gamma[c0 + i] + beta[c0 + i];
         if (res) v += rv[i];
         bits |= (v > 0.f ? 1u : 0u) << i;
-        o[i] = relu ? fmaxf(v, 0.f) : v;
+        o[i] = relu ? (v < 0.f ? 0.f : v) : v;            // like torch's ReLU a NaN stays a NaN (fmaxf would turn it into 0 and hide it)
     }
     if (rmask) {
         if (E == 8) rmask[e] = (unsigned char)bits;
@@ -444,10 +444,10 @@ __global__ void maxpool3x3s2_fwd_kernel(const T* __restrict__ x, T* __restrict__
             int w = q * 2 - 1 + kw; if ((unsigned)w >= (unsigned)W) continue;
             float4 v = ld4<T>(x, ((n * H + h) * W + w) * C4 + c4);
             int k = kh * 3 + kw;
-            if (v.x > best.x) { best.x = v.x; bx = k; }
-            if (v.y > best.y) { best.y = v.y; by = k; }
-            if (v.z > best.z) { best.z = v.z; bz = k; }
-            if (v.w > best.w) { best.w = v.w; bw = k; }
+            if (v.x > best.x || v.x != v.x) { best.x = v.x; bx = k; }
+            if (v.y > best.y || v.y != v.y) { best.y = v.y; by = k; }
+            if (v.z > best.z || v.z != v.z) { best.z = v.z; bz = k; }
+            if (v.w > best.w || v.w != v.w) { best.w = v.w; bw = k; }
         }
     }
     st4<T>(y, e, best);
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_fwd_v_kernel(const T* __rest
             unpack<T, E>(reinterpret_cast<const uint4*>(x)[((n * H + h) * W + w) * CV + cv], v);
             const unsigned k = kh * 3 + kw;
 #pragma unroll
-            for (int i = 0; i < E; ++i) if (v[i] > best[i]) { best[i] = v[i]; bk[i] = k; }
+            for (int i = 0; i < E; ++i) if (v[i] > best[i] || v[i] != v[i]) { best[i] = v[i]; bk[i] = k; }
         }
     }
     reinterpret_cast<uint4*>(y)[e] = pack<T, E>(best);
@@ -566,8 +566,9 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const T* __res
             const unsigned k = kh * 3 + kw;
 #pragma unroll
             for (int i = 0; i < E; ++i) {
-                const float v = round_to<T>(fmaxf((xv[i] - mu[i]) * is[i] * ga[i] + be[i], 0.f));
-                if (v > best[i]) { best[i] = v; bk[i] = k; }
+                const float pre = (xv[i] - mu[i]) * is[i] * ga[i] + be[i];
+                const float v = round_to<T>(pre < 0.f ? 0.f : pre);       // NaN stays NaN, and wins the window like in torch's max pool
+                if (v > best[i] || v != v) { best[i] = v; bk[i] = k; }
             }
         }
     }

@@ -49,7 +49,7 @@ __device__ __forceinline__ float epilogue_value(const KArgs& a, int row, int col
             float u = a.e0[(long)row * a.lde0 + col];
             v *= (1.0f - u * u);
         } break;
-        case EPI_BIAS_RELU: v = fmaxf(0.0f, v + a.bias[col]); break;
+        case EPI_BIAS_RELU: v += a.bias[col]; v = v < 0.f ? 0.f : v; break;        // NaN stays NaN
         default: break;
     }
     return v;

@@ -40,7 +40,7 @@ __device__ __forceinline__ float ep_value(const BArgs& a, int row, int col, floa
             break;
         case EPI_ADD_TANH: { long er = a.a_rows ? (long)a.a_rows[row] : (long)row; v = fast_tanh(v + a.e0[er * a.lde0 + col]); } break;
         case EPI_MUL_DTANH: { float u = a.e0[(long)row * a.lde0 + col]; v *= (1.0f - u * u); } break;
-        case EPI_BIAS_RELU: v = fmaxf(0.0f, v + a.bias[col]); break;
+        case EPI_BIAS_RELU: v += a.bias[col]; v = v < 0.f ? 0.f : v; break;        // NaN stays NaN
         default: break;
     }
     return v;

@@ -423,3 +423,20 @@ def test_bf16_stem_as_tap_pairs_equals_conv2d(E):
     L.check(lib.sat_stem_filter_pad(L.ptr(w3), L.ptr(w8), K * 49, st), "filter pad")
     y8 = E.conv_fwd(x8, w8, 2, 3)
     close(y.float(), y8.float(), 1e-2, "pairs vs 8-channel layout")
+
+
+def test_nan_is_not_swallowed_by_relu_or_max_pool(E):
+    """torch's ReLU and max pool pass a NaN on; so do the kernels (fmaxf(NaN, 0) = 0 would hide a broken layer from the loss)."""
+    from sat_amd import _lib as L
+    x = torch.randn(2, 6, 6, 8)
+    x[0, 2, 3, 1] = float("nan")
+    bn = torch.nn.BatchNorm2d(8).cuda().eval()
+    y, _ = E.bn_fwd(x.cuda(), bn, None, True, False)
+    ref = F.relu(bn.cpu()(x.permute(0, 3, 1, 2))).permute(0, 2, 3, 1)
+    assert torch.equal(torch.isnan(y.cpu()), torch.isnan(ref)) and int(torch.isnan(ref).sum()) == 1
+    xp = x.cuda()
+    P = 3
+    yd = torch.empty(2, P, P, 8, device="cuda"); am = torch.empty(2, P, P, 8, dtype=torch.uint8, device="cuda")
+    L.check(L.lib().sat_maxpool3x3s2_fwd(L.ptr(xp), L.ptr(yd), L.ptr(am), 2, 6, 6, 8, L.stream_ptr()), "maxpool")
+    refp = F.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+    assert torch.equal(torch.isnan(yd.cpu()), torch.isnan(refp)) and int(torch.isnan(refp).sum()) >= 1
