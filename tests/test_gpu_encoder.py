@@ -278,7 +278,9 @@ BCONVS = [(2, 9, 9, 8, 16, 3, 1, 1), (2, 10, 11, 16, 24, 3, 2, 1), (3, 8, 8, 16,
           (2, 12, 12, 128, 64, 3, 1, 1), (2, 13, 11, 64, 128, 3, 2, 1), (3, 9, 9, 192, 64, 1, 1, 0), (2, 8, 8, 64, 72, 3, 1, 1),
           (8, 32, 32, 128, 128, 3, 1, 1), (5, 14, 14, 256, 512, 1, 2, 0), (4, 16, 16, 128, 256, 3, 1, 1),
           # >= 8192 pixels with 64 filters or 64 input channels: the 128x64 tiles (forward, data gradient, k-major weight gradient)
-          (2, 64, 64, 64, 64, 3, 1, 1), (3, 61, 59, 256, 64, 1, 1, 0), (2, 64, 66, 64, 256, 1, 1, 0)]
+          (2, 64, 64, 64, 64, 3, 1, 1), (3, 61, 59, 256, 64, 1, 1, 0), (2, 64, 66, 64, 256, 1, 1, 0),
+          # >= 192 tiles of 128x128 (what the C2 step mostly runs): 3x3 and 1x1, ragged row count
+          (8, 64, 64, 128, 128, 3, 1, 1), (7, 63, 65, 256, 128, 1, 1, 0), (8, 64, 64, 128, 512, 1, 1, 0)]
 
 
 @pytest.mark.parametrize("N,H,W,C,K,R,stride,pad", BCONVS)
@@ -346,7 +348,8 @@ def test_residual_block_bf16_storage(E, kind, cin, planes, stride):
 
 @pytest.mark.parametrize("N,H,W,C,K,R,stride,pad", [(4, 16, 16, 64, 64, 3, 1, 1), (3, 9, 9, 64, 256, 1, 1, 0), (2, 20, 20, 8, 64, 7, 2, 3),
                                                     (5, 13, 11, 128, 72, 3, 2, 1), (8, 32, 32, 64, 128, 3, 1, 1),
-                                                    (2, 64, 64, 64, 64, 3, 1, 1), (3, 61, 59, 256, 64, 1, 1, 0)])      # >= 8192 rows x 64 filters: 128x64 tiles
+                                                    (2, 64, 64, 64, 64, 3, 1, 1), (3, 61, 59, 256, 64, 1, 1, 0),       # >= 8192 rows x 64 filters: 128x64 tiles
+                                                    (8, 64, 64, 128, 128, 3, 1, 1), (7, 63, 65, 64, 256, 1, 1, 0)])    # >= 192 tiles of 128x128
 def test_conv_epilogue_statistics_feed_batchnorm(E, N, H, W, C, K, R, stride, pad):
     """bf16 conv whose epilogue leaves per-row-tile (sum, sum of squares) of its stored output; BatchNorm built on those tiles
     must equal BatchNorm with its own statistics pass over the same tensor (ragged last tile, 64- and 128-row tiles, both kernels)."""

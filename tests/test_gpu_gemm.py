@@ -82,7 +82,8 @@ def _bf(x):
     return x.to(torch.bfloat16).to(torch.float32)
 
 
-BSHAPES = [(64, 64, 32), (128, 128, 64), (640, 2688, 512), (200, 72, 96), (136, 264, 40), (1024, 512, 2048), (8, 8, 8)]
+BSHAPES = [(64, 64, 32), (128, 128, 64), (640, 2688, 512), (200, 72, 96), (136, 264, 40), (1024, 512, 2048), (8, 8, 8),
+           (4096, 1024, 256), (2048, 2048, 512), (3000, 1536, 192)]      # >= 192 tiles of 128x128: the kernels the C2 step mostly runs
 
 
 @pytest.mark.parametrize("M,N,K", BSHAPES)
