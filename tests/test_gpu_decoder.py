@@ -272,3 +272,35 @@ def test_embedding_gradient_with_very_frequent_tokens(M):
     loss_o.backward()
     close(dec.embedding.weight.grad, sdo["embedding.weight"].grad, 2e-4, "embedding gradient")
     assert float(dec.embedding.weight.grad[dec.pad_idx].abs().max()) == 0.0
+
+
+def test_c1_shapes_bf16_mode_tracks_the_oracle(M):
+    """bf16 mode at C1 decoder shapes (D = 256, n = 512: the per-step GEMMs run on bf16 operand copies through the direct-to-LDS
+    kernel, the vocabulary projection on bf16 copies) against the fp32 oracle.  Stated tolerance (bf16 has 8 significant bits,
+    accumulation / state / losses stay fp32): logits 3e-2 of their range, alphas 1e-2 absolute, losses 1e-2 relative, parameter
+    and annotation gradients 2e-2 relative L2 (measured: 6e-3)."""
+    from oracle import prng, sat_oracle as O
+    hp = O.default_hparams(vocab_size=6400, encoder_dim=256, embed_dim=256, attention_dim=128, decoder_dim=512)
+    sd = {k: torch.from_numpy(v) for k, v in prng.decoder_state(hp, 80).items()}
+    ann = torch.from_numpy(prng.uniform((8, 256, 7, 7), 801, 0.0, 2.0))
+    caps, lengths = prng.captions(8, 5, 22, 6400, 802, min_len=8)
+    caps, lengths = torch.from_numpy(caps), torch.from_numpy(lengths)
+    dec = M.SATDecoder(hp).cuda(); dec.load_decoder_state(sd)
+    dec.sat_precision = "bf16"
+    ann_bld = ann.permute(0, 2, 3, 1).reshape(8, 49, 256).contiguous().cuda().requires_grad_()
+    res = dec.train_decode(ann_bld, caps.cuda(), lengths, 1.0)
+    (res["ce"] + res["ds"]).backward()
+    sdo = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    ann_o = ann.clone().requires_grad_()
+    loss_o, out_o = O.training_loss(sdo, hp, ann_o, caps, lengths, 1.0)
+    loss_o.backward()
+    lo = out_o["logits_packed"]
+    assert float((res["logits_packed"].cpu() - lo).abs().max()) <= 3e-2 * float(lo.abs().max())
+    assert float((res["alphas"].cpu() - out_o["alphas"]).abs().max()) <= 1e-2
+    assert abs(float(res["ce"]) + float(res["ds"]) - float(loss_o)) <= 1e-2 * abs(float(loss_o))
+    rl2 = lambda a, b: float((a.double().cpu() - b.double()).norm()) / max(1e-12, float(b.double().norm()))
+    d_ann = ann_bld.grad.reshape(8, 7, 7, 256).permute(0, 3, 1, 2)
+    assert rl2(d_ann, ann_o.grad) <= 2e-2
+    worst = max((rl2(p.grad, sdo[k].grad), k) for k, p in dec.named_parameters())
+    print("bf16 decoder, worst relative L2 gradient error:", worst)
+    assert worst[0] <= 2e-2, worst
