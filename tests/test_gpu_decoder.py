@@ -304,3 +304,37 @@ def test_c1_shapes_bf16_mode_tracks_the_oracle(M):
     worst = max((rl2(p.grad, sdo[k].grad), k) for k, p in dec.named_parameters())
     print("bf16 decoder, worst relative L2 gradient error:", worst)
     assert worst[0] <= 2e-2, worst
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_c2_shapes_against_the_oracle(M, precision):
+    """BASELINE configs[1] decoder shapes at full size (128 images x 5 captions, L = 49, D = 512, V = 6400, T = 22, ragged lengths)
+    against the fp32 oracle run here on the host (~10 s): the tile sizes, split-K factors and workgroup counts of the real step.
+    fp32 mode: 1e-4 (north_star); bf16 mode: the tolerances of the C1 test."""
+    from oracle import prng, sat_oracle as O
+    torch.set_num_threads(min(16, os.cpu_count() or 1))      # the box's CPU share; os.cpu_count() threads thrash
+    hp = O.default_hparams(vocab_size=6400, encoder_dim=512, embed_dim=256, attention_dim=128, decoder_dim=512)
+    sd = {k: torch.from_numpy(v) for k, v in prng.decoder_state(hp, 81).items()}
+    B, R, T = 128, 5, 22
+    ann = torch.from_numpy(prng.uniform((B, 512, 7, 7), 811, 0.0, 2.0))
+    caps, lengths = prng.captions(B, R, T, 6400, 812, min_len=8)
+    caps, lengths = torch.from_numpy(caps), torch.from_numpy(lengths)
+    dec = M.SATDecoder(hp).cuda(); dec.load_decoder_state(sd)
+    dec.sat_precision = precision
+    ann_bld = ann.permute(0, 2, 3, 1).reshape(B, 49, 512).contiguous().cuda().requires_grad_()
+    res = dec.train_decode(ann_bld, caps.cuda(), lengths, 1.0)
+    (res["ce"] + res["ds"]).backward()
+    sdo = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    ann_o = ann.clone().requires_grad_()
+    loss_o, out_o = O.training_loss(sdo, hp, ann_o, caps, lengths, 1.0)
+    loss_o.backward()
+    lo = out_o["logits_packed"]
+    tl, ta, tg = (1e-4, 1e-4, 1e-3) if precision == "fp32" else (3e-2, 1e-2, 2e-2)
+    assert float((res["logits_packed"].cpu() - lo).abs().max()) <= tl * max(1.0, float(lo.abs().max()))
+    assert float((res["alphas"].cpu() - out_o["alphas"]).abs().max()) <= ta
+    assert abs(float(res["ce"]) + float(res["ds"]) - float(loss_o)) <= (1e-5 if precision == "fp32" else 1e-2) * abs(float(loss_o))
+    rl2 = lambda a, b: float((a.double().cpu() - b.double()).norm()) / max(1e-12, float(b.double().norm()))
+    d_ann = ann_bld.grad.reshape(B, 7, 7, 512).permute(0, 3, 1, 2)
+    worst = max([(rl2(p.grad, sdo[k].grad), k) for k, p in dec.named_parameters()] + [(rl2(d_ann, ann_o.grad), "annotations")])
+    print(precision, "C2 decoder, worst relative L2 gradient error:", worst)
+    assert worst[0] <= tg, worst
