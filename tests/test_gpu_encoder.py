@@ -3,6 +3,8 @@ fp32 on the CPU, and of the whole ResNet-18 get_encoder against the oracle's bui
 Encoder parity is unpinned at the reference level (torchvision is absent): the oracle is the
 reference's own get_encoder logic running over the repo's ResNet definition (tests/golden/g_encoder.npz)."""
 import numpy as np
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -218,9 +220,12 @@ def test_residual_block_fwd_bwd(E, kind, cin, planes, stride):
         close(grads[p], refp[k].grad, 2e-4, k)
 
 
-@pytest.mark.parametrize("arch,es,px", [("resnet18", None, 64), ("resnet18", 3, 64), ("resnet50", None, 128)])
+@pytest.mark.parametrize("arch,es,px", [("resnet18", None, 64), ("resnet18", 3, 64), ("resnet50", None, 128), ("resnet50", 7, 256)])
 def test_whole_encoder_against_oracle(E, arch, es, px):
+    """the last case is BASELINE configs[1]'s encoder at its real resolution (batch 8): 32768-row stage-1 maps, i.e. the tile
+    sizes of the real step (fp32 parity mode)"""
     from oracle import prng, sat_oracle as O
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     hp = O.default_hparams(encoder_arch=arch, encoder_dim=32, input_size=px, encoder_size=es)
     torch.manual_seed(3)
     ref = O.build_encoder(hp)                                   # CPU, train mode

@@ -110,16 +110,25 @@ def test_frozen_encoder_and_state_dict_roundtrip():
     assert torch.equal(a, b)
 
 
-def test_bf16_mode_tracks_the_fp32_oracle():
+@pytest.mark.parametrize("size", ["small", "c2-encoder"])
+def test_bf16_mode_tracks_the_fp32_oracle(size):
     """hip_precision="bf16" (BASELINE configs[1]) has no reference counterpart (the reference only has fp16 AMP).
     Stated tolerance against the fp32 oracle: loss 2e-2 relative, logits 6e-2 of their range, alphas 2e-2 absolute,
     decoder-side gradients 0.15 relative L2, encoder gradients cosine >= 0.9 with the fp32 ones (bf16 has 8 significant
     bits; ReLU decisions flip near zero and compound over the residual stack, test_gpu_encoder.py quantifies one block;
     accumulation, statistics and master weights are fp32)."""
-    model, oracle, hp = make(dict(decoder_tf="always", encoder_dim=32, embed_dim=32, attention_dim=16, decoder_dim=64, vocab_size=128,
-                                  input_size=128, encoder_size=None), damp_residual=0.25)
+    import os
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    if size == "small":
+        model, oracle, hp = make(dict(decoder_tf="always", encoder_dim=32, embed_dim=32, attention_dim=16, decoder_dim=64, vocab_size=128,
+                                      input_size=128, encoder_size=None), damp_residual=0.25)
+        nb = 16                                 # 128 px, batch 16: 256 samples per channel in the last stage's BatchNorms
+    else:                                       # resnet50 at 256 px (stage-1 maps of 32768 rows: the real step's tile sizes), C1-width decoder
+        model, oracle, hp = make(dict(decoder_tf="always", encoder_arch="resnet50", encoder_dim=256, embed_dim=256, attention_dim=128,
+                                      decoder_dim=512, vocab_size=640, input_size=256, encoder_size=7), damp_residual=0.25)
+        nb = 8
     model.set_precision("bf16")
-    img, caps, lengths = batch(hp, B=16)        # 128 px, batch 16: 256 samples per channel in the last stage's BatchNorms
+    img, caps, lengths = batch(hp, B=nb)
     loss_o, out_o = oracle.step_loss(img, caps, lengths, 1.0)
     loss_o.backward()
     lp, tp, alphas = model.train_batch((img.cuda(), caps.cuda(), lengths), 1.0)
@@ -131,6 +140,7 @@ def test_bf16_mode_tracks_the_fp32_oracle():
     m["loss"].backward()
     og = oracle.named_grads()
     worst = 0.0
+    coses = []
     for k, p in model.named_parameters():
         assert p.grad is not None and p.grad.dtype == torch.float32 and torch.isfinite(p.grad).all(), k
         e = float((p.grad.cpu().double() - og[k].double()).norm()) / max(1e-9, float(og[k].double().norm()))
@@ -141,10 +151,12 @@ def test_bf16_mode_tracks_the_fp32_oracle():
         if k.startswith("encoder.") and not k.startswith("encoder.9"):
             a, b = p.grad.cpu().double().flatten(), og[k].double().flatten()
             cos = float(a @ b / (a.norm() * b.norm() + 1e-30))
-            assert cos >= 0.9, "%s: cosine with the fp32 gradient %.3f" % (k, cos)
+            coses.append((cos, k))
+            # 16 residual blocks of bf16 rounding and ReLU flips in front of the stem at batch 8 (resnet50) vs 8 blocks (resnet18)
+            assert cos >= (0.9 if size == "small" else 0.75), "%s: cosine with the fp32 gradient %.3f" % (k, cos)
         else:
             assert e <= 0.15, "%s: relative L2 gradient error %.3e" % (k, e)
-    print("bf16 mode: worst relative L2 gradient error", worst)
+    print("bf16 mode: worst relative L2 gradient error", worst, " lowest encoder cosines", sorted(coses)[:4])
 
 
 def test_bf16_filter_copies_stay_current_through_optimizer_steps():
