@@ -278,3 +278,26 @@ def test_batched_beam_search_replayed_from_a_hipgraph():
     same(dec.beam_decode_batched(ann5, (3, 4), **kw), dec.beam_decode_batched(ann5, (3, 4), graph=True, **kw))
     same(dec.beam_decode_batched(ann, (3, 4), **kw), dec.beam_decode_batched(ann, (3, 4), graph=True, **kw))
     assert len(dec._beam_graphs) == 2
+
+
+def test_batched_beam_search_at_c5_decoder_shapes():
+    """BASELINE configs[4] decoder shapes (D = 512, n = 512, V = 6400, L = 49; beam 5): the batched search and its hipGraph
+    replay against the per-image loop, fp32 mode (in bf16 mode the two paths round differently shaped GEMMs)."""
+    import sat_amd  # noqa: F401
+    from sat_amd import model as M
+    from oracle import prng, sat_oracle as O
+    hp = O.default_hparams(vocab_size=6400, encoder_dim=512, embed_dim=256, attention_dim=128, decoder_dim=512)
+    torch.manual_seed(5)
+    dec = M.SATDecoder(hp).cuda().eval()
+    ann = torch.from_numpy(prng.uniform((12, 49, 512), 95, 0.0, 2.0)).cuda()
+    kw = dict(beamk=5, max_gen_length=14, temperature=1.0, rescore_method="LN", return_all=True)
+    a = dec.beam_decode(ann, (7, 7), **kw)
+    b = dec.beam_decode_batched(ann, (7, 7), **kw)
+    c = dec.beam_decode_batched(ann, (7, 7), graph=True, **kw)
+    assert a[0] == b[0]
+    flat = lambda x: [v for e in x for v in e]
+    for u, v in zip(flat(a[1]), flat(b[1])):
+        assert abs(u - v) <= 2e-5 * max(1.0, abs(u))
+    for u, v in zip(flat(a[2]), flat(b[2])):
+        assert u.shape == v.shape and float((u - v).abs().max()) <= 2e-5
+    assert b[0] == c[0] and b[1] == c[1] and all(torch.equal(u, v) for u, v in zip(flat(b[2]), flat(c[2])))
