@@ -338,3 +338,35 @@ def test_c2_shapes_against_the_oracle(M, precision):
     worst = max([(rl2(p.grad, sdo[k].grad), k) for k, p in dec.named_parameters()] + [(rl2(d_ann, ann_o.grad), "annotations")])
     print(precision, "C2 decoder, worst relative L2 gradient error:", worst)
     assert worst[0] <= tg, worst
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_c4_shapes_against_the_oracle(M, precision):
+    """BASELINE configs[3] decoder shapes (L = 196 locations, D = 1024, V = 10000 - not a multiple of the GEMM tiles -, T = 32),
+    16 images x 5 captions, ragged lengths, against the fp32 oracle on the host."""
+    from oracle import prng, sat_oracle as O
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    hp = O.default_hparams(vocab_size=10000, encoder_dim=1024, embed_dim=256, attention_dim=128, decoder_dim=512)
+    sd = {k: torch.from_numpy(v) for k, v in prng.decoder_state(hp, 83).items()}
+    B, R, T = 16, 5, 32
+    ann = torch.from_numpy(prng.uniform((B, 1024, 14, 14), 831, 0.0, 2.0))
+    caps, lengths = prng.captions(B, R, T, 10000, 832, min_len=8)
+    caps, lengths = torch.from_numpy(caps), torch.from_numpy(lengths)
+    dec = M.SATDecoder(hp).cuda(); dec.load_decoder_state(sd)
+    dec.sat_precision = precision
+    ann_bld = ann.permute(0, 2, 3, 1).reshape(B, 196, 1024).contiguous().cuda().requires_grad_()
+    res = dec.train_decode(ann_bld, caps.cuda(), lengths, 1.0)
+    (res["ce"] + res["ds"]).backward()
+    sdo = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    ann_o = ann.clone().requires_grad_()
+    loss_o, out_o = O.training_loss(sdo, hp, ann_o, caps, lengths, 1.0)
+    loss_o.backward()
+    lo = out_o["logits_packed"]
+    tl, ta, tg = (1e-4, 1e-4, 1e-3) if precision == "fp32" else (3e-2, 1e-2, 2e-2)
+    assert float((res["logits_packed"].cpu() - lo).abs().max()) <= tl * max(1.0, float(lo.abs().max()))
+    assert float((res["alphas"].cpu() - out_o["alphas"]).abs().max()) <= ta
+    rl2 = lambda a, b: float((a.double().cpu() - b.double()).norm()) / max(1e-12, float(b.double().norm()))
+    d_ann = ann_bld.grad.reshape(B, 14, 14, 1024).permute(0, 3, 1, 2)
+    worst = max([(rl2(p.grad, sdo[k].grad), k) for k, p in dec.named_parameters()] + [(rl2(d_ann, ann_o.grad), "annotations")])
+    print(precision, "C4 decoder, worst relative L2 gradient error:", worst)
+    assert worst[0] <= tg, worst
