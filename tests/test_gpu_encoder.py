@@ -220,7 +220,8 @@ def test_residual_block_fwd_bwd(E, kind, cin, planes, stride):
         close(grads[p], refp[k].grad, 2e-4, k)
 
 
-@pytest.mark.parametrize("arch,es,px", [("resnet18", None, 64), ("resnet18", 3, 64), ("resnet50", None, 128), ("resnet50", 7, 256)])
+@pytest.mark.parametrize("arch,es,px", [("resnet18", None, 64), ("resnet18", 3, 64), ("resnet50", None, 128), ("resnet50", 7, 256),
+                                        ("wide_resnet50_2", 14, 64), ("resnet34", None, 64)])
 def test_whole_encoder_against_oracle(E, arch, es, px):
     """the last case is BASELINE configs[1]'s encoder at its real resolution (batch 8): 32768-row stage-1 maps, i.e. the tile
     sizes of the real step (fp32 parity mode)"""
