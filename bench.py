@@ -88,7 +88,7 @@ def cpu_baseline(cfg, seconds_budget=30.0):
     while True:
         step(); n += 1
         log("cpu baseline step %d" % n)
-        if time.time() - t0 > seconds_budget * 0.5 or n >= 3:
+        if time.time() - t0 > seconds_budget * 0.5 or n >= 16:      # ~10-15 s of CPU work
             break
     dt = (time.time() - t0) / n
     return {"value": round(B * R / dt, 2), "unit": "captions/s", "cores": cores, "kind": "port",
