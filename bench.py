@@ -5,25 +5,24 @@ resnet50, encoder_size=7 (L=49), encoder_dim=512, vocab=6400, T=22, batch 128 im
 per image (640 caption sequences per GPU-step).
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    (N>1: either under python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ..., or plainly as above --
+     the parent then starts the N ranks itself, before anything touches the GPU, and relays rank 0's JSON line)
 
-Prints ONE JSON line on rank 0.  `roofline` is measured with HIP events inside the library (sat_profile_*)
-on instrumented steps run right after the timed region; `cpu_baseline` times the CPU oracle (a port of the
-reference's arithmetic, oracle/sat_oracle.py) on a bounded sample of the same model on rank 0 at N=1.
+Prints ONE JSON line on rank 0.  `roofline` is measured with HIP events inside the library (sat_profile_*): two
+untimed instrumented steps rank the kernel families (`families` / `top`), then the dominant family alone stays
+instrumented inside the timed region; `cpu_baseline` times the CPU oracle (a port of the reference's arithmetic,
+oracle/sat_oracle.py) on a bounded sample on rank 0 at N=1.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-
-import numpy as np
-import torch
-import torch.distributed as dist
 
 CONFIGS = {
     # name: (arch, encoder_size, encoder_dim, vocab, T, batch per GPU)
@@ -32,8 +31,15 @@ CONFIGS = {
     "c3": ("resnet101", 14, 512, 6400, 22, 32),
     "c4": ("wide_resnet101_2", 14, 1024, 10000, 32, 64),
 }
+#: images per step of the whole job as BASELINE.json states them (--strong splits these over the ranks)
+GLOBAL_BATCH = {"c1": 8, "c2": 128, "c3": 256, "c4": 512}
 PEAK = {"f32": 157.3, "bf16": 2500.0}     # dense MFMA TFLOP/s, MI355X_MICROARCH.md chip table
-HBM_PEAK_GBS = 8000.0
+PEAK_HBM_GBS = 8000.0                     # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+MIN_WARM_S = 1.5
+# in-library profile name -> kernel family of profiles/*_pmc_hbm.json (tools/pmc_aggregate.py)
+PMC_FAMILY = {"bn_apply_bwd": "bn_bwd_apply_kernel", "bn_apply_fwd": "bn_apply_kernel", "bn_stats_bwd": "bn_colstats_kernel<1>",
+              "bn_stats_fwd": "bn_colstats_kernel<0>"}
+PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r02_bf16_bench_c2_pmc_hbm.json", "r01_bf16_bench_c2_pmc_hbm.json")]
 
 
 def hparams(cfg, R=5):
@@ -50,6 +56,7 @@ def hparams(cfg, R=5):
 
 def synthetic_batch(B, R, T, V, seed, ragged):
     """img ~ U[0,1); captions [START] + U{1..V-4} + [END] + PAD; lengths all T-1 (headline) or U{8..T-1}."""
+    import torch
     g = torch.Generator().manual_seed(seed)
     img = torch.rand(B, 3, 256, 256, generator=g)
     lengths = torch.randint(8, T, (B, R), generator=g) if ragged else torch.full((B, R), T - 1, dtype=torch.int64)
@@ -62,8 +69,43 @@ def synthetic_batch(B, R, T, V, seed, ragged):
     return img, caps, lengths
 
 
-def cpu_baseline(cfg, seconds_budget=30.0):
-    """The CPU oracle (kind "port") on B=8 images of the same model: 1 warm-up + timed steps within the budget."""
+#: arch -> (block kind, blocks per stage, width per group): torchvision's table (same as sat_amd.encoder.RESNETS)
+_RESNETS = {"resnet18": ("basic", (2, 2, 2, 2), 64), "resnet50": ("bottleneck", (3, 4, 6, 3), 64), "resnet101": ("bottleneck", (3, 4, 23, 3), 64),
+            "wide_resnet101_2": ("bottleneck", (3, 4, 23, 3), 128)}
+
+
+def algorithmic_work(cfg, R=5):
+    """algorithmic FLOPs (2 x MAC; training = 3 x forward for contraction work) of one caption.
+    Encoder: every convolution of the torchvision ResNet at 256 px + the 1x1 projection."""
+    arch, es, D, V, T, _ = CONFIGS[cfg]
+    kind, depths, wpg = _RESNETS[arch]
+    macs = 128 * 128 * 64 * 3 * 49                       # conv1: 7x7, stride 2 on 256 px
+    hw, cin = 64, 64
+    for si, (planes, nblk) in enumerate(zip((64, 128, 256, 512), depths)):
+        for bi in range(nblk):
+            stride = 2 if (si > 0 and bi == 0) else 1
+            ho = hw // stride
+            if kind == "basic":
+                cout = planes
+                macs += ho * ho * planes * cin * 9 + ho * ho * planes * planes * 9
+            else:
+                mid = int(planes * (wpg / 64.0)); cout = planes * 4
+                macs += hw * hw * mid * cin + ho * ho * mid * mid * 9 + ho * ho * cout * mid
+            if stride != 1 or cin != cout:
+                macs += ho * ho * cout * cin
+            hw, cin = ho, cout
+    macs += hw * hw * D * cin                            # model.py:53
+    f_enc = 2.0 * macs
+    Lc, A, m, n = es * es, 128, 256, 512
+    f_pre = 2.0 * Lc * D * A
+    f_step = 2.0 * (n * A + Lc * A + Lc * D + n * D + (m + D + n) * 4 * n + n * m + D * m + m * V)
+    f_cap = 3.0 * (f_enc / R + f_pre + (T - 1) * f_step)
+    return dict(f_enc=f_enc, f_pre=f_pre, f_step=f_step, f_cap=f_cap)
+
+
+def cpu_baseline(cfg, seconds_budget=24.0, max_steps=16):
+    """The CPU oracle (kind "port") on B=8 images of config ``cfg``'s model: 1 warm-up + timed steps within the budget."""
+    import torch
     from types import SimpleNamespace
     from oracle import sat_oracle as O
     hp, T, _, R = hparams(cfg)
@@ -83,17 +125,17 @@ def cpu_baseline(cfg, seconds_budget=30.0):
         opt.step()
 
     step()
-    log("cpu baseline warm-up step done")
+    log("cpu baseline (%s) warm-up step done" % cfg)
     t0 = time.time(); n = 0
     while True:
         step(); n += 1
-        log("cpu baseline step %d" % n)
-        if time.time() - t0 > seconds_budget * 0.5 or n >= 16:      # ~10-15 s of CPU work
+        if time.time() - t0 > seconds_budget * 0.5 or n >= max_steps:      # ~10 s of CPU work
             break
+    log("cpu baseline (%s): %d steps" % (cfg, n))
     dt = (time.time() - t0) / n
     return {"value": round(B * R / dt, 2), "unit": "captions/s", "cores": cores, "kind": "port",
-            "sample": "%d full train steps (fwd+loss+bwd+Adam, fp32) of the same model at batch %d images x %d captions after 1 warm-up; "
-                      "oracle/sat_oracle.py on torch-CPU, %d threads" % (n, B, R, cores),
+            "sample": "%d full train steps (fwd+loss+bwd+Adam, fp32) of the %s model (%s) at batch %d images x %d captions after 1 warm-up; "
+                      "oracle/sat_oracle.py on torch-CPU, %d threads" % (n, cfg.upper(), CONFIGS[cfg][0], B, R, cores),
             "s_per_step": round(dt, 3)}
 
 
@@ -106,11 +148,30 @@ def log(msg):
         print("[bench %7.1fs] %s" % (time.time() - _T0, msg), file=sys.stderr, flush=True)
 
 
-MIN_WARM_S = 1.5
-PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E ~8 TB/s
-# in-library profile name -> kernel family of profiles/*_pmc_hbm.json (tools/pmc_aggregate.py)
-PMC_FAMILY = {"bn_apply_bwd": "bn_bwd_apply_kernel", "bn_apply_fwd": "bn_apply_kernel", "bn_stats_bwd": "bn_colstats_kernel<1>",
-              "bn_stats_fwd": "bn_colstats_kernel<0>"}
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as children of this process
+    through torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1) and pass rank 0's JSON line through.
+    The parent never touches the GPU (nothing here calls into torch.cuda), and no process that has is ever replaced."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    log("starting %d ranks: %s" % (args.gpus, " ".join(cmd[1:])))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:
+        if out.startswith("{") and '"metric"' in out:
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if rc != 0 or line is None:
+        raise SystemExit("bench.py: the %d-rank run failed (exit code %s)" % (args.gpus, rc))
+    print(line, flush=True)
 
 
 def main():
@@ -123,12 +184,25 @@ def main():
     ap.add_argument("--decoder-tf", default="always", choices=["always", "none"],
                     help="teacher forcing: always (epsilon = 1, the headline) or none (train.py:63 default: argmax feedback after step 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the fp32 parity-mode sub-line and the second CPU baseline")
     ap.add_argument("--batch", type=int, default=None, help="override images per GPU")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: the config's global batch (BASELINE.json: C2 128, C3 256, C4 512 images) is split over the ranks "
+                         "instead of every rank taking the per-GPU batch")
+    ap.add_argument("--bucket-dtype", default="fp32", choices=["fp32", "bf16"], help="wire format of the gradient all-reduce buckets")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
                     help="bf16: bf16 MFMA + bf16 activations (BASELINE configs[1]); fp32: exact fp32 MFMA parity mode")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return spawn_ranks(args)
+
+    import torch
+    import torch.distributed as dist
+
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the SAT hot path has no CPU fallback")
     # SAT_BENCH_REHEARSAL=1 (dev): every rank on GPU 0 with the gloo backend -- rehearses the multi-process flow (buckets, hooks,
@@ -141,13 +215,17 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world)
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     import sat_amd  # noqa: F401
     from sat_amd import _lib, model as M
     from sat_amd.dist import GradSync, broadcast_parameters
 
     hp, T, B, R = hparams(args.config)
+    if args.strong:
+        gb = GLOBAL_BATCH[args.config]
+        if gb % world:
+            raise SystemExit("--strong: the global batch %d does not divide over %d ranks" % (gb, world))
+        B = gb // world
     if args.batch:
         B = args.batch
     if args.decoder_tf == "none":
@@ -158,7 +236,7 @@ def main():
     broadcast_parameters(model)
     model.__dict__["_sat_global_step"] = 2          # past encoder_finetune_after: the encoder trains (and is in the optimizer)
     opt = model.configure_optimizers()
-    sync = GradSync(model)
+    sync = GradSync(model, bucket_dtype=torch.bfloat16 if args.bucket_dtype == "bf16" else torch.float32)
     img, caps, lengths = synthetic_batch(B, R, T, hp["vocab_size"], 1234 + rank, args.ragged)
     img, caps = img.to(dev), caps.to(dev)
 
@@ -170,18 +248,19 @@ def main():
         opt.step()
         return out
 
+    def agree(flag):
+        """every rank must run the same number of steps (each step holds collectives)"""
+        if world > 1:
+            t = torch.tensor([1 if flag else 0], device=dev, dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return bool(t.item())
+        return flag
+
     log("model built (%s, %d images/GPU); warm-up" % (args.config, B))
     # W untimed steps, and in any case MIN_WARM_S seconds of them: a GPU coming out of idle (fresh box / fresh process) needs
     # ~1 s of load before its clocks settle -- with 3 warm-up steps the first 10 timed steps ran 20 % slow (37-42 vs 32 ms)
     t_warm = time.perf_counter(); warm_done = 0
-    while True:
-        more = warm_done < args.warmup or time.perf_counter() - t_warm < MIN_WARM_S
-        if world > 1:        # every rank must run the same number of steps (each step holds collectives): agree on the flag
-            flag = torch.tensor([1 if more else 0], device=dev, dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            more = bool(flag.item())
-        if not more:
-            break
+    while agree(warm_done < args.warmup or time.perf_counter() - t_warm < MIN_WARM_S):
         out = step()
         torch.cuda.synchronize(); warm_done += 1
         if warm_done <= 3 or warm_done % 10 == 0:
@@ -193,14 +272,22 @@ def main():
         step()
     torch.cuda.synchronize()
     entries = sorted(_lib.profile_stop(), key=lambda e: -e["total_ms"])
-    dom_name = entries[0]["name"] if entries else None
+    # the contraction core is ONE kernel family launched under ~20 template names (tile shape x operand form): rank it as one entry
+    gemm = [e for e in entries if e["name"].startswith("gemm_")]
+    fams = [e for e in entries if not e["name"].startswith("gemm_")]
+    if gemm:
+        fams.append(dict(name="gemm_*", launches=sum(e["launches"] for e in gemm), total_ms=sum(e["total_ms"] for e in gemm),
+                         flops=sum(e["flops"] for e in gemm), bytes=sum(e["bytes"] for e in gemm)))
+    fams.sort(key=lambda e: -e["total_ms"])
+    dom_name = fams[0]["name"] if fams else None
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     # ---- the timed region; the dominant family alone stays instrumented inside it (an event pair per launch of that family)
     if os.environ.get("SAT_BENCH_NO_INREGION") == "1":       # dev: A/B the cost of the in-region event pairs
         dom_name = None
-    _lib.profile_start(only=dom_name) if dom_name else None
+    if dom_name:
+        _lib.profile_start(only=dom_name)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -208,7 +295,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    timed = {e["name"]: e for e in _lib.profile_stop()} if dom_name else {}
+    timed = _lib.profile_stop() if dom_name else []
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -216,50 +303,100 @@ def main():
     loss_val = float(out["loss"].item())
     log("timed region: %.1f ms/step" % (dt / args.steps * 1e3))
 
+    line = None
     if rank == 0:
         ms = dt / args.steps * 1e3
         caps_per_s = world * B * R / (dt / args.steps)
-        dom = timed.get(dom_name) or (entries[0] if entries else None)          # the dominant family as measured INSIDE the timed region
-        dom_steps = args.steps if dom_name in timed else prof_steps
+        dom = None
+        if timed:            # the dominant family as measured INSIDE the timed region
+            dom = dict(name=dom_name, launches=sum(e["launches"] for e in timed), total_ms=sum(e["total_ms"] for e in timed),
+                       flops=sum(e["flops"] for e in timed), bytes=sum(e["bytes"] for e in timed))
+        elif fams:
+            dom = fams[0]
+        dom_steps = args.steps if timed else prof_steps
         roof = None
+        peak = PEAK["bf16"] if args.precision == "bf16" else PEAK["f32"]
+        step_tflop = algorithmic_work(args.config, R)["f_cap"] * B * R / 1e12
         if dom:
             hbm_bound = dom["flops"] == 0           # streaming kernels (BatchNorm passes) are instrumented with bytes only
             tf = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
             gbs = dom["bytes"] / (dom["total_ms"] * 1e-3) / 1e9
-            peak = PEAK["bf16"] if ("bf16" in dom["name"] or "glds" in dom["name"]) else PEAK["f32"]
             traffic = None      # HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/pmc_aggregate.py), same workload only
-            pmc = os.path.join(ROOT, "profiles", "r01_bf16_bench_c2_pmc_hbm.json")
-            if args.config == "c2" and args.precision == "bf16" and not args.batch and not args.ragged and os.path.exists(pmc):
-                for row in json.load(open(pmc)):
-                    if row["family"] == PMC_FAMILY.get(dom["name"], dom["name"]):
-                        traffic = round(row["hbm_bytes_per_launch"])
+            pmc_rows, pmc_file = [], None
+            headline = args.config == "c2" and args.precision == "bf16" and not args.batch and not args.ragged and not args.strong
+            for f in PMC_FILES:
+                if headline and os.path.exists(f):
+                    pmc_rows, pmc_file = json.load(open(f)), os.path.relpath(f, ROOT)
+                    break
+            if pmc_rows:
+                want = PMC_FAMILY.get(dom["name"], dom["name"])
+                sel = [r for r in pmc_rows if (r["family"].startswith("gemm_") if want == "gemm_*" else r["family"] == want)]
+                if sel:
+                    traffic = round(sum(r["hbm_bytes_per_launch"] * r["launches"] for r in sel) / sum(r["launches"] for r in sel))
+
+            def row(e):
+                return {"kernel": e["name"], "ms_per_step": round(e["total_ms"] / prof_steps, 3), "launches_per_step": e["launches"] // prof_steps,
+                        "tflops": round(e["flops"] / (e["total_ms"] * 1e-3) / 1e12, 2) if e["total_ms"] > 0 else None,
+                        "gbytes_per_s": round(e["bytes"] / (e["total_ms"] * 1e-3) / 1e9, 1) if e["total_ms"] > 0 else None}
+
             roof = {"bound": "hbm" if hbm_bound else "mfma", "kernel": dom["name"],
                     "achieved": round(gbs if hbm_bound else tf, 2), "peak": PEAK_HBM_GBS if hbm_bound else peak,
                     "unit": "GB/s" if hbm_bound else "TFLOP/s",
-                    "frac": round((gbs / PEAK_HBM_GBS) if hbm_bound else (tf / peak), 4), "traffic": traffic,
+                    "frac": round((gbs / PEAK_HBM_GBS) if hbm_bound else (tf / peak), 4), "traffic": traffic, "traffic_from": pmc_file,
                     "avg_launch_us": round(dom["total_ms"] * 1e3 / dom["launches"], 2), "launches_per_step": dom["launches"] // dom_steps,
+                    "ms_per_step": round(dom["total_ms"] / dom_steps, 3),
                     "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"], "flops_per_launch": dom["flops"] / dom["launches"],
                     "measured_on": ("HIP events on the launch stream around every launch of this family inside the timed region (%d steps); "
-                                    "`top`: every instrumented family over %d untimed steps before it" % (dom_steps, prof_steps)),
-                    "top": [{"kernel": e["name"], "ms_per_step": round(e["total_ms"] / prof_steps, 3),
-                             "tflops": round(e["flops"] / (e["total_ms"] * 1e-3) / 1e12, 2) if e["total_ms"] > 0 else None,
-                             "gbytes_per_s": round(e["bytes"] / (e["total_ms"] * 1e-3) / 1e9, 1) if e["total_ms"] > 0 else None}
-                            for e in entries[:8]]}
+                                    "`families` / `top`: every instrumented family over %d untimed steps before it; `gemm_*` = every template "
+                                    "of the contraction core (tile shape x operand form) summed" % (dom_steps, prof_steps)),
+                    "families": [row(e) for e in fams[:8]],
+                    "top": [row(e) for e in entries[:8]],
+                    # the step as a whole: algorithmic FLOPs of SURVEY 8d (3 x forward contraction work) over the measured step time,
+                    # and the HBM bytes of the committed PMC passes over the same step time
+                    "step_tflop": round(step_tflop, 3), "step_tflops": round(step_tflop / (ms * 1e-3), 1),
+                    "step_mfma_frac": round(step_tflop / (ms * 1e-3) / peak, 4)}
+            meta = [r for r in pmc_rows if r["family"] == "__meta__"]
+            if meta:
+                gb = sum(r["hbm_bytes_per_launch"] * r["launches"] for r in pmc_rows if r["family"] != "__meta__") / meta[0]["steps"] / 1e9
+                roof["step_hbm_gb"] = round(gb, 2)
+                roof["step_hbm_frac"] = round(gb / (ms * 1e-3) / PEAK_HBM_GBS, 4)
         line = {"metric": "captions/sec (train step) at B=128, 256px, seq_len=22", "value": round(caps_per_s, 1), "unit": "captions/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_steps_run": warm_done, "ms_per_step": round(ms, 3), "higher_is_better": True,
-                "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+                "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
                 "config": {"workload": "%s: %s encoder_size=%s encoder_dim=%d vocab=%d T=%d, %d images/GPU x R=%d captions, "
                                        "trainable encoder, Adam, %s lengths, decoder_tf=%s" % (args.config.upper(), CONFIGS[args.config][0],
                                                                                CONFIGS[args.config][1], CONFIGS[args.config][2],
                                                                                hp["vocab_size"], T, B, R, "ragged" if args.ragged else "full", args.decoder_tf),
                            "global_batch_images": world * B, "captions_per_step": world * B * R, "parallelism": "dp%d" % world,
-                           "images_per_s": round(world * B / (dt / args.steps), 1), "final_loss": round(loss_val, 4)},
+                           "images_per_s": round(world * B / (dt / args.steps), 1), "final_loss": round(loss_val, 4),
+                           "grad_bucket_dtype": args.bucket_dtype},
                 "roofline": roof}
+
+    # ---- fp32 parity mode (the mode that meets north_star's 1e-4): a short sub-line of the same workload, after the headline
+    if world == 1 and not args.no_extras and args.precision == "bf16":
+        model.set_precision("fp32")
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        n32 = 5
+        t0 = time.perf_counter()
+        for _ in range(n32):
+            step()
+        torch.cuda.synchronize()
+        d32 = (time.perf_counter() - t0) / n32
+        line["fp32_parity_mode"] = {"ms_per_step": round(d32 * 1e3, 3), "value": round(B * R / d32, 1), "unit": "captions/s", "steps": n32, "warmup": 3,
+                                    "dtype": "f32", "note": "exact fp32 MFMA, fp32 activations: logits / alphas within 1e-4 of the reference"}
+        log("fp32 parity mode: %.1f ms/step" % (d32 * 1e3))
+        model.set_precision("bf16")
+
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             log("CPU baseline (oracle) ...")
             line["cpu_baseline"] = cpu_baseline(args.config)
+            if not args.no_extras and args.config != "c1":      # BASELINE.json configs[0], the reference's own CPU-runnable case
+                line["cpu_baseline_c1"] = cpu_baseline("c1", seconds_budget=12.0)
             log("CPU baseline done")
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -237,6 +237,30 @@ def require_gpu(*tensors):
             raise SatHipError("sat_amd computes on the GPU only: got a %s tensor (no CPU fallback)" % t.device)
 
 
+# ----------------------------------------------------------------------------- gradient destinations (dist.GradSync)
+_grad_sinks = {}
+
+
+def register_grad_sink(param, make_view):
+    """``make_view()`` returns a fresh view of the memory where ``param``'s gradient should be written (a slice of a
+    data-parallel bucket); the backward wrappers ask ``grad_buffer`` for it."""
+    _grad_sinks[id(param)] = make_view
+
+
+def unregister_grad_sink(param):
+    _grad_sinks.pop(id(param), None)
+
+
+def grad_buffer(param):
+    """Where a backward kernel writes ``param``'s gradient: the registered bucket slice when the parameter holds no
+    gradient yet (autograd then adopts the slice as ``param.grad``), else new memory with the parameter's layout
+    (autograd adds it to the existing gradient)."""
+    make = _grad_sinks.get(id(param))
+    if make is not None and param.grad is None:
+        return make()
+    return torch.empty_like(param)
+
+
 def ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 

@@ -1,5 +1,6 @@
 #include "profile.h"
 
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <string>
@@ -12,7 +13,7 @@ namespace {
 struct Rec { std::string name; hipEvent_t e0, e1; double flops, bytes; };
 std::mutex g_mu;
 bool g_on = false;
-std::string g_only;          // non-empty: only scopes of this name are recorded
+std::string g_only;          // non-empty: only scopes of this name (or, ending in '*', of this prefix) are recorded
 std::vector<Rec> g_recs;
 }  // namespace
 
@@ -21,7 +22,10 @@ bool profile_enabled() { return g_on; }
 ProfScope::ProfScope(const char* name, double flops, double bytes, hipStream_t stream) : slot(-1), st(stream) {
     if (!g_on) return;
     std::lock_guard<std::mutex> lk(g_mu);
-    if (!g_only.empty() && g_only != name) return;
+    if (!g_only.empty()) {         // "family" or "prefix*"
+        const bool star = g_only.back() == '*';
+        if (star ? strncmp(name, g_only.c_str(), g_only.size() - 1) != 0 : g_only != name) return;
+    }
     Rec r; r.name = name; r.flops = flops; r.bytes = bytes;
     if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
     hipEventRecord(r.e0, st);

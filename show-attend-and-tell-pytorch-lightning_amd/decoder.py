@@ -165,7 +165,15 @@ class DecoderTrainFn(torch.autograd.Function):
         names = L.param_names(ctx.layers)
         tens = dict(zip(names, params))
         plan, dims = ctx.plan, ctx.dims
-        grads = {k: (None if t is None else torch.empty_like(t)) for k, t in tens.items()}
+        taken = set()
+
+        def gbuf(t):                  # bucket slice of the data-parallel exchange when there is one; a tied weight appears twice: once only
+            if id(t) in taken:
+                return torch.empty_like(t)
+            taken.add(id(t))
+            return L.grad_buffer(t)
+
+        grads = {k: (None if t is None else gbuf(t)) for k, t in tens.items()}
         dann = torch.empty_like(ann)
         if dlogits is None:
             dlogits = torch.zeros(plan.P, dims.V, dtype=torch.float32, device=ann.device)

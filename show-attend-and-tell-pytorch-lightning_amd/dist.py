@@ -9,87 +9,192 @@ few large buckets, launched as soon as their gradients exist --
   fires before the encoder backward starts, so its all-reduce overlaps the whole conv-stack backward);
 * encoder buckets per ResNet stage, last stage first, as the encoder backward produces them.
 
-Each bucket is flattened into one fp32 buffer, all-reduced asynchronously on the communicator's stream and
-copied back (divided by the world size) in ``finish()``, which the optimizer step waits on.
+Every bucket owns ONE persistent flat fp32 buffer.  The backward kernels write each parameter's gradient straight into
+its slice of that buffer (``_lib.grad_buffer``: a fresh view per call, which autograd then adopts as ``p.grad``), so a
+bucket is all-reduced in place: no ``cat`` before the collective and no copy back after it.  A gradient that arrives
+any other way (accumulation into an existing ``p.grad``, a foreign autograd node) is copied into its slice by the hook
+and ``p.grad`` re-pointed at the slice.  ``finish()`` waits for the collectives and divides by the world size; the
+optimizer reads the slices through ``p.grad``.  ``bucket_dtype=torch.bfloat16`` sends a bf16 copy of each bucket
+(half the xGMI bytes; the sum is rounded once per hop) and writes the mean back in fp32.
+
 Per-rank semantics are those of a single-process run on the local shard (F3: InitLSTM mixes rows of the
 *local* batch; BatchNorm uses local batch statistics -- no SyncBN in the reference either)."""
+import contextlib
+
 import torch
 import torch.distributed as dist
 
+from . import _lib as L
+
+
+def _slice_view(flat, off, p):
+    """a fresh view of flat[off : off + p.numel()] with p's shape and memory order (KRSC for channels_last filters)"""
+    seg = flat[off:off + p.numel()]
+    if p.dim() == 4 and not p.is_contiguous() and p.is_contiguous(memory_format=torch.channels_last):
+        k, c, r, s = p.shape
+        return seg.view(k, r, s, c).permute(0, 3, 1, 2)
+    return seg.view(p.shape)
+
+
+class _Bucket:
+    __slots__ = ("params", "offsets", "flat", "pending", "launched", "work", "wire")
+
+    def __init__(self, params):
+        self.params = params
+        self.offsets, off = {}, 0
+        for p in params:
+            self.offsets[id(p)] = off
+            off += (p.numel() + 63) // 64 * 64                  # 256-byte aligned slices
+        self.flat = torch.zeros(off, dtype=torch.float32, device=params[0].device)
+        self.pending, self.launched, self.work, self.wire = 0, False, None, None
+
+    def view(self, p):
+        return _slice_view(self.flat, self.offsets[id(p)], p)
+
+    def owns(self, p):
+        g = p.grad
+        return g is not None and g.data_ptr() == self.flat.data_ptr() + 4 * self.offsets[id(p)] and g.dtype == torch.float32
+
 
 class GradSync:
-    def __init__(self, model, buckets=None):
+    """``sync = GradSync(model)`` once; every step: forward, ``backward()``, ``sync.finish()``, ``optimizer.step()``.
+    Under gradient accumulation wrap the non-final micro-batches in ``with sync.no_sync():`` (DDP's contract)."""
+
+    def __init__(self, model, buckets=None, bucket_dtype=torch.float32):
         self.world = dist.get_world_size() if dist.is_initialized() else 1
-        if buckets is None:
-            buckets = default_buckets(model)
-        self.buckets = [[p for p in b if p.requires_grad] for b in buckets]
-        self.buckets = [b for b in self.buckets if b]
-        self._pending = [0] * len(self.buckets)
-        self._inflight = []
+        self.model = model
+        self._custom = buckets
+        self.bucket_dtype = bucket_dtype
+        self.enabled = True
         self._handles = []
-        self._early = set()                # buckets already launched from inside the encoder backward this step
-        if self.world > 1:
-            for bi, bucket in enumerate(self.buckets):
-                for p in bucket:
-                    self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
-            enc = getattr(model, "encoder", None)
-            if enc is not None and hasattr(enc, "precision"):          # HipEncoder: stage-by-stage notification
-                enc.grad_ready = self.encoder_stage_ready
+        self.buckets = []
+        self._sig = None
+        self._build()
 
-    def _make_hook(self, bi):
-        def hook(param):
-            self._pending[bi] += 1
-            if self._pending[bi] == len(self.buckets[bi]):
-                self._pending[bi] = 0
-                if bi not in self._early:
-                    self._launch(bi)
-        return hook
+    # ------------------------------------------------------------------ construction
+    def _signature(self):
+        return tuple(p.requires_grad for p in self.model.parameters())
 
-    def encoder_stage_ready(self, grads):
-        """Called from the encoder backward with {parameter: gradient} of everything computed so far: buckets that
-        are complete start their all-reduce now, overlapping the rest of the conv-stack backward."""
-        if self.world == 1:
-            return
-        for bi, bucket in enumerate(self.buckets):
-            if bi in self._early or not bucket or any(p not in grads for p in bucket):
-                continue
-            flat = torch.cat([grads[p].reshape(-1) for p in bucket])
-            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
-            self._inflight.append((work, flat, list(bucket)))
-            self._early.add(bi)
-
-    def _launch(self, bi):
-        params = [p for p in self.buckets[bi] if p.grad is not None]
-        if not params:
-            return
-        flat = torch.cat([p.grad.reshape(-1) for p in params])
-        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
-        self._inflight.append((work, flat, params))
-
-    def finish(self):
-        """Wait for every bucket and write the averaged gradients back.  Call after backward, before optimizer.step()."""
-        if self.world == 1:
-            return
-        for bi, n in enumerate(self._pending):       # buckets whose parameters did not all receive a gradient
-            if n:
-                self._pending[bi] = 0
-                if bi not in self._early:
-                    self._launch(bi)
-        self._early = set()
-        for work, flat, params in self._inflight:
-            work.wait()
-            flat.div_(self.world)
-            off = 0
-            for p in params:
-                n = p.grad.numel()
-                p.grad.copy_(flat[off:off + n].view_as(p.grad))
-                off += n
-        self._inflight = []
+    def _build(self):
+        self.remove()
+        groups = self._custom if self._custom is not None else default_buckets(self.model)
+        seen, clean = set(), []
+        for grp in groups:                                       # tied weights appear once
+            keep = []
+            for p in grp:
+                if p.requires_grad and id(p) not in seen:
+                    seen.add(id(p)); keep.append(p)
+            if keep:
+                clean.append(keep)
+        self._sig = self._signature()
+        self.buckets = [_Bucket(g) for g in clean] if self.world > 1 else []
+        self._of = {}
+        for b in self.buckets:
+            for p in b.params:
+                self._of[id(p)] = b
+                self._handles.append(p.register_post_accumulate_grad_hook(self._hook))
+                L.register_grad_sink(p, (lambda b=b, p=p: b.view(p)))
+        enc = getattr(self.model, "encoder", None)
+        if enc is not None and hasattr(enc, "precision"):          # HipEncoder: stage-by-stage notification
+            enc.grad_ready = self.encoder_stage_ready if self.world > 1 else None
 
     def remove(self):
         for h in self._handles:
             h.remove()
         self._handles = []
+        for b in self.buckets:
+            for p in b.params:
+                L.unregister_grad_sink(p)
+                if b.owns(p):
+                    p.grad = p.grad.clone()                      # the flat buffer is about to go away
+        self.buckets = []
+
+    # ------------------------------------------------------------------ per step
+    @contextlib.contextmanager
+    def no_sync(self):
+        """micro-batches whose gradients only accumulate locally (every one but the last of an accumulation window)"""
+        old, self.enabled = self.enabled, False
+        try:
+            yield
+        finally:
+            self.enabled = old
+
+    def _adopt(self, b, p):
+        """make p.grad the bucket slice (copying a gradient that was produced elsewhere)"""
+        if p.grad is None:
+            b.view(p).zero_()
+        elif not b.owns(p):
+            v = b.view(p)
+            v.copy_(p.grad)
+            p.grad = v
+
+    def _hook(self, p):
+        b = self._of.get(id(p))
+        if b is None:
+            return
+        if b.launched:                   # started from inside the encoder backward: the slice already holds (or is receiving) the sum
+            if not b.owns(p):
+                p.grad = b.view(p)       # autograd kept a copy instead of adopting the slice: point at the slice again
+        else:
+            self._adopt(b, p)
+        b.pending += 1
+        if b.pending == len(b.params):
+            b.pending = 0
+            if self.enabled and not b.launched:
+                self._launch(b)
+
+    def encoder_stage_ready(self, grads):
+        """Called from inside the encoder backward with {parameter: gradient} of everything computed so far.  A bucket
+        whose parameters all wrote their gradient straight into its flat buffer (no earlier ``p.grad`` to add to) starts
+        its all-reduce now, overlapping the rest of the conv-stack backward; autograd adopts the same slices afterwards.
+        Anything else (accumulation, a gradient living elsewhere) waits for the post-accumulate hooks."""
+        if self.world == 1 or not self.enabled:
+            return
+        for b in self.buckets:
+            if b.launched:
+                continue
+            ok = True
+            for p in b.params:
+                g = grads.get(p)
+                if g is None or p.grad is not None or g.data_ptr() != b.flat.data_ptr() + 4 * b.offsets[id(p)]:
+                    ok = False
+                    break
+            if ok:
+                self._launch(b)
+
+    def _launch(self, b):
+        b.launched = True
+        if self.bucket_dtype != torch.float32:
+            b.wire = b.flat.to(self.bucket_dtype)
+            b.work = dist.all_reduce(b.wire, op=dist.ReduceOp.SUM, async_op=True)
+        else:
+            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, async_op=True)
+
+    def finish(self):
+        """Wait for every bucket; afterwards every ``p.grad`` holds the mean over ranks.  Call after backward, before
+        ``optimizer.step()`` (with accumulation: after the LAST micro-batch's backward)."""
+        if self.world == 1:
+            return
+        if self._signature() != self._sig:
+            # requires_grad changed since the buckets were laid out (encoder_finetune_after, model.py:584-586): lay them out
+            # again and reduce this step's gradients from where autograd left them
+            self._build()
+        for b in self.buckets:
+            if not b.launched:
+                for p in b.params:                               # parameters the hooks did not see this step
+                    self._adopt(b, p)
+                b.pending = 0
+                self._launch(b)
+        for b in self.buckets:
+            b.work.wait()
+            if b.wire is not None:
+                b.flat.copy_(b.wire)
+                b.wire = None
+            b.flat.div_(self.world)
+            b.work, b.launched, b.pending = None, False, 0
+            for p in b.params:
+                if p.grad is None:                               # unused this step: the mean of the ranks' zeros / gradients
+                    p.grad = b.view(p)
 
 
 def default_buckets(model):

@@ -145,16 +145,21 @@ def _slab(device, nbytes):
     return cur
 
 
-def conv_wgrad(dy, x, w, stride, pad, stride_w=0):
-    """fp32 gradient of the (K,C,R,S) filter, whatever the activation storage."""
+def conv_wgrad(dy, x, w, stride, pad, stride_w=0, param=None):
+    """fp32 gradient of the (K,C,R,S) filter, whatever the activation storage.  ``param``: the filter parameter itself, when the
+    gradient may be written to its data-parallel bucket slice (``_lib.grad_buffer``)."""
     N, H, W, Cc = x.shape
     K, _, R, S = w.shape
     g = _geom(N, H, W, Cc, K, R, S, stride, pad, stride_w)
     lib = L.lib()
     nbytes = max(lib.sat_conv2d_wgrad_slab_bytes(C.byref(g)), 128 << 20)
     slab = _slab(x.device, nbytes)
-    dw = torch.empty(K, R, S, Cc, dtype=torch.float32, device=x.device)       # KRSC
     fn = lib.sat_conv2d_wgrad_bf16 if _is_bf(x) else lib.sat_conv2d_wgrad
+    out = L.grad_buffer(param) if param is not None else None                 # (K,C,R,S), KRSC memory when the parameter is
+    if out is not None and tuple(out.shape) == (K, Cc, R, S) and out.permute(0, 2, 3, 1).is_contiguous():
+        L.check(fn(L.ptr(dy), L.ptr(x), L.ptr(out), C.byref(g), L.ptr(slab), slab.numel(), L.stream_ptr()), "sat_conv2d_wgrad")
+        return out
+    dw = torch.empty(K, R, S, Cc, dtype=torch.float32, device=x.device)       # KRSC
     L.check(fn(L.ptr(dy), L.ptr(x), L.ptr(dw), C.byref(g), L.ptr(slab), slab.numel(), L.stream_ptr()), "sat_conv2d_wgrad")
     return dw.permute(0, 3, 1, 2)                                             # (K,C,R,S) view, channels_last memory
 
@@ -203,7 +208,7 @@ def bn_bwd(dy, x, y, stats, bn, relu, dres=None, dres_accumulate=False):
     lib = L.lib()
     Cc = x.shape[-1]; rows = x.numel() // Cc
     dx = torch.empty_like(x)
-    dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device); dbeta = torch.empty_like(dgamma)
+    dgamma, dbeta = L.grad_buffer(bn.weight), L.grad_buffer(bn.bias)
     scratch = torch.empty(lib.sat_bn_scratch_bytes(rows, Cc) // 8 + 1, dtype=torch.float64, device=x.device)
     L.check(lib.sat_bn_train_bwd_t(int(_is_bf(x)), L.ptr(dy), L.ptr(x), L.ptr(y), rows, Cc, L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(bn.weight),
                                    int(relu), L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dres), int(dres_accumulate),
@@ -247,16 +252,16 @@ def stem_tail_bwd(dy_pool, x, stats, bn):
     lib = L.lib()
     N, H, W, Cc = x.shape
     dx = torch.empty_like(x)
-    dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device); dbeta = torch.empty_like(dgamma)
+    dgamma, dbeta = L.grad_buffer(bn.weight), L.grad_buffer(bn.bias)
     scratch = torch.empty(lib.sat_bn_scratch_bytes(N * H * W, Cc) // 8 + 1, dtype=torch.float64, device=x.device)
     L.check(lib.sat_stem_tail_bwd_t(int(_is_bf(x)), L.ptr(dy_pool), L.ptr(stats[2]), L.ptr(x), N, H, W, Cc, L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(bn.weight),
                                     L.ptr(bn.bias), L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), L.ptr(scratch), L.stream_ptr()), "sat_stem_tail_bwd")
     return dx, dgamma, dbeta
 
 
-def colsum(x2d):
+def colsum(x2d, out=None):
     rows, cols = x2d.shape
-    out = torch.empty(cols, dtype=torch.float32, device=x2d.device)
+    out = torch.empty(cols, dtype=torch.float32, device=x2d.device) if out is None else out
     scratch = torch.empty(((rows + 255) // 256) * cols, dtype=torch.float32, device=x2d.device)
     L.check(L.lib().sat_colsum(L.ptr(x2d), x2d.stride(0), rows, cols, L.ptr(out), L.ptr(scratch), L.stream_ptr()), "sat_colsum")
     return out
@@ -297,22 +302,22 @@ def _block_bwd(r, dout, grads, need_dx, W=None):
     g = torch.empty_like(r.out)                      # gradient of the residual branch (= dout masked by the final ReLU)
     if blk.kind == "basic":
         dx2, grads[blk.bn2.weight], grads[blk.bn2.bias] = bn_bwd(dout, r.c2, r.out, r.s2, blk.bn2, True, dres=g)
-        grads[blk.conv2.weight] = conv_wgrad(dx2, r.a1, blk.conv2.weight, 1, 1)
+        grads[blk.conv2.weight] = conv_wgrad(dx2, r.a1, blk.conv2.weight, 1, 1, param=blk.conv2.weight)
         da1 = conv_dgrad(dx2, W(blk.conv2.weight), r.a1.shape, 1, 1)
         first_w, first_stride, first_pad = blk.conv1.weight, blk.stride, 1
     else:
         dx3, grads[blk.bn3.weight], grads[blk.bn3.bias] = bn_bwd(dout, r.c3, r.out, r.s3, blk.bn3, True, dres=g)
-        grads[blk.conv3.weight] = conv_wgrad(dx3, r.a2, blk.conv3.weight, 1, 0)
+        grads[blk.conv3.weight] = conv_wgrad(dx3, r.a2, blk.conv3.weight, 1, 0, param=blk.conv3.weight)
         da2 = conv_dgrad(dx3, W(blk.conv3.weight), r.a2.shape, 1, 0)
         dx2, grads[blk.bn2.weight], grads[blk.bn2.bias] = bn_bwd(da2, r.c2, r.a2, r.s2, blk.bn2, True)
-        grads[blk.conv2.weight] = conv_wgrad(dx2, r.a1, blk.conv2.weight, blk.stride, 1)
+        grads[blk.conv2.weight] = conv_wgrad(dx2, r.a1, blk.conv2.weight, blk.stride, 1, param=blk.conv2.weight)
         da1 = conv_dgrad(dx2, W(blk.conv2.weight), r.a1.shape, blk.stride, 1)
         first_w, first_stride, first_pad = blk.conv1.weight, 1, 0
     dx1, grads[blk.bn1.weight], grads[blk.bn1.bias] = bn_bwd(da1, r.c1, r.a1, r.s1, blk.bn1, True)
-    grads[first_w] = conv_wgrad(dx1, r.x, first_w, first_stride, first_pad)
+    grads[first_w] = conv_wgrad(dx1, r.x, first_w, first_stride, first_pad, param=first_w)
     if blk.downsample is not None:
         dxd, grads[blk.downsample[1].weight], grads[blk.downsample[1].bias] = bn_bwd(g, r.cd, None, r.sd, blk.downsample[1], False)
-        grads[blk.downsample[0].weight] = conv_wgrad(dxd, r.x, blk.downsample[0].weight, blk.stride, 0)
+        grads[blk.downsample[0].weight] = conv_wgrad(dxd, r.x, blk.downsample[0].weight, blk.stride, 0, param=blk.downsample[0].weight)
         if not need_dx:
             return None
         dx = conv_dgrad(dx1, W(first_w), r.x.shape, first_stride, first_pad)
@@ -448,20 +453,20 @@ class EncoderFn(torch.autograd.Function):
             L.check(lib.sat_resize_bwd(L.ptr(d), L.ptr(dx), Nn, Hh, Ww, Cc, enc.out_size, enc.out_size, st), "sat_resize_bwd")
             d = dx
         if enc.proj is not None:
-            grads[enc.proj.bias] = colsum(d.reshape(-1, d.shape[-1]))
+            grads[enc.proj.bias] = colsum(d.reshape(-1, d.shape[-1]), out=L.grad_buffer(enc.proj.bias))
             if bf:
                 from .decoder import gemm
                 D = enc.proj.out_channels; Cc = t["trunk"].shape[-1]
                 db = cast_bf16(d.reshape(-1, D))
-                dw = torch.empty(D, Cc, dtype=torch.float32, device=d.device)
-                gemm(db, t["trunk"].view(-1, Cc), amode=1, bmode=1, out=dw, slab=_slab(d.device, 128 << 20), bf16_mfma=True)
-                grads[enc.proj.weight] = dw.view(D, Cc, 1, 1)
+                dw = L.grad_buffer(enc.proj.weight)                                   # (D, Cc, 1, 1): D x Cc row-major underneath
+                gemm(db, t["trunk"].view(-1, Cc), amode=1, bmode=1, out=dw.view(D, Cc), slab=_slab(d.device, 128 << 20), bf16_mfma=True)
+                grads[enc.proj.weight] = dw
                 if enc.trunk_trainable:
                     dtr = torch.empty(t["trunk"].shape, dtype=BF16, device=d.device)
                     gemm(db, Wt(enc.proj.weight).view(D, Cc), amode=0, bmode=1, out=dtr.view(-1, Cc), bf16_mfma=True)
                     d = dtr
             else:
-                grads[enc.proj.weight] = conv_wgrad(d, t["trunk"], enc.proj.weight, 1, 0)
+                grads[enc.proj.weight] = conv_wgrad(d, t["trunk"], enc.proj.weight, 1, 0, param=enc.proj.weight)
                 d = conv_dgrad(d, enc.proj.weight, t["trunk"].shape, 1, 0) if enc.trunk_trainable else None
         if enc.trunk_trainable:
             n_per_stage = [len(enc[li]) for li in (5, 6, 7, 8)]
@@ -483,7 +488,7 @@ class EncoderFn(torch.autograd.Function):
                 dwp = conv_wgrad(dc0, t["x0"], t["wp"], 2, 0, stride_w=1)               # (64,8,7,4) view of K,7,4,8 fp32 memory
             else:
                 dwp = conv_wgrad(dc0, t["x0"], t["wp"], 2, 3)                          # (64,cpad,7,7) view of KRS{4,8} fp32 memory
-            dw3 = torch.empty_like(_krsc(enc[1].weight))
+            dw3 = L.grad_buffer(enc[1].weight)
             if t.get("stem_pairs"):
                 L.check(lib.sat_stem_filter_grad_unpairs(L.ptr(dwp), L.ptr(dw3), enc[1].out_channels, st), "sat_stem_filter_grad_unpairs")
             elif bf:

@@ -455,7 +455,8 @@ class SAT(SATDecoder, _Base):
             hp.setdefault(k, v)
         self.scheduler = None
         self.opt_init_lr = None
-        self.__dict__["_sat_global_step"] = 0
+        self.__dict__["_sat_global_step"] = 0           # optimizer steps taken (Lightning's trainer.global_step when no trainer is attached)
+        self.__dict__["_sat_micro_batches"] = 0         # training_step calls inside the current accumulation window
         # reference order: criterion -> encoder -> decoder parts (model.py:148-195); get_encoder writes
         # hp.encoder_dim back when no projection is needed (model.py:56)
         self._build_decoder(hp, encoder_factory=get_encoder)
@@ -545,19 +546,54 @@ class SAT(SATDecoder, _Base):
             return math.exp(math.log(hp.decoder_tf_min) / hp.epochs) ** current_epoch
         raise ValueError("decoder_tf=%r" % (hp.decoder_tf,))
 
+    def sat_global_step(self):
+        """Lightning's ``trainer.global_step`` (optimizer steps taken so far); without a trainer, the module's own count:
+        one more every ``hparams.accumulate`` calls of ``training_step`` (train.py:70-71, 267)."""
+        tr = getattr(self, "_trainer", None) if pl is not None else None
+        if tr is not None:
+            return int(tr.global_step)
+        return int(self.__dict__["_sat_global_step"])
+
+    def _train_optimizer(self):
+        """the optimizer ``configure_optimizers`` built: Lightning's ``self.optimizers()`` under a trainer"""
+        if pl is not None and getattr(self, "_trainer", None) is not None:
+            return self.optimizers()
+        return self.__dict__.get("_sat_optimizer")
+
+    def step_learning_rate(self, gstep):
+        """model.py:614-626, run at the end of every ``training_step`` with the optimizer steps taken so far: linear warm-up of
+        every group's LR from ``opt_init_lr`` while ``gstep < lr_warmup_steps``; afterwards the per-batch schedulers
+        (CosineAnnealingWarmRestarts, OneCycleLR) advance once per call."""
+        hp = self.hp
+        opt = self._train_optimizer()
+        if opt is None or self.opt_init_lr is None:          # the caller drives its own optimizer (configure_optimizers never ran)
+            return
+        if gstep < hp.lr_warmup_steps:
+            lr_scale = min(1, float(gstep + 1) / hp.lr_warmup_steps)
+            for pg, init_lr in zip(opt.param_groups, self.opt_init_lr):
+                pg["lr"] = lr_scale * init_lr
+        elif gstep > 0:
+            if type(self.scheduler) in [CosineAnnealingWarmRestarts, OneCycleLR]:
+                self.scheduler.step()
+
     def training_step(self, batch, batch_idx=0):
         """model.py:559-628: returns the metrics dict whose "loss" the trainer back-propagates."""
         hp = self.hp
-        epoch = getattr(self, "current_epoch", 0) if pl is not None and isinstance(self, pl.LightningModule) else 0
+        epoch = int(getattr(self, "current_epoch", 0) or 0)        # Lightning's property, or a plain attribute set by the caller's loop
         epsilon = self.teacher_forcing_epsilon(epoch)
-        gstep = self.__dict__["_sat_global_step"]
+        gstep = self.sat_global_step()
         if gstep == hp.encoder_finetune_after and hp.encoder_finetune_after >= 0:
             for p in self.encoder.parameters():
                 p.requires_grad = True
         lp, tp, alphas = self.train_batch(batch, epsilon)
         loss = self.criterion(lp.data, tp.data)                                   # model.py:592
         loss = loss + Dk.DoublyStochasticFn.apply(alphas, float(hp.att_gamma))      # model.py:594
-        self.__dict__["_sat_global_step"] = gstep + 1
+        self.step_learning_rate(gstep)                                            # model.py:614-626
+        micro = self.__dict__["_sat_micro_batches"] + 1
+        if micro >= max(1, int(getattr(hp, "accumulate", 1) or 1)):                # the trainer steps the optimizer after this batch
+            self.__dict__["_sat_global_step"] += 1
+            micro = 0
+        self.__dict__["_sat_micro_batches"] = micro
         return {"loss": loss, "accuracy": self.criterion.last_accuracy, "epsilon_tf": float(epsilon)}
 
     # ------------------------------------------------------------------ validation (model.py:630-718)
@@ -673,6 +709,7 @@ class SAT(SATDecoder, _Base):
         else:
             opt = torch.optim.AdamW(params, lr=hp.decoder_lr, betas=(hp.adam_b1, hp.adam_b2))
         self.opt_init_lr = [pg["lr"] for pg in opt.param_groups]
+        self.__dict__["_sat_optimizer"] = opt
         sched = getattr(hp, "scheduler", None)
         if sched == "step":
             self.scheduler = MultiStepLR(opt, milestones=hp.milestones, gamma=hp.lr_gamma)

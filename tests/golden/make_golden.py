@@ -348,6 +348,52 @@ def g_encoder():
          out_sum=y1.double().sum().detach(), seed=np.int64(7), **counts)
 
 
+# ---------------------------------------------------------------- G12: learning-rate trace of the reference's own training_step
+def g12():
+    """model.py:614-626 (+ configure_optimizers, model.py:720-817) executed by the reference itself: per-batch learning rates of
+    every parameter group under linear warm-up, CosineAnnealingWarmRestarts (per-batch stepping, t0 re-fit), OneCycleLR, and
+    warm-up under gradient accumulation (trainer.global_step advances once per `accumulate` batches)."""
+    from types import SimpleNamespace
+    cases = {
+        "warm_cosine": dict(scheduler="cosine", lr_warmup_steps=5, cosine_iterations=6, cosine_multi=1, accumulate=1),
+        "warm_cosine_tm2": dict(scheduler="cosine", lr_warmup_steps=3, cosine_iterations=4, cosine_multi=2, accumulate=1),
+        "one_cycle": dict(scheduler="one_cycle", lr_warmup_steps=4, accumulate=1),
+        "warm_accumulate2": dict(scheduler=None, lr_warmup_steps=6, accumulate=2),
+        "warm_plateau": dict(scheduler="plateau", lr_warmup_steps=4, accumulate=1),
+    }
+    out = {}
+    for name, over in cases.items():
+        hp = small_hp(opt="adam", decoder_lr=2e-3, embedding_lr=5e-3, encoder_lr=1e-4, weight_decay=1e-4, adam_b1=0.9, adam_b2=0.999,
+                      momentum=0.9, nesterov=False, epochs=2, train_loader_len=10, min_lr=1e-6, lr_gamma=0.5, plateau_patience=1,
+                      milestones=[1], one_cycle_pct=0.3, one_cycle_div=10.0, one_cycle_fdiv=100.0, decoder_tf=None, **over)
+        model, _ = build(hp, 60)
+        opt = model.configure_optimizers()
+        model.optimizers = lambda opt=opt: opt
+        model.logger = SimpleNamespace(experiment=SimpleNamespace(add_scalar=lambda *a, **k: None))
+        model.current_epoch = 0
+        B, R, T, H, W = 2, 2, 6, 2, 2
+        ann = torch.from_numpy(prng.uniform((B, hp.encoder_dim, H, W), 61))
+        caps_np, len_np = prng.captions(B, R, T, hp.vocab_size, 62)
+        batch = (ann, torch.from_numpy(caps_np), torch.from_numpy(len_np))
+        trace = []
+        n_batches = hp.epochs * hp.train_loader_len
+        for b in range(n_batches):
+            g = b // hp.accumulate
+            model.trainer = SimpleNamespace(global_step=g)
+            model.global_step = g
+            torch.manual_seed(1000 + b)
+            metrics = model.training_step(batch, b)
+            trace.append([pg["lr"] for pg in opt.param_groups])
+            metrics["loss"].backward()
+            if (b + 1) % hp.accumulate == 0:
+                opt.step(); opt.zero_grad()
+        out[name + ".lr"] = np.array(trace, np.float64)
+        out[name + ".init_lr"] = np.array(model.opt_init_lr, np.float64)
+        for k, v in over.items():
+            out[name + ".hp." + k] = np.array(-1 if v is None else v) if not isinstance(v, str) else np.array(v)
+    save("g12_lr_trace", **out)
+
+
 if __name__ == "__main__":
     g1(); g2(); g3()
     g4("tf1", 1.0, 40)
@@ -359,4 +405,4 @@ if __name__ == "__main__":
     g4("layers2", 1.0, 46, decoder_layers=2)
     g4("embnorm", 1.0, 47, embed_norm=0.3)
     g4("gamma", 0.0, 48, att_gamma=0.5, B=4, R=3, T=9, H=3, W=3)
-    g6(); g7(); g8(); g9(); g10(); g11(); g_encoder()
+    g6(); g7(); g8(); g9(); g10(); g11(); g12(); g_encoder()

@@ -1,5 +1,9 @@
 """CPU, world_size 2 over gloo: the data-parallel gradient exchange (sat_amd/dist.py) averages gradients
-exactly like one process on the concatenated batch, bucket by bucket, and parameters start identical."""
+exactly like one process on the concatenated batch, bucket by bucket, and parameters start identical.
+Covers the persistent flat buckets (gradients written straight into their slices through ``_lib.grad_buffer`` and
+adopted by autograd, or copied in by the hooks), the early launch from inside the encoder backward, gradient
+accumulation (``no_sync``), parameters unfrozen after construction (encoder_finetune_after, reference
+model.py:584-586) and the bf16 wire format."""
 import os
 import sys
 
@@ -10,6 +14,23 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+class _SinkLinear(torch.autograd.Function):
+    """y = x @ w.T whose backward writes dw where the product's backward wrappers do: ``_lib.grad_buffer(w)``."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return x @ w.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        from sat_amd import _lib as L
+        x, w = ctx.saved_tensors
+        dw = L.grad_buffer(w)
+        torch.mm(g.t(), x, out=dw)
+        return g @ w, dw
+
+
 class Toy(torch.nn.Module):
     """Parameter names shaped like the product's (encoder.<idx>.* / decoder keys) so default_buckets applies."""
 
@@ -17,10 +38,17 @@ class Toy(torch.nn.Module):
         super().__init__()
         self.encoder = torch.nn.Sequential(*[torch.nn.Linear(6, 6) for _ in range(10)])
         self.embedding = torch.nn.Embedding(11, 6)
+        self.sink = torch.nn.Parameter(torch.randn(6, 6) * 0.3)      # decoder-side parameter with a sink-writing backward
         self.output = torch.nn.Linear(6, 3)
 
     def forward(self, idx, x):
-        return self.output(self.encoder(x + self.embedding(idx))).pow(2).mean()
+        h = self.encoder(x + self.embedding(idx))
+        return self.output(_SinkLinear.apply(h, self.sink)).pow(2).mean()
+
+
+def _data():
+    g = torch.Generator().manual_seed(7)
+    return torch.randint(0, 11, (8,), generator=g), torch.randn(8, 6, generator=g)
 
 
 def _worker(rank, world, port, out):
@@ -34,26 +62,76 @@ def _worker(rank, world, port, out):
     broadcast_parameters(model)
     sync = GradSync(model)
     assert len(default_buckets(model)) == 5 and len(sync.buckets) == 5
-    g = torch.Generator().manual_seed(7)
-    idx = torch.randint(0, 11, (8,), generator=g); x = torch.randn(8, 6, generator=g)
+    idx, x = _data()
     sl = slice(rank * 4, rank * 4 + 4)
-    for step in range(2):                               # two steps: hooks re-arm
+    for step in range(2):                               # two steps: hooks re-arm, slices are re-used
         model.zero_grad(set_to_none=True)
         model(idx[sl], x[sl]).backward()
         sync.finish()
-    # early path: the encoder backward announces a finished stage before autograd has accumulated anything
+        for b in sync.buckets:                          # every gradient lives in its bucket slice: nothing to copy back
+            assert all(b.owns(p) for p in b.params)
     ref_grads = {k: p.grad.clone() for k, p in model.named_parameters()}
+    res = {"plain": ref_grads}
+
+    # early path: the encoder backward announces a finished stage whose gradients already sit in the bucket slices
     model.zero_grad(set_to_none=True)
     loss = model(idx[sl], x[sl])
     stage = sync.buckets[1]                              # the "projection + layer4" bucket
-    sync.encoder_stage_ready(dict(zip(stage, torch.autograd.grad(loss, stage, retain_graph=True))))
-    assert 1 in sync._early
+    early = {}
+    for p, g in zip(stage.params, torch.autograd.grad(loss, stage.params, retain_graph=True)):
+        v = stage.view(p); v.copy_(g); early[p] = v
+    sync.encoder_stage_ready(early)
+    assert stage.launched
     loss.backward()
     sync.finish()
     for k, p in model.named_parameters():
         assert torch.allclose(p.grad, ref_grads[k], atol=1e-7, rtol=1e-6), k
-    assert not sync._early and not sync._inflight
-    torch.save({k: p.grad.clone() for k, p in model.named_parameters()}, out % rank)
+    assert not any(b.launched for b in sync.buckets)
+
+    # accumulation: two micro-batches of two samples; only the second one exchanges
+    model.zero_grad(set_to_none=True)
+    a, b_ = slice(rank * 4, rank * 4 + 2), slice(rank * 4 + 2, rank * 4 + 4)
+    with sync.no_sync():
+        (0.5 * model(idx[a], x[a])).backward()
+        sync.encoder_stage_ready({p: p.grad for p in stage.params})       # must not start anything
+        assert not any(bk.launched for bk in sync.buckets)
+    (0.5 * model(idx[b_], x[b_])).backward()
+    sync.finish()
+    res["accumulate"] = {k: p.grad.clone() for k, p in model.named_parameters()}
+
+    # bf16 on the wire
+    sync16 = None
+    sync.remove()
+    sync16 = GradSync(model, bucket_dtype=torch.bfloat16)
+    model.zero_grad(set_to_none=True)
+    model(idx[sl], x[sl]).backward()
+    sync16.finish()
+    res["bf16"] = {k: p.grad.clone() for k, p in model.named_parameters()}
+    sync16.remove()
+
+    # frozen encoder, unfrozen later (model.py:584-586): the buckets are laid out again
+    for p in model.encoder.parameters():
+        p.requires_grad = False
+    sync = GradSync(model)
+    assert len(sync.buckets) == 1
+    model.zero_grad(set_to_none=True)
+    model(idx[sl], x[sl]).backward()
+    sync.finish()
+    assert all(p.grad is None for p in model.encoder.parameters())
+    for p in model.encoder.parameters():
+        p.requires_grad = True
+    model.zero_grad(set_to_none=True)
+    model(idx[sl], x[sl]).backward()
+    sync.finish()
+    assert len(sync.buckets) == 5
+    res["unfrozen"] = {k: p.grad.clone() for k, p in model.named_parameters()}
+    model.zero_grad(set_to_none=True)                    # and the step after runs through the hooks again
+    model(idx[sl], x[sl]).backward()
+    sync.finish()
+    for k, p in model.named_parameters():
+        assert torch.allclose(p.grad, res["unfrozen"][k], atol=1e-7, rtol=1e-6), k
+
+    torch.save(res, out % rank)
     torch.save({k: p.detach().clone() for k, p in model.named_parameters()}, (out % rank) + ".w")
     dist.destroy_process_group()
 
@@ -61,15 +139,20 @@ def _worker(rank, world, port, out):
 def test_two_rank_gradient_mean_matches_single_process(tmp_path):
     out = str(tmp_path / "grads_%d.pt")
     mp.spawn(_worker, args=(2, 29533, out), nprocs=2, join=True)
-    g0, g1 = torch.load(out % 0), torch.load(out % 1)
+    r0, r1 = torch.load(out % 0), torch.load(out % 1)
     w0, w1 = torch.load((out % 0) + ".w"), torch.load((out % 1) + ".w")
+    sys.path.insert(0, ROOT)
     model = Toy()
     model.load_state_dict(w0)
     for k in w0:
         assert torch.equal(w0[k], w1[k]), k                 # broadcast made the replicas identical
-    g = torch.Generator().manual_seed(7)
-    idx = torch.randint(0, 11, (8,), generator=g); x = torch.randn(8, 6, generator=g)
+    idx, x = _data()
     (0.5 * (model(idx[:4], x[:4]) + model(idx[4:], x[4:]))).backward()
-    for k, p in model.named_parameters():
-        assert torch.equal(g0[k], g1[k]), k                 # every rank ends with the same gradient
-        assert torch.allclose(g0[k], p.grad, atol=1e-7, rtol=1e-5), k
+    for case in ("plain", "accumulate", "bf16", "unfrozen"):
+        g0, g1 = r0[case], r1[case]
+        for k, p in model.named_parameters():
+            assert torch.equal(g0[k], g1[k]), (case, k)         # every rank ends with the same gradient
+            if case == "bf16":
+                assert torch.allclose(g0[k], p.grad, atol=2e-3 * p.grad.abs().max().item() + 1e-6, rtol=1e-2), (case, k)
+            else:
+                assert torch.allclose(g0[k], p.grad, atol=1e-7, rtol=1e-5), (case, k)

@@ -1,0 +1,91 @@
+"""CPU tests of the host-side logic around the hot path: the per-batch learning-rate recipe of ``SAT.training_step``
+(reference model.py:614-626) against the trace the REFERENCE itself produced (fixture G12, tests/golden/make_golden.py:g12),
+and the algorithmic-work formulas bench.py reports against SURVEY 8d's table."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+from oracle import sat_oracle as O  # noqa: E402
+
+
+def _hp(case, d):
+    over = {}
+    for k in d.files:
+        if k.startswith(case + ".hp."):
+            v = d[k]
+            name = k[len(case) + 4:]
+            over[name] = (str(v) if v.dtype.kind in "US" else (None if float(v) == -1 else (int(v) if float(v).is_integer() else float(v))))
+    return over
+
+
+@pytest.mark.parametrize("case", ["warm_cosine", "warm_cosine_tm2", "one_cycle", "warm_accumulate2", "warm_plateau"])
+@pytest.mark.parametrize("fused", [True, False])
+def test_learning_rate_trace_equals_the_reference(case, fused):
+    import sat_amd  # noqa: F401
+    from sat_amd import model as M
+    d = np.load(os.path.join(GOLD, "g12_lr_trace.npz"))
+    over = _hp(case, d)
+    hp = O.default_hparams(vocab_size=23, encoder_dim=12, embed_dim=10, attention_dim=7, decoder_dim=9, input_size=64,
+                           opt="adam", decoder_lr=2e-3, embedding_lr=5e-3, encoder_lr=1e-4, weight_decay=1e-4, adam_b1=0.9, adam_b2=0.999,
+                           momentum=0.9, nesterov=False, epochs=2, train_loader_len=10, min_lr=1e-6, lr_gamma=0.5, plateau_patience=1,
+                           milestones=[1], one_cycle_pct=0.3, one_cycle_div=10.0, one_cycle_fdiv=100.0, decoder_tf=None,
+                           fused_optimizer=fused, **over)
+    model = M.SAT(**vars(hp))
+    opt = model.configure_optimizers()
+    assert np.allclose(model.opt_init_lr, d[case + ".init_lr"], rtol=0, atol=0)
+    want = d[case + ".lr"]
+    acc = int(over.get("accumulate", 1))
+    got = []
+    for b in range(want.shape[0]):
+        # what training_step does after the forward pass (the forward itself needs the GPU): the LR recipe, then the step count
+        g = model.sat_global_step()
+        assert g == b // acc
+        model.step_learning_rate(g)
+        got.append([pg["lr"] for pg in opt.param_groups])
+        micro = model.__dict__["_sat_micro_batches"] + 1
+        if micro >= acc:
+            model.__dict__["_sat_global_step"] += 1; micro = 0
+        model.__dict__["_sat_micro_batches"] = micro
+    got = np.array(got)
+    assert got.shape == want.shape
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-15), (got[:6], want[:6])
+
+
+def test_algorithmic_work_equals_the_survey_table():
+    import bench
+    table = {"c1": (4.75, 3.21, 8.30, 3.38), "c2": (10.81, 6.42, 9.76, 7.12), "c3": (20.51, 25.69, 9.95, 13.01), "c4": (59.70, 51.38, 14.88, 37.36)}
+    for cfg, (enc, pre, step, cap) in table.items():
+        w = bench.algorithmic_work(cfg)
+        assert abs(w["f_enc"] / 1e9 - enc) < 0.006 and abs(w["f_pre"] / 1e6 - pre) < 0.006
+        assert abs(w["f_step"] / 1e6 - step) < 0.006 and abs(w["f_cap"] / 1e9 - cap) < 0.006
+
+
+def test_bench_starts_its_own_ranks_without_touching_the_gpu(monkeypatch, capsys):
+    """`python bench.py --gpus 2` (no launcher): the parent only builds a torch.distributed.run command line and relays the JSON line."""
+    import bench
+    seen = {}
+
+    class FakeProc:
+        def __init__(self, cmd, **kw):
+            seen["cmd"], seen["env"] = cmd, kw.get("env")
+            self.stdout = iter(["noise\n", '{"metric": "m", "value": 1}\n'])
+
+        def wait(self):
+            return 0
+
+    monkeypatch.setattr(bench.subprocess, "Popen", FakeProc)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3"])
+    monkeypatch.delenv("RANK", raising=False)
+    bench.main()
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "2"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "2", "--steps", "3"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert capsys.readouterr().out.strip() == '{"metric": "m", "value": 1}'

@@ -2,7 +2,10 @@
 per-kernel HBM bytes per launch.  FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE tallies 64 B per 128-B
 request for wide coalesced streaming reads, so the read side is doubled.
 
-    python tools/pmc_aggregate.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_bf16_bench_c2_pmc_hbm.json
+    python tools/pmc_aggregate.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r02_bf16_bench_c2_pmc_hbm.json [steps]
+
+``steps`` = train steps the profiled command ran (warm-up + profile + timed + extras); written as a ``__meta__`` row so
+that bench.py can state HBM bytes per step.
 """
 import collections, csv, glob, json, re, sys
 
@@ -43,6 +46,12 @@ if __name__ == "__main__":
         rows.append(dict(family=k, launches=n, read_bytes_per_launch=2 * fs * 1024 / n, write_bytes_per_launch=ws * 1024 / n,
                          hbm_bytes_per_launch=(2 * fs + ws) * 1024 / n, avg_us_under_pmc=t / n / 1e3))
     rows.sort(key=lambda r: -r["avg_us_under_pmc"] * r["launches"])
+    if len(sys.argv) > 4:
+        total = sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows)
+        rows.append(dict(family="__meta__", steps=int(sys.argv[4]), launches=0, hbm_bytes_per_launch=0.0, hbm_gb_per_step=total / int(sys.argv[4]) / 1e9))
+        print("HBM bytes per step: %.2f GB over %s steps" % (total / int(sys.argv[4]) / 1e9, sys.argv[4]))
     json.dump(rows, open(sys.argv[3], "w"), indent=1)
     for r in rows[:10]:
+        if r["family"] == "__meta__":
+            continue
         print("%-40s n=%4d  %8.1f MB/launch  %7.1f us" % (r["family"], r["launches"], r["hbm_bytes_per_launch"] / 1e6, r["avg_us_under_pmc"]))
