@@ -13,7 +13,9 @@
  *     layout, conv weights are KRSC (torch channels_last memory), activations NHWC;
  *   - no allocation, no synchronisation, no ownership transfer: the caller provides
  *     outputs and a workspace (size from the *_workspace_bytes query) and a hipStream_t
- *     (passed as void*); calls are capture-safe and re-entrant per stream;
+ *     (passed as void*); calls are re-entrant per stream.  Stream capture (hipGraph): sat_beam_search_batched /
+ *     _sampled enqueue kernels only and are tested under capture + replay; the other entry points also enqueue
+ *     hipMemsetAsync / hipMemcpyAsync nodes (and read HOST arrays while enqueueing) and are NOT tested under capture;
  *   - return 0 on success, non-zero otherwise with text in sat_last_error()
  *     (thread-local).  Nothing throws, nothing exits.
  */
@@ -26,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SAT_HIP_ABI_VERSION 14
+#define SAT_HIP_ABI_VERSION 15
 
 int sat_abi_version(void);
 /* dev aid: after every kernel launch wait for the device and print the launch's name to stderr (a device fault then points at the
@@ -220,6 +222,58 @@ int sat_attention_precompute(const float* ann, const float* att_enc_w, float* U,
 int sat_attention_step_fwd(const float* ann, const float* U, const float* hc, int32_t hc_ld, const float* att_f,
                            const int32_t* lengths, int32_t step, float* alphas, int32_t T1, float* Z, float* XZ,
                            int32_t B, int32_t R, int32_t L, int32_t D, int32_t A, void* stream);
+
+/* Backward of sat_attention_step_fwd (what autograd does for SoftAttention.forward + the gate product, model.py:94-109, 541).
+ * dZ: gradient of the un-gated context Z (from DeepOutput), dXZ: gradient of the gated context beta * z (from the LSTM input).
+ * Outputs: DZ (rows, D) = total gradient of z; dhc[:, 0:A] = gradient of q = h W_d^T, dhc[:, A:A+D] = gradient of the gate's
+ * pre-activation; dU (B, L, A) and dwf_part (B, A) are ACCUMULATED (+=: zero them before the first step; attention.f_att.weight's
+ * gradient is the column sum of dwf_part); da_scratch: (B*R, L) floats.  dalphas: external gradient of alphas (same layout) or NULL.
+ * The annotation gradient is  dann = sat_attention_context_bwd(alphas, DZ) + dU * W_e  (the second term a GEMM). */
+int sat_attention_step_bwd(const float* ann, const float* U, const float* hc, int32_t hc_ld, const float* att_f, const int32_t* lengths, int32_t step,
+                           const float* alphas, const float* dalphas, int32_t T1, const float* Z, const float* dZ, const float* dXZ, float* DZ, float* dhc,
+                           int32_t dhc_ld, float* dU, float* dwf_part, float* da_scratch, int32_t B, int32_t R, int32_t L, int32_t D, int32_t A, void* stream);
+/* dann[b, l, :] (+)= sum over the image's R captions and their live steps t < lengths of alphas[b*R + r, t, l] * DZ[t, b*R + r, :]
+ * (alphas (B*R, T1, L); DZ time-major (T1, B*R, D)) */
+int sat_attention_context_bwd(const float* alphas, const float* DZ, const int32_t* lengths, float* dann, int32_t accumulate, int32_t B, int32_t R, int32_t T1,
+                              int32_t L, int32_t D, void* stream);
+/* nn.LSTM, one layer, one time step for N rows (model.py:175-180, called with seq_len 1 at model.py:326, 544).  x (N, in), weights in
+ * torch's layout (4n, in) / (4n, n), gate order i,f,g,o.  `gates` (N, 4n) receives the ACTIVATED gates, the only tensor backward needs
+ * besides the states.  bias_scratch: 4n floats.  Backward: dx, dh_prev, dc_prev and the four parameter gradients are overwritten;
+ * dc_new may be NULL (no gradient into the new cell state); dgates (N, 4n) and scratch (ceil(N/256) * 4n floats) are work space. */
+int sat_lstm_cell_fwd(const float* x, int32_t in, const float* h_prev, const float* c_prev, const float* w_ih, const float* w_hh, const float* b_ih,
+                      const float* b_hh, float* gates, float* h_new, float* c_new, float* bias_scratch, int32_t N, int32_t n, void* stream);
+int sat_lstm_cell_bwd(const float* x, int32_t in, const float* h_prev, const float* c_prev, const float* c_new, const float* gates, const float* dh_new,
+                      const float* dc_new, const float* w_ih, const float* w_hh, float* dx, float* dh_prev, float* dc_prev, float* dw_ih, float* dw_hh,
+                      float* db_ih, float* db_hh, float* dgates, float* scratch, int32_t N, int32_t n, void* stream);
+/* DeepOutput.forward (model.py:125-131): logits = (dropout(tanh(prev_embed + hidden W_h^T + context W_c^T))) W_o^T + b_o; context = NULL is the
+ * shallow form (x = hidden W_h^T; prev_embed unused).  u (N, m) keeps x for backward, udrop (N, m) the dropped copy (dropout > 0 only; masks =
+ * counter-based hash of (seed, element), the same in backward).  Backward overwrites every output; d_prev_embed doubles as the (N, m) work
+ * buffer in the shallow form; db_out may be NULL (weight tying); scratch: ceil(N/256) * V floats. */
+int sat_deep_output_fwd(const float* prev_embed, const float* hidden, const float* context, const float* w_hidden, const float* w_context, const float* w_out,
+                        const float* b_out, float dropout, uint64_t seed, float* u, float* udrop, float* logits, int32_t N, int32_t m, int32_t n, int32_t D,
+                        int32_t V, void* stream);
+int sat_deep_output_bwd(const float* dlogits, const float* hidden, const float* context, const float* u, const float* udrop, const float* w_hidden,
+                        const float* w_context, const float* w_out, float dropout, uint64_t seed, float* d_prev_embed, float* d_hidden, float* d_context,
+                        float* dw_hidden, float* dw_context, float* dw_out, float* db_out, float* scratch, int32_t N, int32_t m, int32_t n, int32_t D, int32_t V,
+                        void* stream);
+/* InitLSTM.forward (model.py:76-81) for N annotation rows (N, L, D): mean over L -> dropout -> factorize -> init.  `init` (N, n2 = 2 n layers)
+ * row-major IS the reference's (2 layers, N, n) buffer: its `.reshape` without a permute is a reinterpretation, h0 = the first
+ * layers*N*n floats, c0 = the rest.  mean (N, D) (after dropout) and f (N, m) are kept for backward, which overwrites the four parameter
+ * gradients and dann (N, L, D); df (N, m), dmean (N, D), scratch (ceil(N/256) * max(n2, m) floats) are work space. */
+int sat_init_lstm_fwd(const float* ann, const float* w_f, const float* b_f, const float* w_i, const float* b_i, float dropout, uint64_t seed, float* mean, float* f,
+                      float* init, int32_t N, int32_t L, int32_t D, int32_t m, int32_t n2, void* stream);
+int sat_init_lstm_bwd(const float* dinit, const float* mean, const float* f, const float* w_f, const float* w_i, float dropout, uint64_t seed, float* dw_f,
+                      float* db_f, float* dw_i, float* db_i, float* dann, float* df, float* dmean, float* scratch, int32_t N, int32_t L, int32_t D, int32_t m,
+                      int32_t n2, void* stream);
+
+/* nn.Embedding(V, m, max_norm, padding_idx) as the reference calls it (model.py:158-164; uses at 298, 526).  Forward: rows of `table`
+ * gathered by token id (-1 = zero row); max_norm > 0 first renormalises, IN PLACE like torch, the table rows that occur in `tokens`
+ * (flags_scratch: V ints).  Backward: dtable fully overwritten; rows of dY are added per vocabulary row in increasing row order (no
+ * floating-point atomics), the padding row stays zero; scratch: 3 V + 1 + rows ints. */
+int sat_embedding_fwd(float* table, const int32_t* tokens, float* out, int32_t rows, int32_t V, int32_t m, float max_norm, int32_t* flags_scratch, void* stream);
+int sat_embedding_bwd(const float* dY, const int32_t* tokens, float* dtable, int32_t rows, int32_t V, int32_t m, int32_t padding_idx, int32_t* scratch, void* stream);
+/* backward of the beta gate's Sigmoid (model.py:187-192): dpre = dy * y * (1 - y); the Linear around it is sat_gemm_f32 (epi 2 forward) */
+int sat_sigmoid_bwd(const float* dy, const float* y, float* dpre, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------ encoder (get_encoder, model.py:16-63)
  * The reference builds the encoder from torchvision ResNet layers (model.py:19-29) + Normalize

@@ -182,6 +182,21 @@ SYMBOLS.update({"sat_optimizer_chunk_elems": (C.c_int32, []),
                 "sat_optimizer_step": (C.c_int, [_vp, _vp, _i32, C.POINTER(OptHyper), _vp, _vp])})
 SYMBOLS.update({"sat_stem_tail_fwd_t": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
                 "sat_stem_tail_bwd_t": (C.c_int, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])})
+_u64 = C.c_uint64
+SYMBOLS.update({
+    "sat_attention_step_bwd": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp,
+                                         _i32, _i32, _i32, _i32, _i32, _vp]),
+    "sat_attention_context_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "sat_lstm_cell_fwd": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "sat_lstm_cell_bwd": (C.c_int, [_vp, _i32] + [_vp] * 17 + [_i32, _i32, _vp]),
+    "sat_deep_output_fwd": (C.c_int, [_vp] * 7 + [_f, _u64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "sat_deep_output_bwd": (C.c_int, [_vp] * 8 + [_f, _u64] + [_vp] * 8 + [_i32, _i32, _i32, _i32, _i32, _vp]),
+    "sat_init_lstm_fwd": (C.c_int, [_vp] * 5 + [_f, _u64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "sat_init_lstm_bwd": (C.c_int, [_vp] * 5 + [_f, _u64] + [_vp] * 8 + [_i32, _i32, _i32, _i32, _i32, _vp]),
+    "sat_embedding_fwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _f, _vp, _vp]),
+    "sat_embedding_bwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "sat_sigmoid_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+})
 SYMBOLS.update({"sat_image_batch_workspace_bytes": (C.c_size_t, [_vp, _i32, _i32, _i32]),
                 "sat_image_batch_transform": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _f, _vp, _vp, _vp, C.c_size_t, _vp])})
 SYMBOLS.update({"sat_profile_start": (C.c_int, []),
@@ -220,8 +235,8 @@ def lib():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(handle, name)          # AttributeError if the export is missing
             fn.restype, fn.argtypes = res, args
-        if handle.sat_abi_version() != 14:
-            raise SatHipError("libsat_hip.so ABI version %d != 14 (rebuild: make -C csrc)" % handle.sat_abi_version())
+        if handle.sat_abi_version() != 15:
+            raise SatHipError("libsat_hip.so ABI version %d != 15 (rebuild: make -C csrc)" % handle.sat_abi_version())
         _lib = handle
     return _lib
 

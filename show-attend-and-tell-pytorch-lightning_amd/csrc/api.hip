@@ -168,4 +168,84 @@ int sat_attention_step_fwd(const float* ann, const float* U, const float* hc, in
     return launch_attention_fwd((hipStream_t)stream, ann, U, hc, hc_ld, att_f, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A);
 }
 
+int sat_attention_step_bwd(const float* ann, const float* U, const float* hc, int32_t hc_ld, const float* att_f, const int32_t* lengths, int32_t step,
+                           const float* alphas, const float* dalphas, int32_t T1, const float* Z, const float* dZ, const float* dXZ, float* DZ, float* dhc,
+                           int32_t dhc_ld, float* dU, float* dwf_part, float* da_scratch, int32_t B, int32_t R, int32_t L, int32_t D, int32_t A, void* stream) {
+    if (!ann || !U || !hc || !att_f || !lengths || !alphas || !Z || !dZ || !dXZ || !DZ || !dhc || !dU || !dwf_part || !da_scratch)
+        return fail(SAT_EINVAL, "attention_step_bwd: null pointer");
+    if (hc_ld < A + D || dhc_ld < A + D) return fail(SAT_EINVAL, "attention_step_bwd: hc_ld %d / dhc_ld %d < A+D", hc_ld, dhc_ld);
+    if (B < 1 || R < 1 || L < 1 || D < 1 || A < 1 || T1 < 1 || step < 0 || step >= T1) return fail(SAT_EINVAL, "attention_step_bwd: bad shape");
+    return attention_step_bwd(ann, U, hc, hc_ld, att_f, lengths, step, alphas, dalphas, T1, Z, dZ, dXZ, DZ, dhc, dhc_ld, dU, dwf_part, da_scratch, B, R, L, D, A,
+                              (hipStream_t)stream);
+}
+int sat_attention_context_bwd(const float* alphas, const float* DZ, const int32_t* lengths, float* dann, int32_t accumulate, int32_t B, int32_t R, int32_t T1,
+                              int32_t L, int32_t D, void* stream) {
+    if (!alphas || !DZ || !lengths || !dann) return fail(SAT_EINVAL, "attention_context_bwd: null pointer");
+    if (B < 1 || R < 1 || L < 1 || D < 1 || T1 < 1) return fail(SAT_EINVAL, "attention_context_bwd: bad shape");
+    return attention_context_bwd(alphas, DZ, lengths, dann, accumulate, B, R, T1, L, D, (hipStream_t)stream);
+}
+int sat_lstm_cell_fwd(const float* x, int32_t in, const float* h_prev, const float* c_prev, const float* w_ih, const float* w_hh, const float* b_ih,
+                      const float* b_hh, float* gates, float* h_new, float* c_new, float* bias_scratch, int32_t N, int32_t n, void* stream) {
+    if (!x || !h_prev || !c_prev || !w_ih || !w_hh || !b_ih || !b_hh || !gates || !h_new || !c_new || !bias_scratch) return fail(SAT_EINVAL, "lstm_cell_fwd: null pointer");
+    if (N < 1 || n < 1 || in < 1) return fail(SAT_EINVAL, "lstm_cell_fwd: bad shape (N=%d n=%d in=%d)", N, n, in);
+    return lstm_cell_fwd(x, in, h_prev, c_prev, w_ih, w_hh, b_ih, b_hh, gates, h_new, c_new, bias_scratch, N, n, (hipStream_t)stream);
+}
+int sat_lstm_cell_bwd(const float* x, int32_t in, const float* h_prev, const float* c_prev, const float* c_new, const float* gates, const float* dh_new,
+                      const float* dc_new, const float* w_ih, const float* w_hh, float* dx, float* dh_prev, float* dc_prev, float* dw_ih, float* dw_hh,
+                      float* db_ih, float* db_hh, float* dgates, float* scratch, int32_t N, int32_t n, void* stream) {
+    if (!x || !h_prev || !c_prev || !c_new || !gates || !dh_new || !w_ih || !w_hh || !dx || !dh_prev || !dc_prev || !dw_ih || !dw_hh || !db_ih || !db_hh || !dgates || !scratch)
+        return fail(SAT_EINVAL, "lstm_cell_bwd: null pointer");
+    if (N < 1 || n < 1 || in < 1) return fail(SAT_EINVAL, "lstm_cell_bwd: bad shape (N=%d n=%d in=%d)", N, n, in);
+    return lstm_cell_bwd(x, in, h_prev, c_prev, c_new, gates, dh_new, dc_new, w_ih, w_hh, dx, dh_prev, dc_prev, dw_ih, dw_hh, db_ih, db_hh, dgates, scratch, N, n,
+                         (hipStream_t)stream);
+}
+int sat_deep_output_fwd(const float* prev_embed, const float* hidden, const float* context, const float* w_hidden, const float* w_context, const float* w_out,
+                        const float* b_out, float dropout, uint64_t seed, float* u, float* udrop, float* logits, int32_t N, int32_t m, int32_t n, int32_t D,
+                        int32_t V, void* stream) {
+    if (!hidden || !w_hidden || !w_out || !u || !logits) return fail(SAT_EINVAL, "deep_output_fwd: null pointer");
+    if (context && (!w_context || !prev_embed)) return fail(SAT_EINVAL, "deep_output_fwd: the deep form needs output.context.weight and the previous embedding");
+    if (!(dropout >= 0.f && dropout < 1.f) || (dropout > 0.f && !udrop)) return fail(SAT_EINVAL, "deep_output_fwd: dropout %g needs a udrop buffer", dropout);
+    if (N < 1 || m < 1 || n < 1 || V < 1 || (context && D < 1)) return fail(SAT_EINVAL, "deep_output_fwd: bad shape");
+    return deep_output_fwd(prev_embed, hidden, context, w_hidden, w_context, w_out, b_out, dropout, seed, u, udrop, logits, N, m, n, D, V, (hipStream_t)stream);
+}
+int sat_deep_output_bwd(const float* dlogits, const float* hidden, const float* context, const float* u, const float* udrop, const float* w_hidden,
+                        const float* w_context, const float* w_out, float dropout, uint64_t seed, float* d_prev_embed, float* d_hidden, float* d_context,
+                        float* dw_hidden, float* dw_context, float* dw_out, float* db_out, float* scratch, int32_t N, int32_t m, int32_t n, int32_t D, int32_t V,
+                        void* stream) {
+    if (!dlogits || !hidden || !u || !w_hidden || !w_out || !d_prev_embed || !d_hidden || !dw_hidden || !dw_out || !scratch) return fail(SAT_EINVAL, "deep_output_bwd: null pointer");
+    if (context && (!w_context || !d_context || !dw_context)) return fail(SAT_EINVAL, "deep_output_bwd: the deep form needs the context weight and gradient buffers");
+    if (!(dropout >= 0.f && dropout < 1.f) || (dropout > 0.f && !udrop)) return fail(SAT_EINVAL, "deep_output_bwd: dropout %g needs the forward's udrop buffer", dropout);
+    if (N < 1 || m < 1 || n < 1 || V < 1 || (context && D < 1)) return fail(SAT_EINVAL, "deep_output_bwd: bad shape");
+    return deep_output_bwd(dlogits, hidden, context, u, udrop, w_hidden, w_context, w_out, dropout, seed, d_prev_embed, d_hidden, d_context, dw_hidden, dw_context,
+                           dw_out, db_out, scratch, N, m, n, D, V, (hipStream_t)stream);
+}
+int sat_init_lstm_fwd(const float* ann, const float* w_f, const float* b_f, const float* w_i, const float* b_i, float dropout, uint64_t seed, float* mean, float* f,
+                      float* init, int32_t N, int32_t L, int32_t D, int32_t m, int32_t n2, void* stream) {
+    if (!ann || !w_f || !b_f || !w_i || !b_i || !mean || !f || !init) return fail(SAT_EINVAL, "init_lstm_fwd: null pointer");
+    if (N < 1 || L < 1 || D < 1 || m < 1 || n2 < 2 || !(dropout >= 0.f && dropout < 1.f)) return fail(SAT_EINVAL, "init_lstm_fwd: bad shape / dropout");
+    return init_lstm_fwd(ann, w_f, b_f, w_i, b_i, dropout, seed, mean, f, init, N, L, D, m, n2, (hipStream_t)stream);
+}
+int sat_init_lstm_bwd(const float* dinit, const float* mean, const float* f, const float* w_f, const float* w_i, float dropout, uint64_t seed, float* dw_f,
+                      float* db_f, float* dw_i, float* db_i, float* dann, float* df, float* dmean, float* scratch, int32_t N, int32_t L, int32_t D, int32_t m,
+                      int32_t n2, void* stream) {
+    if (!dinit || !mean || !f || !w_f || !w_i || !dw_f || !db_f || !dw_i || !db_i || !dann || !df || !dmean || !scratch) return fail(SAT_EINVAL, "init_lstm_bwd: null pointer");
+    if (N < 1 || L < 1 || D < 1 || m < 1 || n2 < 2 || !(dropout >= 0.f && dropout < 1.f)) return fail(SAT_EINVAL, "init_lstm_bwd: bad shape / dropout");
+    return init_lstm_bwd(dinit, mean, f, w_f, w_i, dropout, seed, dw_f, db_f, dw_i, db_i, dann, df, dmean, scratch, N, L, D, m, n2, (hipStream_t)stream);
+}
+
+int sat_embedding_fwd(float* table, const int32_t* tokens, float* out, int32_t rows, int32_t V, int32_t m, float max_norm, int32_t* flags_scratch, void* stream) {
+    if (!table || !tokens || !out || (max_norm > 0.f && !flags_scratch)) return fail(SAT_EINVAL, "embedding_fwd: null pointer");
+    if (rows < 1 || V < 1 || m < 1) return fail(SAT_EINVAL, "embedding_fwd: bad shape");
+    return embedding_fwd(table, tokens, out, rows, V, m, max_norm, flags_scratch, (hipStream_t)stream);
+}
+int sat_embedding_bwd(const float* dY, const int32_t* tokens, float* dtable, int32_t rows, int32_t V, int32_t m, int32_t padding_idx, int32_t* scratch, void* stream) {
+    if (!dY || !tokens || !dtable || !scratch) return fail(SAT_EINVAL, "embedding_bwd: null pointer");
+    if (rows < 1 || V < 1 || m < 1) return fail(SAT_EINVAL, "embedding_bwd: bad shape");
+    return embedding_bwd(dY, tokens, dtable, rows, V, m, padding_idx, scratch, (hipStream_t)stream);
+}
+int sat_sigmoid_bwd(const float* dy, const float* y, float* dpre, int64_t n, void* stream) {
+    if (!dy || !y || !dpre || n < 1) return fail(SAT_EINVAL, "sigmoid_bwd: null pointer / empty");
+    return sigmoid_bwd(dy, y, dpre, n, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -860,6 +860,183 @@ int topk(const float* x, float* work, long n, int k, float* values, int* indices
     return launch_ok("topk");
 }
 
+// ------------------------------------------------------------------ sub-module step entry points (SURVEY 8b minimum set)
+// The reference's sub-modules called on their own (model.py:76-81, 94-109, 125-131, 175-180 / 326, 544): the same kernels and GEMMs
+// as the train loop above, for N independent rows, exact fp32 MFMA.  Scratch comes from the caller (sizes in include/sat_hip.h).
+static int fill_f(hipStream_t st, float* p, long n, float v) {
+    if (n <= 0) return SAT_OK;
+    hipLaunchKernelGGL(fill_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, p, n, v);
+    return launch_ok("fill");
+}
+
+int attention_step_bwd(const float* ann, const float* U, const float* hc, int hc_ld, const float* wf, const int* lengths, int step, const float* alphas,
+                       const float* dalphas, int T1, const float* Z, const float* dZ, const float* dXZ, float* DZ, float* dhc, int dhc_ld, float* dU,
+                       float* dwf_part, float* da, int B, int R, int L, int D, int A, hipStream_t st) {
+    t_bf16_mfma = 0;
+    return attention_bwd_split(R < ATT_RMAX ? R : ATT_RMAX, st, ann, U, hc, hc_ld, wf, lengths, step, alphas, dalphas, T1, Z, dZ, dXZ, DZ, dhc, dhc_ld, dU, dwf_part,
+                               da, B, R, L, D, A, nullptr);
+}
+
+int attention_context_bwd(const float* alphas, const float* DZ, const int* lengths, float* dann, int accumulate, int B, int R, int T1, int L, int D, hipStream_t st) {
+    const int lq4 = (L + 3) / 4;
+    const int NQ = (lq4 <= 13) ? 13 : 16;
+    const int Lq = (lq4 + NQ - 1) / NQ * NQ;
+    const size_t lds = (size_t)R * T1 * Lq * 16;
+    SAT_REQUIRE(lds <= 160 * 1024, "attention_context_bwd: R*T1*L = %d floats of alphas do not fit the LDS", R * T1 * L);
+    if (NQ == 13) {
+        SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dann_from_context_kernel<13>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(dann_from_context_kernel<13>, dim3(B, cdiv(D, 256)), dim3(256), lds, st, alphas, DZ, lengths, dann, accumulate, R, B * R, T1, L, D);
+    } else {
+        SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dann_from_context_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(dann_from_context_kernel<16>, dim3(B, cdiv(D, 256)), dim3(256), lds, st, alphas, DZ, lengths, dann, accumulate, R, B * R, T1, L, D);
+    }
+    return launch_ok("dann_from_context");
+}
+
+// nn.LSTM, one layer, one time step (model.py:175-180; calls at 326, 544): gates = x W_ih^T + b_ih + h W_hh^T + b_hh, i,f,g,o
+int lstm_cell_fwd(const float* x, int in, const float* h_prev, const float* c_prev, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                  float* gates, float* h_new, float* c_new, float* bias_scratch, int N, int n, hipStream_t st) {
+    t_bf16_mfma = 0;
+    hipLaunchKernelGGL(add_kernel, dim3(cdiv(4 * n, 256)), dim3(256), 0, st, bias_scratch, b_ih, b_hh, (long)4 * n);
+    SAT_TRY(launch_ok("bias add"));
+    SAT_TRY(gemm(st, A_ROW, B_ROW, x, in, w_ih, in, gates, 4 * n, N, 4 * n, in, 0, EPI_BIAS, bias_scratch));
+    SAT_TRY(gemm(st, A_ROW, B_ROW, h_prev, n, w_hh, n, gates, 4 * n, N, 4 * n, n, 1));
+    hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(cdiv((long)N * n, 256)), dim3(256), 0, st, gates, 4 * n, (const float*)nullptr, c_prev, h_prev, c_new, h_new,
+                       (const int*)nullptr, 0, N, n, (__bf16*)nullptr);
+    return launch_ok("lstm_cell_fwd");
+}
+
+int lstm_cell_bwd(const float* x, int in, const float* h_prev, const float* c_prev, const float* c_new, const float* gates, const float* dh_new, const float* dc_new,
+                  const float* w_ih, const float* w_hh, float* dx, float* dh_prev, float* dc_prev, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh,
+                  float* dgates, float* scratch, int N, int n, hipStream_t st) {
+    t_bf16_mfma = 0;
+    // the cell kernel adds its `carry` inputs and leaves dc_prev in the cell carry: start them from the incoming cell gradient / zero
+    if (dc_new) SAT_CHECK_HIP(hipMemcpyAsync(dc_prev, dc_new, (size_t)N * n * 4, hipMemcpyDeviceToDevice, st));
+    else SAT_TRY(fill_f(st, dc_prev, (long)N * n, 0.f));
+    SAT_TRY(fill_f(st, dh_prev, (long)N * n, 0.f));
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(cdiv((long)N * n, 256)), dim3(256), 0, st, gates, 4 * n, c_prev, c_new, dh_new, dh_prev, dc_prev, dgates, 4 * n,
+                       (const int*)nullptr, 0, N, n, (__bf16*)nullptr);
+    SAT_TRY(launch_ok("lstm_cell_bwd"));
+    SAT_TRY(gemm(st, A_ROW, B_KMAJOR, dgates, 4 * n, w_ih, in, dx, in, N, in, 4 * n));
+    SAT_TRY(gemm(st, A_ROW, B_KMAJOR, dgates, 4 * n, w_hh, n, dh_prev, n, N, n, 4 * n));
+    SAT_TRY(gemm(st, A_KMAJOR, B_KMAJOR, dgates, 4 * n, x, in, dw_ih, in, 4 * n, in, N));
+    SAT_TRY(gemm(st, A_KMAJOR, B_KMAJOR, dgates, 4 * n, h_prev, n, dw_hh, n, 4 * n, n, N));
+    Ws w; w.colpart = scratch;
+    SAT_TRY(colsum(st, w, dgates, 4 * n, N, 4 * n, db_ih));
+    SAT_CHECK_HIP(hipMemcpyAsync(db_hh, db_ih, (size_t)4 * n * 4, hipMemcpyDeviceToDevice, st));
+    return SAT_OK;
+}
+
+// DeepOutput.forward (model.py:125-131)
+int deep_output_fwd(const float* prev_embed, const float* hidden, const float* context, const float* w_hidden, const float* w_context, const float* w_out,
+                    const float* b_out, float dropout, unsigned long long seed, float* u, float* udrop, float* logits, int N, int m, int n, int D, int V, hipStream_t st) {
+    t_bf16_mfma = 0;
+    if (context) {
+        SAT_TRY(gemm(st, A_ROW, B_ROW, hidden, n, w_hidden, n, u, m, N, m, n));
+        SAT_TRY(gemm(st, A_ROW, B_ROW, context, D, w_context, D, u, m, N, m, D, 1, EPI_ADD_TANH, nullptr, nullptr, nullptr, prev_embed, m));
+    } else {
+        SAT_TRY(gemm(st, A_ROW, B_ROW, hidden, n, w_hidden, n, u, m, N, m, n));
+    }
+    const float* uin = u;
+    if (dropout > 0.f) {
+        hipLaunchKernelGGL(dropout_rows_kernel, dim3(cdiv((long)N * m, 256)), dim3(256), 0, st, u, udrop, (long)N * m, m, dropout, seed, 2u, 0L);
+        SAT_TRY(launch_ok("output dropout"));
+        uin = udrop;
+    }
+    return gemm(st, A_ROW, B_ROW, uin, m, w_out, m, logits, V, N, V, m, 0, b_out ? EPI_BIAS : EPI_NONE, b_out);
+}
+
+int deep_output_bwd(const float* dlogits, const float* hidden, const float* context, const float* u, const float* udrop, const float* w_hidden, const float* w_context,
+                    const float* w_out, float dropout, unsigned long long seed, float* d_prev_embed, float* d_hidden, float* d_context, float* dw_hidden,
+                    float* dw_context, float* dw_out, float* db_out, float* scratch, int N, int m, int n, int D, int V, hipStream_t st) {
+    t_bf16_mfma = 0;
+    const bool deep = context != nullptr;
+    float* du = d_prev_embed;                 // gradient of the pre-tanh sum = gradient of the embedding input (deep); scratch of the same shape (shallow)
+    if (dropout > 0.f) {
+        SAT_TRY(gemm(st, A_ROW, B_KMAJOR, dlogits, V, w_out, m, du, m, N, m, V));
+        hipLaunchKernelGGL(dropout_rows_kernel, dim3(cdiv((long)N * m, 256)), dim3(256), 0, st, du, du, (long)N * m, m, dropout, seed, 2u, 0L);
+        SAT_TRY(launch_ok("output dropout bwd"));
+        if (deep) {
+            hipLaunchKernelGGL(mul_dtanh_kernel, dim3(cdiv((long)N * m, 256)), dim3(256), 0, st, du, u, (long)N * m);
+            SAT_TRY(launch_ok("tanh bwd"));
+        }
+    } else {
+        SAT_TRY(gemm(st, A_ROW, B_KMAJOR, dlogits, V, w_out, m, du, m, N, m, V, 0, deep ? EPI_MUL_DTANH : EPI_NONE, nullptr, nullptr, nullptr, u, m));
+    }
+    SAT_TRY(gemm(st, A_KMAJOR, B_KMAJOR, dlogits, V, dropout > 0.f ? udrop : u, m, dw_out, m, V, m, N));
+    Ws w; w.colpart = scratch;
+    if (db_out) SAT_TRY(colsum(st, w, dlogits, V, N, V, db_out));
+    SAT_TRY(gemm(st, A_ROW, B_KMAJOR, du, m, w_hidden, n, d_hidden, n, N, n, m));
+    SAT_TRY(gemm(st, A_KMAJOR, B_KMAJOR, du, m, hidden, n, dw_hidden, n, m, n, N));
+    if (deep) {
+        SAT_TRY(gemm(st, A_ROW, B_KMAJOR, du, m, w_context, D, d_context, D, N, D, m));
+        SAT_TRY(gemm(st, A_KMAJOR, B_KMAJOR, du, m, context, D, dw_context, D, m, D, N));
+    }
+    return SAT_OK;
+}
+
+// InitLSTM.forward (model.py:76-81) on N rows; `init` (N, n2) row-major IS the (2*layers, N, n) buffer of the raw reshape (F3)
+int init_lstm_fwd(const float* ann, const float* w_f, const float* b_f, const float* w_i, const float* b_i, float dropout, unsigned long long seed, float* mean,
+                  float* f, float* init, int N, int L, int D, int m, int n2, hipStream_t st) {
+    t_bf16_mfma = 0;
+    hipLaunchKernelGGL(ann_mean_kernel, dim3(N), dim3(256), 0, st, ann, mean, L, D);
+    SAT_TRY(launch_ok("ann_mean"));
+    if (dropout > 0.f) {
+        hipLaunchKernelGGL(init_mean_rows_kernel, dim3(cdiv((long)N * D, 256)), dim3(256), 0, st, mean, mean, N, 1, D, dropout, seed);
+        SAT_TRY(launch_ok("init_mean_rows"));
+    }
+    SAT_TRY(gemm(st, A_ROW, B_ROW, mean, D, w_f, D, f, m, N, m, D, 0, EPI_BIAS, b_f));
+    return gemm(st, A_ROW, B_ROW, f, m, w_i, m, init, n2, N, n2, m, 0, EPI_BIAS, b_i);
+}
+
+int init_lstm_bwd(const float* dinit, const float* mean, const float* f, const float* w_f, const float* w_i, float dropout, unsigned long long seed, float* dw_f,
+                  float* db_f, float* dw_i, float* db_i, float* dann, float* df, float* dmean, float* scratch, int N, int L, int D, int m, int n2, hipStream_t st) {
+    t_bf16_mfma = 0;
+    Ws w; w.colpart = scratch;
+    SAT_TRY(gemm(st, A_KMAJOR, B_KMAJOR, dinit, n2, f, m, dw_i, m, n2, m, N));
+    SAT_TRY(colsum(st, w, dinit, n2, N, n2, db_i));
+    SAT_TRY(gemm(st, A_ROW, B_KMAJOR, dinit, n2, w_i, m, df, m, N, m, n2));
+    SAT_TRY(gemm(st, A_KMAJOR, B_KMAJOR, df, m, mean, D, dw_f, D, m, D, N));
+    SAT_TRY(colsum(st, w, df, m, N, m, db_f));
+    SAT_TRY(gemm(st, A_ROW, B_KMAJOR, df, m, w_f, D, dmean, D, N, D, m));
+    if (dropout > 0.f) {
+        hipLaunchKernelGGL(init_mean_rows_bwd_kernel, dim3(cdiv((long)N * D, 256)), dim3(256), 0, st, dmean, dmean, N, 1, D, dropout, seed);
+        SAT_TRY(launch_ok("init_mean_rows_bwd"));
+    }
+    const long tot = (long)N * L * D;
+    SAT_TRY(fill_f(st, dann, tot, 0.f));
+    hipLaunchKernelGGL(dann_add_mean_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, st, dann, dmean, L, D, tot);
+    return launch_ok("dann_add_mean");
+}
+
+// nn.Embedding forward (model.py:158-164, use at 298, 526): optional in-place max-norm renormalisation of the rows used, then the gather
+int embedding_fwd(float* table, const int* tokens, float* out, int rows, int V, int m, float max_norm, int* flags, hipStream_t st) {
+    if (max_norm > 0.f) {
+        hipLaunchKernelGGL(fill_int_kernel, dim3(cdiv(V, 256)), dim3(256), 0, st, flags, (long)V, 0);
+        hipLaunchKernelGGL(embedding_mark_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, st, tokens, rows, flags, V);
+        SAT_TRY(launch_ok("embedding_mark"));
+        hipLaunchKernelGGL(embedding_renorm_kernel, dim3(V), dim3(64), 0, st, table, flags, m, max_norm);
+        SAT_TRY(launch_ok("embedding_renorm"));
+    }
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(rows), dim3(64), 0, st, table, tokens, out, rows, m, 0.f, 0ull, 0L);
+    return launch_ok("embedding gather");
+}
+// its gradient: rows of dY added into the table rows of their tokens in increasing row order (no floating-point atomics); padding row zero
+int embedding_bwd(const float* dY, const int* tokens, float* dtable, int rows, int V, int m, int padding_idx, int* scratch, hipStream_t st) {
+    int* count = scratch; int* offset = count + V; int* cursor = offset + V + 1; int* list = cursor + V;
+    hipLaunchKernelGGL(fill_int_kernel, dim3(cdiv(V, 256)), dim3(256), 0, st, count, (long)V, 0);
+    hipLaunchKernelGGL(embedding_count_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, st, tokens, rows, V, padding_idx, count);
+    hipLaunchKernelGGL(embedding_scan_kernel, dim3(1), dim3(1024), 0, st, count, V, offset, cursor);
+    hipLaunchKernelGGL(embedding_place_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, st, tokens, rows, V, padding_idx, offset, cursor, list);
+    hipLaunchKernelGGL(embedding_sum_kernel, dim3(V), dim3(256), 0, st, dY, tokens, offset, list, dtable, rows, m, padding_idx);
+    return launch_ok("embedding gradient");
+}
+// backward of y = sigmoid(pre): dpre = dy * y * (1 - y)   (the beta gate, model.py:187-192)
+int sigmoid_bwd(const float* dy, const float* y, float* dpre, long n, hipStream_t st) {
+    hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, dy, y, dpre, n);
+    return launch_ok("sigmoid_bwd");
+}
+
 // ------------------------------------------------------------------ losses
 int ce_fwd(const float* logits, const int* targets, int P, int V, float smoothing, float* lse_rows, float* loss_rows, int* correct_rows, float* out, hipStream_t st) {
     SAT_REQUIRE(P > 0 && V > 0, "ce_fwd: empty input (P=%d V=%d)", P, V);

@@ -423,7 +423,7 @@ __global__ void lstm_cell_fwd_kernel(float* __restrict__ gates, int g_ld, const 
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)N * n) return;
     int i = (int)(idx / n), j = (int)(idx - (long)i * n);
-    if (lengths[i] <= step) {       // finished caption: state is carried unchanged (model.py:544 updates live rows only)
+    if (lengths && lengths[i] <= step) {       // finished caption: state is carried unchanged (model.py:544 updates live rows only); lengths NULL: every row live
         const float hp = h_prev[idx];
         c_new[idx] = c_prev[idx]; h_new[idx] = hp;
         if (hb_new) hb_new[idx] = (__bf16)hp;
@@ -458,7 +458,7 @@ __global__ void lstm_cell_bwd_kernel(const float* __restrict__ gates, int g_ld, 
     int i = (int)(idx / n), j = (int)(idx - (long)i * n);
     float* dg = dgates + (long)i * dg_ld;
     __bf16* db = dgb ? dgb + (long)i * dg_ld : nullptr;            // bf16 copy with the same row stride (operand of this step's GEMMs)
-    if (lengths[i] <= step) {
+    if (lengths && lengths[i] <= step) {
         dg[j] = 0.f; dg[n + j] = 0.f; dg[2 * n + j] = 0.f; dg[3 * n + j] = 0.f;
         if (db) { db[j] = (__bf16)0.f; db[n + j] = (__bf16)0.f; db[2 * n + j] = (__bf16)0.f; db[3 * n + j] = (__bf16)0.f; }
         return;
@@ -1032,6 +1032,15 @@ __global__ __launch_bounds__(64) void embedding_renorm_kernel(float* __restrict_
 }
 
 // out[i] = a[i] + b[i]
+__global__ void sigmoid_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dpre, long n) {
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) { const float v = y[e]; dpre[e] = dy[e] * v * (1.f - v); }
+}
+// g[e] *= 1 - u[e]^2 : backward of tanh from its output
+__global__ void mul_dtanh_kernel(float* __restrict__ g, const float* __restrict__ u, long n) {
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) { const float t = u[e]; g[e] *= 1.f - t * t; }
+}
 __global__ void add_kernel(float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ b, long n) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = a[i] + b[i];

@@ -1,9 +1,10 @@
 """Drop-in mirror of the reference's ``model.py`` surface for the train-step hot path:
 ``get_encoder``, ``InitLSTM``, ``SoftAttention``, ``DeepOutput`` and ``SAT`` with the same
 constructor kwargs, attribute names and state-dict keys (reference model.py:16-199),
-so ``train.py``-style callers and checkpoints keep working.  The sub-modules only *hold*
-parameters (created in the reference's order, so a given seed yields the same initial
-weights); all arithmetic goes through ``libsat_hip.so``.
+so ``train.py``-style callers and checkpoints keep working.  The sub-modules (modules.py) hold the
+parameters (created in the reference's order, so a given seed yields the same initial weights) and
+are callable with the reference's signatures; ``train_batch`` runs the whole decode loop fused in
+the library instead of calling them step by step.  All arithmetic goes through ``libsat_hip.so``.
 """
 import math
 from types import SimpleNamespace
@@ -17,6 +18,7 @@ from torch.optim.lr_scheduler import MultiStepLR, ReduceLROnPlateau, Exponential
 
 from . import _lib as L
 from . import decoder as Dk
+from .modules import DeepOutput, Embedding, Gate, InitLSTM, LSTM, SoftAttention  # noqa: F401  (the reference's module names, model.py:66-131)
 from .encoder import get_encoder  # noqa: F401  (module-level name, as in the reference)
 
 try:                                     # Lightning is optional plumbing (absent in the build image)
@@ -35,40 +37,6 @@ class _HParams(dict):
             raise AttributeError(k) from None
 
     __setattr__ = dict.__setitem__
-
-
-class InitLSTM(nn.Module):
-    """Parameter holder for model.py:66-81 (factorize: D->m, init: m->2*n*layers)."""
-
-    def __init__(self, args, bias=True):
-        super().__init__()
-        self.decoder_dim, self.decoder_layers = args.decoder_dim, args.decoder_layers
-        self.factorize = nn.Linear(args.encoder_dim, args.embed_dim, bias=bias)
-        self.init = nn.Linear(args.embed_dim, 2 * args.decoder_dim * args.decoder_layers, bias=bias)
-        self.dropout = nn.Dropout(p=args.dropout)
-
-
-class SoftAttention(nn.Module):
-    """Parameter holder for model.py:84-109 (three bias-free Linears)."""
-
-    def __init__(self, args):
-        super().__init__()
-        self.encoder_att = nn.Linear(args.encoder_dim, args.attention_dim, bias=False)
-        self.decoder_att = nn.Linear(args.decoder_dim, args.attention_dim, bias=False)
-        self.f_att = nn.Linear(args.attention_dim, 1, bias=False)
-
-
-class DeepOutput(nn.Module):
-    """Parameter holder for model.py:112-131."""
-
-    def __init__(self, args):
-        super().__init__()
-        self.deep = args.deep_output
-        self.dropout = nn.Dropout(p=args.dropout)
-        self.hidden = nn.Linear(args.decoder_dim, args.embed_dim, bias=False)
-        if self.deep:
-            self.context = nn.Linear(args.encoder_dim, args.embed_dim, bias=False)
-        self.output = nn.Linear(args.embed_dim, args.vocab_size, bias=(not args.weight_tying))
 
 
 class LabelSmoothing(nn.Module):
@@ -105,12 +73,12 @@ class SATDecoder(nn.Module):
         self.pad_idx = int(hp.vocab_stoi["<PAD>"])
         if encoder_factory is not None:                     # registered here to keep the reference's module order
             self.encoder = encoder_factory(hp)
-        self.embedding = nn.Embedding(hp.vocab_size, hp.embed_dim, max_norm=getattr(hp, "embed_norm", None), padding_idx=self.pad_idx)
+        self.embedding = Embedding(hp.vocab_size, hp.embed_dim, max_norm=getattr(hp, "embed_norm", None), padding_idx=self.pad_idx)
         self.embedding_dropout = nn.Dropout(p=hp.embedding_dropout)
         self.init_lstm = InitLSTM(hp, bias=True)
-        self.lstm = nn.LSTM(input_size=hp.embed_dim + hp.encoder_dim, hidden_size=hp.decoder_dim, num_layers=hp.decoder_layers, bias=True)
+        self.lstm = LSTM(input_size=hp.embed_dim + hp.encoder_dim, hidden_size=hp.decoder_dim, num_layers=hp.decoder_layers, bias=True)
         self.attention = SoftAttention(hp)
-        self.beta = nn.Sequential(nn.Linear(hp.decoder_dim, hp.encoder_dim, bias=True), nn.Sigmoid())
+        self.beta = Gate(nn.Linear(hp.decoder_dim, hp.encoder_dim, bias=True), nn.Sigmoid())
         fan_in = self.beta[0].weight.shape[1]
         self.beta[0].bias.data.fill_(1 / fan_in)
         self.output = DeepOutput(hp)

@@ -50,8 +50,14 @@ class FusedOptimizer(torch.optim.Optimizer):
             arr = np.array(rows, dtype=[("tensor", np.int32), ("reserved", np.int32), ("start", np.int64)])
             self._chunks = torch.from_numpy(arr.view(np.uint8).copy()).to(dev)
             self._n_chunks = len(rows)
-            self._host = torch.empty(len(entries) * C.sizeof(L.OptTensor), dtype=torch.uint8).pin_memory()
-            self._dev = torch.empty_like(self._host, device=dev)
+            # The pointer table is rebuilt on the host every step and uploaded asynchronously.  The host may run a step or more
+            # ahead of the GPU, so a pinned table must not be rewritten before its previous upload has executed: a small ring
+            # of pinned tables, each with the event of its last upload (and no upload at all while the table is unchanged).
+            nbytes = len(entries) * C.sizeof(L.OptTensor)
+            self._ring = [[torch.empty(nbytes, dtype=torch.uint8).pin_memory(), None] for _ in range(3)]
+            self._ring_pos = 0
+            self._uploaded = None
+            self._dev = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             self._scratch = torch.empty(self._n_chunks, dtype=torch.float64, device=dev)
             self._coef = torch.ones(2, dtype=torch.float32, device=dev)
             self._sig = sig
@@ -79,7 +85,12 @@ class FusedOptimizer(torch.optim.Optimizer):
             if tuple(g["betas"]) != (beta1, beta2) or g["eps"] != g0["eps"] or g["momentum"] != g0["momentum"] or g["nesterov"] != g0["nesterov"]:
                 raise ValueError("FusedOptimizer: betas / eps / momentum / nesterov must be the same in every group (lr and weight_decay may differ)")
         chunks = self._tables(entries, dev)
-        table = (L.OptTensor * len(entries)).from_buffer(self._host.numpy())
+        self._ring_pos = (self._ring_pos + 1) % len(self._ring)
+        slot = self._ring[self._ring_pos]
+        if slot[1] is not None:
+            slot[1].synchronize()                      # the upload that last read this pinned table has executed
+        host = slot[0]
+        table = (L.OptTensor * len(entries)).from_buffer(host.numpy())
         steps = set()
         for i, (p, group) in enumerate(entries):
             dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))      # KRSC filters
@@ -108,7 +119,13 @@ class FusedOptimizer(torch.optim.Optimizer):
         if len(steps) != 1:
             raise ValueError("FusedOptimizer: parameters are at different step counts %s" % sorted(steps))
         step = steps.pop()
-        self._dev.copy_(self._host, non_blocking=True)
+        raw = host.numpy().tobytes()
+        if raw != self._uploaded:                      # pointers / lr / weight decay changed since the table on the device was written
+            self._dev.copy_(host, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            slot[1] = ev
+            self._uploaded = raw
         coef = None
         if self.grad_clip == "norm":
             L.check(lib.sat_grad_clip_coef(L.ptr(self._dev), L.ptr(chunks), self._n_chunks, self.clip_value, L.ptr(self._scratch),

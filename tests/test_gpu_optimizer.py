@@ -71,3 +71,41 @@ def test_fused_optimizer_is_bitwise_reproducible_and_rejects_cpu():
     cpu[0].grad = torch.ones(4)
     with pytest.raises(_lib.SatHipError):
         FusedOptimizer(cpu, kind="adam").step()
+
+
+def test_pointer_table_survives_a_host_that_runs_ahead():
+    """The pointer / learning-rate table is rebuilt on the host every step and uploaded asynchronously.  With no host
+    synchronisation between steps the host runs steps ahead of the GPU: alternate two sets of gradient buffers and the learning
+    rate every step, keep the GPU busy so that the uploads lag, and compare with torch.optim on the CPU."""
+    import sat_amd  # noqa: F401
+    from sat_amd.optim import FusedOptimizer
+    g = torch.Generator().manual_seed(11)
+    shapes = [(4099,), (300, 70), (65537,)]
+    ref = [torch.randn(s, generator=g).requires_grad_() for s in shapes]
+    dev = [p.detach().clone().cuda().requires_grad_() for p in ref]
+    topt = torch.optim.Adam(ref, lr=1e-2)
+    fopt = FusedOptimizer(dev, kind="adam", lr=1e-2)
+    steps = 12
+    grads = [[torch.randn(s, generator=g) for s in shapes] for _ in range(steps)]
+    sets = [[torch.empty(s, device="cuda") for s in shapes] for _ in range(2)]
+    staged = [[gr.cuda() for gr in gs] for gs in grads]
+    ballast = torch.randn(4096, 4096, device="cuda")
+    torch.cuda.synchronize()
+    for step in range(steps):
+        lr = 1e-2 if step % 2 == 0 else 3e-3
+        for pg in topt.param_groups:
+            pg["lr"] = lr
+        for pg in fopt.param_groups:
+            pg["lr"] = lr
+        for _ in range(6):                       # ~ms of queued GPU work: the optimizer's upload executes long after the host moved on
+            ballast = (ballast @ ballast).clamp_(-1, 1)
+        bufs = sets[step % 2]
+        for q, b, src in zip(dev, bufs, staged[step]):
+            b.copy_(src); q.grad = b
+        for p, gr in zip(ref, grads[step]):
+            p.grad = gr.clone()
+        topt.step(); fopt.step()                 # no synchronisation anywhere in the loop
+    torch.cuda.synchronize()
+    for i, (p, q) in enumerate(zip(ref, dev)):
+        err = float((q.detach().cpu() - p.detach()).abs().max())
+        assert err <= 5e-6 * max(1.0, float(p.detach().abs().max())), (i, err)
