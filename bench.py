@@ -286,11 +286,21 @@ def main():
     # ---- the timed region; the dominant family alone stays instrumented inside it (an event pair per launch of that family)
     if os.environ.get("SAT_BENCH_NO_INREGION") == "1":       # dev: A/B the cost of the in-region event pairs
         dom_name = None
+    # an event pair costs the command processor ~2 us; the contraction core has ~280 launches per step, so it is instrumented on
+    # every INSTR_EVERY-th timed step only (all of its launches of that step): the other families have <= 52 launches per step
+    instr_every = 4 if dom_name == "gemm_*" else 1
+    instr_steps = 0
     if dom_name:
         _lib.profile_start(only=dom_name)
+        _lib.profile_pause(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        on = bool(dom_name) and i % instr_every == 0
+        if on:
+            _lib.profile_pause(False); instr_steps += 1
         out = step()
+        if on:
+            _lib.profile_pause(True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -313,7 +323,7 @@ def main():
                        flops=sum(e["flops"] for e in timed), bytes=sum(e["bytes"] for e in timed))
         elif fams:
             dom = fams[0]
-        dom_steps = args.steps if timed else prof_steps
+        dom_steps = instr_steps if timed else prof_steps
         roof = None
         peak = PEAK["bf16"] if args.precision == "bf16" else PEAK["f32"]
         step_tflop = algorithmic_work(args.config, R)["f_cap"] * B * R / 1e12
@@ -346,7 +356,7 @@ def main():
                     "avg_launch_us": round(dom["total_ms"] * 1e3 / dom["launches"], 2), "launches_per_step": dom["launches"] // dom_steps,
                     "ms_per_step": round(dom["total_ms"] / dom_steps, 3),
                     "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"], "flops_per_launch": dom["flops"] / dom["launches"],
-                    "measured_on": ("HIP events on the launch stream around every launch of this family inside the timed region (%d steps); "
+                    "measured_on": ("HIP events on the launch stream around every launch of this family inside the timed region (on %d of its steps); "
                                     "`families` / `top`: every instrumented family over %d untimed steps before it; `gemm_*` = every template "
                                     "of the contraction core (tile shape x operand form) summed" % (dom_steps, prof_steps)),
                     "families": [row(e) for e in fams[:8]],

@@ -47,8 +47,10 @@ typedef struct sat_profile_entry {
     double bytes;         /* algorithmic bytes of those launches       */
 } sat_profile_entry;
 int sat_profile_start(void);
-/* the same, recording only the scopes of one family (negligible overhead: used inside bench.py's timed region) */
+/* the same, recording only the scopes of one family, or of every family with a common prefix when `name` ends in '*' */
 int sat_profile_start_only(const char* name);
+/* recording off (1) / on again (0) between start and stop, keeping what was recorded: bench.py instruments every n-th timed step */
+int sat_profile_pause(int32_t paused);
 int sat_profile_stop(sat_profile_entry* out, int32_t max_entries, int32_t* n_out);
 
 /* ------------------------------------------------------------------ GEMM family

@@ -201,6 +201,7 @@ SYMBOLS.update({"sat_image_batch_workspace_bytes": (C.c_size_t, [_vp, _i32, _i32
                 "sat_image_batch_transform": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _f, _vp, _vp, _vp, C.c_size_t, _vp])})
 SYMBOLS.update({"sat_profile_start": (C.c_int, []),
                 "sat_profile_start_only": (C.c_int, [C.c_char_p]),
+                "sat_profile_pause": (C.c_int, [_i32]),
                 "sat_profile_stop": (C.c_int, [C.POINTER(ProfileEntry), _i32, C.POINTER(C.c_int32)])})
 
 
@@ -210,6 +211,10 @@ def profile_start(only=None):
         check(lib().sat_profile_start_only(only.encode()), "sat_profile_start_only")
     else:
         check(lib().sat_profile_start(), "sat_profile_start")
+
+
+def profile_pause(paused=True):
+    check(lib().sat_profile_pause(1 if paused else 0), "sat_profile_pause")
 
 
 def profile_stop(max_entries=256):

@@ -57,6 +57,11 @@ int sat_profile_start(void) {
     g_on = true;
     return 0;
 }
+int sat_profile_pause(int32_t paused) {        // keep the records and the family filter, stop / resume recording
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_on = !paused;
+    return 0;
+}
 int sat_profile_stop(sat_profile_entry* out, int32_t max_entries, int32_t* n_out) {
     std::lock_guard<std::mutex> lk(g_mu);
     g_on = false;

@@ -243,32 +243,35 @@ class Gate(nn.Sequential):
 
 
 # ----------------------------------------------------------------------------- embedding (model.py:158-164)
+def _embedding_gather(tok, table, max_norm):
+    """rows of `table` for the token ids (any shape); max_norm > 0 first renormalises the used rows of `table` in place"""
+    L.require_gpu(tok, table)
+    V, m = table.shape
+    flat = tok.reshape(-1).to(torch.int32).contiguous()
+    out = _empty(flat.numel(), m, like=table)
+    flags = torch.empty(V, dtype=torch.int32, device=table.device) if max_norm else None
+    L.check(L.lib().sat_embedding_fwd(L.ptr(table), L.ptr(flat), L.ptr(out), flat.numel(), V, m, float(max_norm or 0.0), L.ptr(flags), L.stream_ptr()),
+            "sat_embedding_fwd")
+    return out, flat
+
+
 class _EmbeddingFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, tok, table, max_norm, padding_idx):
-        L.require_gpu(tok, table)
-        V, m = table.shape
-        flat = tok.reshape(-1).to(torch.int32).contiguous()
-        rows = flat.numel()
-        out = _empty(rows, m, like=table)
-        flags = torch.empty(V, dtype=torch.int32, device=table.device) if max_norm else None
-        L.check(L.lib().sat_embedding_fwd(L.ptr(table), L.ptr(flat), L.ptr(out), rows, V, m, float(max_norm or 0.0), L.ptr(flags), L.stream_ptr()),
-                "sat_embedding_fwd")
-        if max_norm:
-            ctx.mark_dirty(table)                   # renormalised in place, like torch's embedding_renorm_
+    def forward(ctx, tok, table, padding_idx):
+        out, flat = _embedding_gather(tok, table, None)
         ctx.save_for_backward(flat)
-        ctx.cfg = (V, m, int(-1 if padding_idx is None else padding_idx), tuple(tok.shape))
-        return out.reshape(*tok.shape, m)
+        ctx.cfg = (table.shape[0], table.shape[1], int(-1 if padding_idx is None else padding_idx))
+        return out.reshape(*tok.shape, table.shape[1])
 
     @staticmethod
     def backward(ctx, dy):
         (flat,) = ctx.saved_tensors
-        V, m, pad, shape = ctx.cfg
+        V, m, pad = ctx.cfg
         dy = _f32(dy).reshape(-1, m)
         dtable = _empty(V, m, like=dy)
         scratch = torch.empty(3 * V + 1 + flat.numel(), dtype=torch.int32, device=dy.device)
         L.check(L.lib().sat_embedding_bwd(L.ptr(dy), L.ptr(flat), L.ptr(dtable), flat.numel(), V, m, pad, L.ptr(scratch), L.stream_ptr()), "sat_embedding_bwd")
-        return None, dtable, None, None
+        return None, dtable, None
 
 
 class Embedding(nn.Embedding):
@@ -276,10 +279,10 @@ class Embedding(nn.Embedding):
     renormalisation) on the library's kernels; the gradient is accumulated in a fixed order."""
 
     def forward(self, tokens):
-        if self.max_norm:
-            with torch.no_grad():                   # torch renormalises outside autograd as well (embedding_renorm_)
-                _EmbeddingFn.apply(tokens, self.weight.data, self.max_norm, self.padding_idx)
-        return _EmbeddingFn.apply(tokens, self.weight, None, self.padding_idx)
+        if self.max_norm:                           # torch renormalises the used rows in place, outside autograd (embedding_renorm_)
+            with torch.no_grad():
+                _embedding_gather(tokens, self.weight.data, self.max_norm)
+        return _EmbeddingFn.apply(tokens, self.weight, self.padding_idx)
 
 
 # ----------------------------------------------------------------------------- nn.LSTM, one step at a time (model.py:175-180)
