@@ -81,9 +81,14 @@ def test_golden_train_batch_and_grads(M, golden_dir, tag):
         O.embed({"embedding.weight": w}, fed, hp.embed_norm)                            # the oracle renormalises w in place
         close(dec.embedding.weight, w, 1e-6, "renormalised embedding table")
         assert float(dec.embedding.weight.detach().cpu().norm(dim=1)[fed.unique()].max()) <= hp.embed_norm * (1 + 1e-5)
-    # doubly-stochastic term: report the distance to the reference bit pattern
+    # doubly-stochastic term against the reference's BIT PATTERN (north_star): the reference sums on the CPU in ATen's order and
+    # through libm's tanh / exp, the kernels in a fixed device order through __expf, so the float differs in its last bits;
+    # bound: 64 ulp (= 4e-6 relative, 25x inside the 1e-4 stated for the other outputs).  Bit identity run-to-run on the
+    # device is asserted in test_reductions_are_bit_reproducible.
     bits = np.float32(res["ds"].item()).view(np.uint32)
-    print("ds ulps vs reference:", abs(int(bits) - int(g["ds_bits"])))
+    ulps = abs(int(bits) - int(g["ds_bits"]))
+    print("ds ulps vs reference:", ulps)
+    assert ulps <= 64, "doubly-stochastic loss %d ulp from the reference's bit pattern" % ulps
 
 
 def test_c1_shapes_against_oracle_and_golden(M, golden_dir):

@@ -220,22 +220,35 @@ def test_residual_block_fwd_bwd(E, kind, cin, planes, stride):
         close(grads[p], refp[k].grad, 2e-4, k)
 
 
-@pytest.mark.parametrize("arch,es,px", [("resnet18", None, 64), ("resnet18", 3, 64), ("resnet50", None, 128), ("resnet50", 7, 256),
-                                        ("wide_resnet50_2", 14, 64), ("resnet34", None, 64)])
-def test_whole_encoder_against_oracle(E, arch, es, px):
-    """the last case is BASELINE configs[1]'s encoder at its real resolution (batch 8): 32768-row stage-1 maps, i.e. the tile
-    sizes of the real step (fp32 parity mode)"""
+def _damp(enc_like, value=0.25):
+    """scale the last BatchNorm of every residual branch: the well-conditioned variant of the net (a freshly initialised ResNet
+    doubles its activation scale every block; ReLU decisions then flip between fp32 and fp64 and no tight comparison is possible)"""
+    with torch.no_grad():
+        for mod in enc_like.modules():
+            if hasattr(mod, "conv1") and hasattr(mod, "bn2"):
+                (mod.bn3 if hasattr(mod, "bn3") else mod.bn2).weight.fill_(value)
+
+
+@pytest.mark.parametrize("arch,es,px,D,nb", [("resnet18", None, 64, 32, 8), ("resnet18", 3, 64, 32, 8), ("resnet50", None, 128, 32, 8), ("resnet50", 7, 256, 32, 8),
+                                             ("wide_resnet50_2", 14, 64, 32, 8), ("resnet34", None, 64, 32, 8),
+                                             # BASELINE configs[2] and [3]: the encoders at their real resolution and annotation shape
+                                             ("resnet101", 14, 256, 512, 4), ("wide_resnet101_2", 14, 256, 1024, 4)])
+def test_whole_encoder_against_oracle(E, arch, es, px, D, nb):
+    """Whole encoders, fp32 parity mode, forward + every gradient against the CPU oracle; the fp64 run of the same oracle is the
+    yardstick for what fp32 itself costs.  ("resnet50", 7, 256) is BASELINE configs[1]'s encoder at its real resolution
+    (32768-row stage-1 maps: the tile sizes of the real step); the last two are configs[2] / [3] (L = 196, D = 512 / 1024)."""
     from oracle import prng, sat_oracle as O
     torch.set_num_threads(min(16, os.cpu_count() or 1))
-    hp = O.default_hparams(encoder_arch=arch, encoder_dim=32, input_size=px, encoder_size=es)
+    hp = O.default_hparams(encoder_arch=arch, encoder_dim=D, input_size=px, encoder_size=es)
     torch.manual_seed(3)
     ref = O.build_encoder(hp)                                   # CPU, train mode
-    hp2 = O.default_hparams(encoder_arch=arch, encoder_dim=32, input_size=px, encoder_size=es)
+    _damp(ref)
+    hp2 = O.default_hparams(encoder_arch=arch, encoder_dim=D, input_size=px, encoder_size=es)
     enc = E.get_encoder(hp2)
     assert list(enc.state_dict().keys()) == list(ref.state_dict().keys())
     enc.load_state_dict(ref.state_dict())
     enc = enc.cuda().train()
-    img = torch.from_numpy(prng.uniform((8, 3, px, px), 77, 0.0, 1.0))
+    img = torch.from_numpy(prng.uniform((nb, 3, px, px), 77, 0.0, 1.0))
     import copy
     ref64 = copy.deepcopy(ref).double()                         # fp64 run of the same oracle: the yardstick for fp32 noise
     y_ref = ref(img.clone())
@@ -247,22 +260,18 @@ def test_whole_encoder_against_oracle(E, arch, es, px):
     close(y, y_ref, 2e-4, "annotations")
     y.backward(dy.cuda())
     gref = dict(ref.named_parameters()); g64 = dict(ref64.named_parameters())
-    worst = 0.0
+    worst = (0.0, 0.0, "")
     for k, p in enc.named_parameters():
         assert p.grad is not None, k
         exact = g64[k].grad
         nrm = max(1e-12, float(exact.norm()))
         err_gpu = float((p.grad.cpu().double() - exact).norm()) / nrm
         err_cpu = float((gref[k].grad.double() - exact).norm()) / nrm      # what fp32 itself costs on this net
-        worst = max(worst, err_gpu)
-        # A randomly initialised ResNet at batch 8 is badly conditioned (ReLU / max-pool decisions flip between fp32
-        # and fp64): the CPU fp32 oracle itself is ~2e-2 (relative L2) away from its own fp64 run on every tensor.
-        # The layer and block tests above are the tight ones; here the HIP path must be as close to fp64 as the
-        # fp32 reference is.  One ReLU decision flipping on a pre-activation within fp32 rounding of zero moves a
-        # tensor's gradient by ~1/sqrt(samples*channels) ~ 4e-3..2e-2 here (seen on resnet18 at 64 px; the path is
-        # bit-reproducible run to run, tools/diag_determinism.py), hence 5e-2 per tensor.
-        assert err_gpu <= 2 * err_cpu + 5e-2, "%s: HIP %.3e vs CPU-fp32 %.3e (relative L2 to fp64)" % (k, err_gpu, err_cpu)
-    print("worst relative grad error vs fp64:", worst)
+        worst = max(worst, (err_gpu, err_cpu, k))
+        # the HIP path must be as close to fp64 as the fp32 CPU reference is: twice its error plus 2e-3 (the exact-fp32 MFMA sums in
+        # another order and BatchNorm statistics accumulate in double on both sides; no additive slack beyond that)
+        assert err_gpu <= 2 * err_cpu + 2e-3, "%s: HIP %.3e vs CPU-fp32 %.3e (relative L2 to fp64)" % (k, err_gpu, err_cpu)
+    print("worst relative grad error vs fp64 (HIP, CPU fp32, tensor):", worst)
     # running statistics follow nn.BatchNorm2d
     sd, sr = enc.state_dict(), ref.state_dict()
     for k in sd:
@@ -321,11 +330,10 @@ def test_conv_bf16_fwd_dgrad_wgrad(E, N, H, W, C, K, R, stride, pad):
 
 @pytest.mark.parametrize("kind,cin,planes,stride", [("basic", 16, 16, 1), ("basic", 16, 32, 2), ("bottleneck", 64, 16, 1), ("bottleneck", 32, 16, 2)])
 def test_residual_block_bf16_storage(E, kind, cin, planes, stride):
-    """bf16 activations / filter copies through one residual block against the fp32 oracle block:
-    relative L2 error <= 1e-2 on the output and <= 0.2 on the input gradient and every parameter gradient.  The
-    gradient error is dominated by ReLU decisions that flip for pre-activations within bf16 rounding of zero (the bias
-    gradient -- a plain masked sum accumulated in double -- already shows 3e-2), not by the arithmetic."""
-    from oracle import sat_oracle as O
+    """bf16 activations / filter copies through one residual block against the oracle block with bf16 rounding at the same storage
+    points (oracle/bf16_emulation.py): ReLU decisions agree, so the output is within one bf16 ulp (1e-2 of its range) and the input
+    gradient and every parameter gradient within 3e-2 relative L2 (what is left: fp32 accumulation order flipping a bf16 rounding)."""
+    from oracle import bf16_emulation as B16, sat_oracle as O
     g = torch.Generator().manual_seed(cin + planes + stride)
     torch.manual_seed(cin * 7 + planes)
     ref = O._Residual(kind, cin, planes, stride, 64)
@@ -335,13 +343,13 @@ def test_residual_block_bf16_storage(E, kind, cin, planes, stride):
             if p.dim() == 1:
                 p.copy_(torch.rand(p.shape, generator=g) + 0.5)
     blk.load_state_dict(ref.state_dict()); E._channels_last_(blk); blk = blk.cuda().train()
-    x = torch.randn(6, cin, 12, 12, generator=g).requires_grad_()
-    y = ref(x.clone()); dy = torch.randn(y.shape, generator=g); y.backward(dy)
+    x = B16.bf(torch.randn(6, cin, 12, 12, generator=g)).requires_grad_()
+    y = B16._block(ref, x); dy = B16.bf(torch.randn(y.shape, generator=g)); y.backward(dy)
     cache = {}
     Wt = lambda p: cache.setdefault(p, E.cast_bf16(p))
     rec = E._block_fwd(blk, nhwc(x.detach()).cuda().to(torch.bfloat16), True, Wt)
     l2 = lambda a, b: float((a.detach().float().cpu() - b.detach()).norm() / b.detach().norm())
-    assert l2(nchw(rec.out), y) <= 1e-2
+    assert l2(nchw(rec.out), y) <= 5e-3
     grads = {}
     dx = E._block_bwd(rec, nhwc(dy).cuda().to(torch.bfloat16), grads, True, Wt)
     errs = {"dx": l2(nchw(dx), x.grad)}
@@ -349,7 +357,7 @@ def test_residual_block_bf16_storage(E, kind, cin, planes, stride):
     for k, p in blk.named_parameters():
         errs[k] = l2(grads[p], refp[k].grad)
     print(errs)
-    assert max(errs.values()) <= 0.2, errs
+    assert max(errs.values()) <= 3e-2, errs
 
 
 @pytest.mark.parametrize("N,H,W,C,K,R,stride,pad", [(4, 16, 16, 64, 64, 3, 1, 1), (3, 9, 9, 64, 256, 1, 1, 0), (2, 20, 20, 8, 64, 7, 2, 3),

@@ -301,3 +301,33 @@ def test_batched_beam_search_at_c5_decoder_shapes():
     for u, v in zip(flat(a[2]), flat(b[2])):
         assert u.shape == v.shape and float((u - v).abs().max()) <= 2e-5
     assert b[0] == c[0] and b[1] == c[1] and all(torch.equal(u, v) for u, v in zip(flat(b[2]), flat(c[2])))
+
+
+@pytest.mark.parametrize("images,precision", [(12, "fp32"), (64, "fp32")])
+def test_c5_beam_search_against_the_cpu_oracle(images, precision):
+    """BASELINE configs[4] at its real decoder dimensions (D = 512, n = 512, A = 128, m = 256, V = 6400, L = 49, beam 5; 64 images):
+    the batched on-device search against the CPU oracle's per-image beam search (oracle.sat_oracle.beam_search = model.py:237-472
+    restated; pinned by fixture G7): captions token for token, list order included; scores, perplexities and attention maps 1e-4."""
+    import os
+    import sat_amd  # noqa: F401
+    from sat_amd import model as M
+    from oracle import prng, sat_oracle as O
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    hp = O.default_hparams(vocab_size=6400, encoder_dim=512, embed_dim=256, attention_dim=128, decoder_dim=512)
+    torch.manual_seed(5)
+    dec = M.SATDecoder(hp).cuda().eval()
+    sd = {k: v.detach().cpu().clone() for k, v in dec.state_dict().items()}
+    ann_bld = torch.from_numpy(prng.uniform((images, 49, 512), 95, 0.0, 2.0))
+    ann_img = ann_bld.reshape(images, 7, 7, 512).permute(0, 3, 1, 2).contiguous()
+    kw = dict(beamk=5, max_gen_length=14, temperature=1.0, rescore_method="LN", return_all=True)
+    with torch.no_grad():
+        want = O.beam_search(sd, hp, ann_img, **kw)
+    got = dec.beam_decode_batched(ann_bld.cuda(), (7, 7), **kw)
+    assert got[0] == want[0], "captions differ from the CPU oracle"
+    flat = lambda x: [v for e in x for v in e]                            # noqa: E731
+    for u, v in zip(flat(got[1]), flat(want[1])):
+        assert abs(u - v) <= 1e-4 * max(1.0, abs(v)), (u, v)
+    for u, v in zip(flat(got[3]), flat(want[3])):
+        assert abs(u - v) <= 1e-4 * max(1.0, abs(v)), (u, v)
+    for u, v in zip(flat(got[2]), flat(want[2])):
+        assert u.shape == v.shape and float((u - v).abs().max()) <= 1e-4

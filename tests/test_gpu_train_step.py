@@ -110,53 +110,53 @@ def test_frozen_encoder_and_state_dict_roundtrip():
     assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("size", ["small", "c2-encoder"])
-def test_bf16_mode_tracks_the_fp32_oracle(size):
-    """hip_precision="bf16" (BASELINE configs[1]) has no reference counterpart (the reference only has fp16 AMP).
-    Stated tolerance against the fp32 oracle: loss 2e-2 relative, logits 6e-2 of their range, alphas 2e-2 absolute,
-    decoder-side gradients 0.15 relative L2, encoder gradients cosine >= 0.9 with the fp32 ones (bf16 has 8 significant
-    bits; ReLU decisions flip near zero and compound over the residual stack, test_gpu_encoder.py quantifies one block;
-    accumulation, statistics and master weights are fp32)."""
+BF16_CASES = {
+    # name: (hparams, images, residual damping)
+    "small": (dict(decoder_tf="always", encoder_dim=32, embed_dim=32, attention_dim=16, decoder_dim=64, vocab_size=128, input_size=128, encoder_size=None), 16, 0.25),
+    # resnet50 at 256 px (stage-1 maps of 32768 rows: the real step's tile sizes), C1-width decoder
+    "c2-encoder": (dict(decoder_tf="always", encoder_arch="resnet50", encoder_dim=256, embed_dim=256, attention_dim=128, decoder_dim=512, vocab_size=640,
+                        input_size=256, encoder_size=7), 8, 0.25),
+    # the same net as torch initialises it (no damping): the case whose ReLU flips made the fp32-oracle comparison useless
+    "c2-encoder-undamped": (dict(decoder_tf="always", encoder_arch="resnet50", encoder_dim=256, embed_dim=256, attention_dim=128, decoder_dim=512, vocab_size=640,
+                                 input_size=256, encoder_size=7), 8, None),
+}
+
+
+@pytest.mark.parametrize("size", sorted(BF16_CASES))
+def test_bf16_mode_against_the_bf16_rounding_oracle(size):
+    """hip_precision="bf16" (BASELINE configs[1]) has no reference counterpart (the reference only has fp16 AMP).  Its yardstick
+    is the CPU oracle with bf16 rounding applied at the SAME storage points (oracle/bf16_emulation.py: activations, filter copies, GEMM
+    operands), so ReLU / max-pool decisions agree and what is left is accumulation order.  Stated tolerance: loss 2e-3 relative, logits
+    2e-2 of their range, alphas 2e-3 absolute, every gradient tensor 5e-2 relative L2 (3e-2 on the damped nets).  Against the plain fp32
+    oracle the same run is only required to stay within the coarse envelope of the design (loss 3e-2)."""
     import os
+    from oracle import bf16_emulation as B16
     torch.set_num_threads(min(16, os.cpu_count() or 1))
-    if size == "small":
-        model, oracle, hp = make(dict(decoder_tf="always", encoder_dim=32, embed_dim=32, attention_dim=16, decoder_dim=64, vocab_size=128,
-                                      input_size=128, encoder_size=None), damp_residual=0.25)
-        nb = 16                                 # 128 px, batch 16: 256 samples per channel in the last stage's BatchNorms
-    else:                                       # resnet50 at 256 px (stage-1 maps of 32768 rows: the real step's tile sizes), C1-width decoder
-        model, oracle, hp = make(dict(decoder_tf="always", encoder_arch="resnet50", encoder_dim=256, embed_dim=256, attention_dim=128,
-                                      decoder_dim=512, vocab_size=640, input_size=256, encoder_size=7), damp_residual=0.25)
-        nb = 8
+    over, nb, damp = BF16_CASES[size]
+    model, oracle, hp = make(over, damp_residual=damp)
     model.set_precision("bf16")
     img, caps, lengths = batch(hp, B=nb)
-    loss_o, out_o = oracle.step_loss(img, caps, lengths, 1.0)
+    with torch.no_grad():
+        loss_f32, _ = oracle.step_loss(img, caps, lengths, 1.0)
+    loss_o, out_o = B16.step_loss(oracle, img, caps, lengths, 1.0)
     loss_o.backward()
     lp, tp, alphas = model.train_batch((img.cuda(), caps.cuda(), lengths), 1.0)
     assert lp.data.dtype == torch.float32 and alphas.dtype == torch.float32
-    assert rel(lp.data, out_o["logits_packed"]) <= 6e-2
-    assert float((alphas.cpu() - out_o["alphas"]).abs().max()) <= 2e-2
+    assert rel(lp.data, out_o["logits_packed"]) <= 2e-2, rel(lp.data, out_o["logits_packed"])
+    assert float((alphas.cpu() - out_o["alphas"]).abs().max()) <= 2e-3
     m = model.training_step((img.cuda(), caps.cuda(), lengths), 0)
-    assert abs(m["loss"].item() - loss_o.item()) <= 2e-2 * abs(loss_o.item())
+    assert abs(m["loss"].item() - loss_o.item()) <= 2e-3 * abs(loss_o.item()), (m["loss"].item(), loss_o.item())
+    assert abs(m["loss"].item() - loss_f32.item()) <= 3e-2 * abs(loss_f32.item())
     m["loss"].backward()
     og = oracle.named_grads()
-    worst = 0.0
-    coses = []
+    tol = 5e-2 if damp is None else 3e-2
+    errs = {}
     for k, p in model.named_parameters():
         assert p.grad is not None and p.grad.dtype == torch.float32 and torch.isfinite(p.grad).all(), k
-        e = float((p.grad.cpu().double() - og[k].double()).norm()) / max(1e-9, float(og[k].double().norm()))
-        worst = max(worst, e)
-        print("%-40s %.3e" % (k, e))
-        # the batch-8 ResNet amplifies rounding in front of its BatchNorms (test_gpu_encoder: fp32 itself is 2e-2 off
-        # fp64 there); decoder-side tensors are well conditioned
-        if k.startswith("encoder.") and not k.startswith("encoder.9"):
-            a, b = p.grad.cpu().double().flatten(), og[k].double().flatten()
-            cos = float(a @ b / (a.norm() * b.norm() + 1e-30))
-            coses.append((cos, k))
-            # 16 residual blocks of bf16 rounding and ReLU flips in front of the stem at batch 8 (resnet50) vs 8 blocks (resnet18)
-            assert cos >= (0.9 if size == "small" else 0.75), "%s: cosine with the fp32 gradient %.3f" % (k, cos)
-        else:
-            assert e <= 0.15, "%s: relative L2 gradient error %.3e" % (k, e)
-    print("bf16 mode: worst relative L2 gradient error", worst, " lowest encoder cosines", sorted(coses)[:4])
+        errs[k] = float((p.grad.cpu().double() - og[k].double()).norm()) / max(1e-9, float(og[k].double().norm()))
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:6]
+    print("bf16 mode vs the rounding oracle: worst relative L2 gradient errors", worst)
+    assert worst[0][1] <= tol, worst
 
 
 def test_bf16_filter_copies_stay_current_through_optimizer_steps():
@@ -234,9 +234,10 @@ def test_c2_full_size_step_is_reproducible_bit_for_bit():
     assert float(rm.abs().max()) > 0 and int(s1["encoder.2.num_batches_tracked"]) == 3      # model.py:46-48's probe forward at construction + 2 steps
 
 
-@pytest.mark.parametrize("cfg,ragged", [("c2", True), ("c1", False)])
+@pytest.mark.parametrize("cfg,ragged", [("c2", True), ("c1", False), ("c3", True), ("c4", True)])
 def test_full_size_steps_stay_finite(cfg, ragged):
-    """BASELINE-size steps on ragged captions: every gradient and parameter finite after three optimizer steps, loss falling.
+    """BASELINE-size steps on ragged captions (C3 / C4: the per-GPU shards of configs[2] / [3], resnet101 L=196 with 32 images and
+    wide_resnet101_2 D=1024 T=32 with 64 images): every gradient and parameter finite after three optimizer steps, loss falling.
     (ReLU written as fmaxf maps NaN to 0, so a kernel that produces NaN in the trunk does not show in the loss: check the tensors.)"""
     import os
     import sys
@@ -263,3 +264,34 @@ def test_full_size_steps_stay_finite(cfg, ragged):
     assert [k for k, p in model.named_parameters() if not bool(torch.isfinite(p).all())] == []
     assert [k for k, b in model.named_buffers() if b.is_floating_point() and not bool(torch.isfinite(b).all())] == []
     assert losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize("cfg", ["c3", "c4"])
+def test_c3_c4_shard_steps_are_reproducible_bit_for_bit(cfg):
+    """BASELINE configs[2] / [3] at their per-GPU shard sizes (bench.py --config c3 / c4), bf16 mode: two identical models stepped on the
+    same batch agree bit for bit in loss and every gradient (fixed-order reductions on every tile shape these nets launch)."""
+    import math
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    import sat_amd  # noqa: F401
+    from sat_amd import model as M
+    hp, T, B, R = bench.hparams(cfg)
+    img, caps, lengths = bench.synthetic_batch(B, R, T, hp["vocab_size"], 4321, True)
+    img, caps = img.cuda(), caps.cuda()
+
+    def run():
+        torch.manual_seed(42)
+        model = M.SAT(**hp).cuda().train(); model.set_precision("bf16")
+        model.__dict__["_sat_global_step"] = 2
+        out = model.training_step((img.clone(), caps, lengths), 0)
+        out["loss"].backward()
+        return out["loss"].detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    l1, g1 = run()
+    junk = torch.full((1 << 26,), float("nan"), device="cuda"); del junk
+    l2, g2 = run()
+    assert torch.equal(l1, l2) and math.isfinite(float(l1)) and abs(float(l1) - math.log(hp["vocab_size"])) < 1.5
+    assert [k for k in g1 if not torch.equal(g1[k], g2[k])] == []
+    assert all(bool(torch.isfinite(v).all()) for v in g1.values()) and len(g1) > 300
