@@ -34,6 +34,9 @@ int sat_abi_version(void);
 /* dev aid: after every kernel launch wait for the device and print the launch's name to stderr (a device fault then points at the
  * launch after the last printed line).  Also switched on by SAT_TRACE_LAUNCH=1.  Not for captured streams. */
 int sat_debug_trace_launches(int32_t on);
+/* dev aid: tuning switches of the GEMM launcher by name ("glds_tile": force a tile form of csrc/gemm_glds.hip, -1 = automatic;
+ * "glds_stages8": LDS ring depth of its 8-wave forms; "tile_override": replace the launcher's own choice).  Not for production use. */
+int sat_debug_option(const char* name, int32_t value);
 const char* sat_last_error(void);
 
 /* ------------------------------------------------------------------ kernel timing for the roofline report

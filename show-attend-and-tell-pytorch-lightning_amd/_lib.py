@@ -91,6 +91,7 @@ class DecoderBatch(C.Structure):
 SYMBOLS = {
     "sat_abi_version": (C.c_int, []),
     "sat_debug_trace_launches": (C.c_int, [C.c_int32]),
+    "sat_debug_option": (C.c_int, [C.c_char_p, C.c_int32]),
     "sat_last_error": (C.c_char_p, []),
     "sat_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
     "sat_decoder_workspace_bytes": (C.c_size_t, [C.POINTER(DecoderDims)]),

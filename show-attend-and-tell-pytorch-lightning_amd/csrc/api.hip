@@ -4,6 +4,7 @@
 #include "../../include/sat_hip.h"
 #include "decoder.h"
 #include "gemm.h"
+#include "gemm_bf16_common.h"
 
 namespace sat {
 static thread_local char g_err[512] = {0};
@@ -21,6 +22,13 @@ extern "C" {
 
 int sat_abi_version(void) { return SAT_HIP_ABI_VERSION; }
 int sat_debug_trace_launches(int32_t on) { sat::trace_launches() = on ? 1 : 0; return SAT_OK; }
+int sat_debug_option(const char* name, int32_t value) {
+    if (!name) return fail(SAT_EINVAL, "debug_option: null name");
+    if (!strcmp(name, "glds_tile")) { glds_force_tile() = value; return SAT_OK; }
+    if (!strcmp(name, "glds_stages8")) { glds_stages8() = value; return SAT_OK; }
+    if (!strcmp(name, "tile_override")) { gemm_tile_override() = value; return SAT_OK; }
+    return fail(SAT_EINVAL, "debug_option: unknown option %s", name);
+}
 const char* sat_last_error(void) { return last_error_buf(); }
 
 static int gemm_from_desc(const sat_gemm_desc* d, const sat_gemm_types* t, void* stream);

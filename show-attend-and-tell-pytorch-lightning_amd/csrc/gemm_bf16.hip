@@ -318,8 +318,31 @@ int gemm_bf16_eligible(const GemmArgs& g) {
     return 1;
 }
 
+int& gemm_tile_override() { static int v = -1; return v; }      // dev: sat_debug_option("tile_override", BMt): 64, 128, 256 (256x256), 257 (256x128)
+
+static int launch_gemm_bf16_tile(const GemmArgs& g, int tile_mode, hipStream_t st);
+
+// 8-wave tile forms of gemm_glds.hip (256x256 / 256x128, one workgroup per CU): chosen where they cut the L2 -> LDS operand traffic
+// of the 128x128 form - every operand tile is re-read once per tile of the OTHER dimension - and still fill the chip.
+static int pick_wide_tile(const GemmArgs& g) {
+    static const int wide = getenv("SAT_WIDE_TILES") ? atoi(getenv("SAT_WIDE_TILES")) : 1;
+    if (!wide || !g.a_bf16 || !g.b_bf16 || g.a_rows || g.c_rows || g.K % 64) return 0;
+    if (g.M < 256 || g.N < 128) return 0;
+    return 0;     // (set by measurement below)
+}
+
 int launch_gemm_bf16(const GemmArgs& g, hipStream_t st) {
     if (g.M == 0 || g.N == 0) return SAT_OK;
+    int mode = gemm_tile_override() > 0 ? gemm_tile_override() : pick_wide_tile(g);
+    if (mode >= 256) {
+        const int r = launch_gemm_bf16_tile(g, mode, st);
+        if (r != -1) return r;
+    }
+    return launch_gemm_bf16_tile(g, (mode == 64 || mode == 128) ? mode : 0, st);
+}
+
+// tile_mode: 0 = automatic 64 / 128; 64, 128 forced; 256 = 256x256, 257 = 256x128 (direct-to-LDS forms only: -1 when the problem does not fit them)
+static int launch_gemm_bf16_tile(const GemmArgs& g, int tile_mode, hipStream_t st) {
     SAT_REQUIRE(g.A && g.B && g.C, "gemm_bf16: null operand");
     SAT_REQUIRE(gemm_bf16_eligible(g), "gemm_bf16: operands not 16-byte gatherable (mode %d,%d M=%d N=%d K=%d)", g.amode, g.bmode, g.M, g.N, g.K);
     BArgs k;
@@ -332,7 +355,9 @@ int launch_gemm_bf16(const GemmArgs& g, hipStream_t st) {
     if ((long)cdiv(g.M, 128) * cdiv(g.N, 128) >= tiles128_min && g.M >= 128 && g.N >= 128) BMt = 128;
     // long reductions (weight gradients): split-K supplies the parallelism, so keep the 64x64-per-wave tile
     if (g.slab && g.M >= 128 && g.N >= 128 && g.K >= 64 * KB) BMt = 128;
-    long blocks = (long)cdiv(g.M, BMt) * cdiv(g.N, BMt);
+    if (tile_mode) BMt = tile_mode;
+    const int tbm = BMt >= 256 ? 256 : BMt, tbn = BMt == 256 ? 256 : (BMt == 257 ? 128 : BMt);
+    long blocks = (long)cdiv(g.M, tbm) * cdiv(g.N, tbn);
     int ns = 1;
     if (g.slab && blocks < 256 && g.K >= 16 * KB) {
         // split-K: enough blocks to keep every CU streaming (~TARGET blocks), but the fp32 partial slabs (written and
@@ -340,7 +365,8 @@ int launch_gemm_bf16(const GemmArgs& g, hipStream_t st) {
         static const int target = getenv("SAT_SPLIT_TARGET") ? atoi(getenv("SAT_SPLIT_TARGET")) : 768;
         static const int frac = getenv("SAT_SPLIT_FRAC") ? atoi(getenv("SAT_SPLIT_FRAC")) : 8;
         static const int target128 = getenv("SAT_SPLIT_TARGET128") ? atoi(getenv("SAT_SPLIT_TARGET128")) : 512;
-        const int tgt = (BMt == 128) ? target128 : target;      // resident workgroups: 2 per CU with 128-wide tiles, ~3 with 64-wide; rounding DOWN keeps the grid inside one residency round
+        static const int target256 = getenv("SAT_SPLIT_TARGET256") ? atoi(getenv("SAT_SPLIT_TARGET256")) : 256;
+        const int tgt = (BMt >= 256) ? target256 : (BMt == 128) ? target128 : target;      // resident workgroups: 2 per CU with 128-wide tiles, ~3 with 64-wide; rounding DOWN keeps the grid inside one residency round
         static const int floor_mode = getenv("SAT_SPLIT_FLOOR") ? atoi(getenv("SAT_SPLIT_FLOOR")) : 1;
         int want = floor_mode ? (int)(tgt / blocks) : (int)((tgt + blocks - 1) / blocks), maxs = g.K / (8 * KB);
         if (want < 1) want = 1;
@@ -358,7 +384,7 @@ int launch_gemm_bf16(const GemmArgs& g, hipStream_t st) {
     k.wide_slab = (k.nsplit > 1 && g.N % 4 == 0 && al16(g.slab)) ? 1 : 0;
     k.tile_stats = nullptr;
     if (g.tile_rows) *g.tile_rows = 0;
-    if (g.tile_stats && g.tile_rows && g.c_bf16 && k.wide_store && !g.accumulate && !g.g.cls) { k.tile_stats = g.tile_stats; *g.tile_rows = BMt; }
+    if (g.tile_stats && g.tile_rows && g.c_bf16 && k.wide_store && !g.accumulate && !g.g.cls) { k.tile_stats = g.tile_stats; *g.tile_rows = tbm; }
 
     static const bool log_shapes = getenv("SAT_LOG_GEMM") != nullptr;     // dev: one stderr line per launch, in launch order
     if (log_shapes) fprintf(stderr, "GEMMLOG am=%d bm=%d M=%d N=%d K=%d ns=%d acc=%d types=%d%d%d epi=%d\n", g.amode, g.bmode, g.M, g.N, g.K, k.nsplit,
@@ -370,6 +396,7 @@ int launch_gemm_bf16(const GemmArgs& g, hipStream_t st) {
         const int r = launch_gemm_glds(k, g.amode, g.bmode, cb, BMt, st, &bm_used);
         if (r != -1) { if (k.tile_stats && g.tile_rows) *g.tile_rows = bm_used; return r; }
     }
+    if (BMt >= 256) { if (g.tile_rows) *g.tile_rows = 0; return -1; }
     if (ab && bb) {         // encoder: bf16 activations / filters
         if (g.amode == A_CONV_FWD && g.bmode == B_ROW && cb) SAT_BCASE(A_CONV_FWD, B_ROW, __bf16, __bf16, __bf16)
         if (g.amode == A_ROW && g.bmode == B_ROW && cb) SAT_BCASE(A_ROW, B_ROW, __bf16, __bf16, __bf16)

@@ -204,6 +204,137 @@ __device__ __forceinline__ void store_tile(const BArgs& a, f32x16 (&acc)[BM / 64
             }
 }
 
+// The same write-out for a workgroup of WR x WC waves (wave (wr, wc) owns the (BM / WR) x (BN / WC) block at (wm, wn) of the tile;
+// acc[i][j] its 32x32 MFMA blocks): gemm_glds.hip's 8-wave tiles.  `smem` must hold the staged tile (see store_lds_bytes).
+template <int BM, int BN, int WR, int WC, typename TC> constexpr size_t store_lds_bytes() {
+    return sizeof(TC) == 2 ? (size_t)BM * (BN + 8) * 2 + (size_t)WR * BN * 2 * 4 : (size_t)(BM / WR) * (BN + 4) * 4;
+}
+template <int BM, int BN, int WR, int WC, typename TC>
+__device__ __forceinline__ void store_tile_w(const BArgs& a, f32x16 (&acc)[BM / WR / 32][BN / WC / 32], __bf16* smem, int bm, int bn, int bz, int wm, int wn,
+                                             int wrow, int tid, int lane) {
+    constexpr int TM = BM / WR / 32, TN = BN / WC / 32, NTH = 64 * WR * WC;
+    const int li = lane & 31, lh = lane >> 5;
+    if (sizeof(TC) == 2 && a.wide_store) {
+        constexpr int LDC = BN + 8;
+        __bf16* cs = smem;
+        __syncthreads();
+        if (a.tile_stats) {
+            float* sbuf = reinterpret_cast<float*>(smem + BM * LDC);           // [WR wave rows][BN][2], behind the staged tile
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = bm + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const float vb = (float)(__bf16)acc[i][j][r];
+                        if (row < a.M) { s1 += vb; s2 = fmaf(vb, vb, s2); }
+                    }
+                s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+                if (lh == 0) { float* q = sbuf + (wrow * BN + wn + j * 32 + li) * 2; q[0] = s1; q[1] = s2; }
+            }
+            __syncthreads();
+            if (tid < BN && bn + tid < a.N) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WR; ++w) { s1 += sbuf[(w * BN + tid) * 2]; s2 += sbuf[(w * BN + tid) * 2 + 1]; }
+                float* o = a.tile_stats + ((long)(bm / BM) * a.N + bn + tid) * 2;
+                o[0] = s1; o[1] = s2;
+            }
+        }
+        const bool odd = lane & 1;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const int lr0 = wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, lc = wn + j * 32 + li;
+                    float v0 = acc[i][j][r], v1 = acc[i][j][r + 1];
+                    if (a.epi != EPI_NONE && bn + lc < a.N) {
+                        if (bm + lr0 < a.M) v0 = ep_value(a, bm + lr0, bn + lc, v0);
+                        if (bm + lr0 + 1 < a.M) v1 = ep_value(a, bm + lr0 + 1, bn + lc, v1);
+                    }
+                    const float give = odd ? v0 : v1;
+                    const float got = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(give), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true));
+                    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                    bf16x2 pk;
+                    if (odd) { pk[0] = (__bf16)got; pk[1] = (__bf16)v1; } else { pk[0] = (__bf16)v0; pk[1] = (__bf16)got; }
+                    *reinterpret_cast<bf16x2*>(cs + (lr0 + (odd ? 1 : 0)) * LDC + (lc & ~1)) = pk;
+                }
+        __syncthreads();
+        constexpr int VPR = BN / 8;
+#pragma unroll
+        for (int j = 0; j < BM * VPR / NTH; ++j) {
+            int v = tid + j * NTH, lr = v / VPR, lc = (v % VPR) * 8;
+            int row = bm + lr, col = bn + lc;
+            if (row < a.M && col < a.N) {
+                bf16x8 o = *reinterpret_cast<const bf16x8*>(cs + lr * LDC + lc);
+                const long orow = a.g.cls ? class_row(a, row) : (long)row;
+                __bf16* dst = reinterpret_cast<__bf16*>(a.C) + orow * a.ldc + col;
+                if (a.accumulate) {
+                    bf16x8 old = *reinterpret_cast<const bf16x8*>(dst);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (__bf16)((float)o[e] + (float)old[e]);
+                }
+                *reinterpret_cast<bf16x8*>(dst) = o;
+            }
+        }
+        return;
+    }
+    if ((a.nsplit > 1) ? a.wide_slab : (sizeof(TC) == 4 && a.wide_store)) {
+        // fp32 result or split-K partial: one wave row of the tile at a time through LDS, 16-byte row segments out
+        constexpr int LDF = BN + 4, RB = BM / WR, VPR = BN / 4;
+        float* fs = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int h = 0; h < WR; ++h) {
+            __syncthreads();
+            if (wrow == h) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            fs[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDF + wn + j * 32 + li] = acc[i][j][r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int jj = 0; jj < RB * VPR / NTH; ++jj) {
+                const int v = tid + jj * NTH, lr = v / VPR, lc = (v % VPR) * 4;
+                const int row = bm + h * RB + lr, col = bn + lc;
+                if (row < a.M && col < a.N) {
+                    float4 o = *reinterpret_cast<const float4*>(fs + lr * LDF + lc);
+                    if (a.nsplit > 1) { *reinterpret_cast<float4*>(a.slab + ((long)bz * a.M + row) * a.N + col) = o; continue; }
+                    const long orow = a.g.cls ? class_row(a, row) : (long)row;
+                    float* dst = reinterpret_cast<float*>(a.C) + orow * a.ldc + col;
+                    if (a.accumulate) { const float4 old = *reinterpret_cast<const float4*>(dst); o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+                    if (a.epi != EPI_NONE) {
+                        o.x = ep_value(a, row, col, o.x); o.y = ep_value(a, row, col + 1, o.y);
+                        o.z = ep_value(a, row, col + 2, o.z); o.w = ep_value(a, row, col + 3, o.w);
+                    }
+                    *reinterpret_cast<float4*>(dst) = o;
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = bm + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                int col = bn + wn + j * 32 + li;
+                if (row < a.M && col < a.N) {
+                    if (a.nsplit > 1) a.slab[((long)bz * a.M + row) * a.N + col] = acc[i][j][r];
+                    else put<TC>(a, row, col, acc[i][j][r]);
+                }
+            }
+}
+
 template <typename TC>
 __global__ void splitk_reduce_b_kernel(BArgs a) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -249,5 +380,8 @@ __device__ __forceinline__ void xcd_tile(int& bx, int& by, int& bz) {
 // gemm_glds.hip: direct-to-LDS operand staging; returns -1 when the problem does not fit its forms (caller falls through)
 // *bm_used (if given): rows per tile of the kernel that ran (what the per-tile statistics are indexed by)
 int launch_gemm_glds(const BArgs& k, int amode, int bmode, int c_bf16, int BMt, hipStream_t st, int* bm_used = nullptr);
+int& glds_force_tile();      // dev switches (sat_debug_option)
+int& glds_stages8();
+int& gemm_tile_override();
 
 }  // namespace sat

@@ -70,16 +70,21 @@ __device__ __forceinline__ unsigned tap_mask(int rlo, int rhi, int clo, int chi,
 
 struct PixEnt { int off; unsigned mask; };   // wgrad: byte offset of the input pixel under tap (0,0) of an output pixel, valid taps
 
-template <int BM, int BN, int AM, int BMo, typename TC>
-__global__ __launch_bounds__(NT) void gemm_glds_kernel(BArgs a) {
+// WR x WC waves per workgroup; wave (wr, wc) owns the (BM / WR) x (BN / WC) block of the tile.  2 x 2 waves on 128x128 (and 128x64,
+// 64x64) is the original form; 4 x 2 waves on 256x128 and 256x256 tiles (one workgroup per CU) halve the L2 -> LDS traffic per
+// product and, on 256x256, read 6 LDS fragments per 8 MFMAs instead of 4 per 4.
+template <int BM, int BN, int WR, int WC, int AM, int BMo, typename TC>
+__global__ __launch_bounds__(64 * WR * WC) void gemm_glds_kernel(BArgs a) {
     constexpr int KB = 64;
+    constexpr int NW = WR * WC, NTH = 64 * NW;
     constexpr bool AK = (AM == A_KMAJOR);
     constexpr bool BKM = (BMo != B_ROW);
     constexpr bool ACONV = (AM == A_CONV_FWD || AM == A_CONV_DGRAD);
     constexpr int A_EL = BM * KB, B_EL = BN * KB;
     constexpr int STAGE = A_EL + B_EL;
-    constexpr int NA = BM / 32, NB = BN / 32;          // LDS-DMA wave-instructions per wave and k-tile
-    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int NA = BM / (8 * NW), NB = BN / (8 * NW);          // LDS-DMA wave-instructions per wave and k-tile
+    constexpr int TM = BM / WR / 32, TN = BN / WC / 32;
+    static_assert(NA >= 1 && NB >= 1 && TM >= 1 && TN >= 1, "tile too small for this wave grid");
     constexpr bool WG = (BMo == B_CONV_WGRAD);
     constexpr int G = NA + NB;                          // (vmcnt bookkeeping)
     constexpr int SMAX = 4;                             // deepest ring
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(NT) void gemm_glds_kernel(BArgs a) {
     const int bm = by * BM, bn = bx * BN;
     const int kbeg = bz * a.kchunk;
     const int kend = min(a.K, kbeg + a.kchunk);
-    const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
+    const int wrow = wave / WC, wm = wrow * (BM / WR), wn = (wave % WC) * (BN / WC);
     const int li = lane & 31, lh = lane >> 5;
     const int tg = lane >> 4, ti = lane & 15;
     const int t_h = tg >> 1, t_mh = tg & 1, t_q = ti >> 2, t_p = ti & 3;
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(NT) void gemm_glds_kernel(BArgs a) {
     int a_off0[NA]; unsigned a_mask[NA];
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
-        const int chunk = j * 4 + wave;
+        const int chunk = j * NW + wave;
         a_mask[j] = 0;
         if (!AK) {
             const int row = chunk * 8 + (lane >> 3), ks = (lane & 7) ^ ((row >> 1) & 7);
@@ -137,7 +142,7 @@ __global__ __launch_bounds__(NT) void gemm_glds_kernel(BArgs a) {
         } else {
             constexpr int SP = BM / 8;
             const int krow = chunk * (64 / SP) + lane / SP, sl = lane % SP;
-            const int lq = (sl >> 2) ^ (BM == 128 ? (krow & 3) : ((krow >> 1) & 1));
+            const int lq = (sl >> 2) ^ (BM >= 128 ? (krow & 3) : ((krow >> 1) & 1));
             int col = bm + (lq * 4 + (sl & 3)) * 8;
             if (col >= a.M) col = a.M - 8;
             a_off0[j] = (int)(((long)krow * a.lda + col) * 2);
@@ -146,7 +151,7 @@ __global__ __launch_bounds__(NT) void gemm_glds_kernel(BArgs a) {
     int b_off0[NB]; unsigned b_bit[NB]; int b_krow[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        const int chunk = j * 4 + wave;
+        const int chunk = j * NW + wave;
         b_bit[j] = 0; b_krow[j] = 0;
         if (!BKM) {
             const int row = chunk * 8 + (lane >> 3), ks = (lane & 7) ^ ((row >> 1) & 7);
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(NT) void gemm_glds_kernel(BArgs a) {
         } else {
             constexpr int SP = BN / 8;
             const int krow = chunk * (64 / SP) + lane / SP, sl = lane % SP;
-            const int lq = (sl >> 2) ^ (BN == 128 ? (krow & 3) : ((krow >> 1) & 1));
+            const int lq = (sl >> 2) ^ (BN >= 128 ? (krow & 3) : ((krow >> 1) & 1));
             int n = bn + (lq * 4 + (sl & 3)) * 8;
             const bool ok = n < a.N;
             if (!ok) n = a.N - 8;
@@ -215,9 +220,9 @@ __global__ __launch_bounds__(NT) void gemm_glds_kernel(BArgs a) {
         }
     };
 
-    // wgrad pixel table of one k-tile: the four waves take turns (tile t is decoded by wave t & 3)
+    // wgrad pixel table of one k-tile: the waves take turns (tile t is decoded by wave t mod NW)
     auto fill_tab = [&](int slot, int t) {
-        if (WG && wave == (t & 3)) {
+        if (WG && wave == (t & (NW - 1))) {
             PixEnt e; e.off = 0; e.mask = 0;
             int tt = t + rot; if (tt >= T) tt -= T;          // sequence position -> k-tile (positions past the end are never loaded)
             const int k = kbeg + tt * KB + lane;
@@ -237,16 +242,16 @@ __global__ __launch_bounds__(NT) void gemm_glds_kernel(BArgs a) {
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             if (j != jj) continue;
-            if (ACONV) dma16(rA, (a_mask[j] & tap_bit) ? a_off0[j] + tapA : OOB, 0, as + (j * 4 + wave) * 512);
-            else dma16(rA, a_off0[j], sA, as + (j * 4 + wave) * 512);
+            if (ACONV) dma16(rA, (a_mask[j] & tap_bit) ? a_off0[j] + tapA : OOB, 0, as + (j * NW + wave) * 512);
+            else dma16(rA, a_off0[j], sA, as + (j * NW + wave) * 512);
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             if (j + NA != jj) continue;
             if (WG) {
                 const PixEnt e = ptab[tb][b_krow[j]];
-                dma16(rB, (e.mask & b_bit[j]) ? e.off + b_off0[j] : OOB, 0, bs + (j * 4 + wave) * 512);
-            } else dma16(rB, b_off0[j], sB, bs + (j * 4 + wave) * 512);
+                dma16(rB, (e.mask & b_bit[j]) ? e.off + b_off0[j] : OOB, 0, bs + (j * NW + wave) * 512);
+            } else dma16(rB, b_off0[j], sB, bs + (j * NW + wave) * 512);
         }
     };
     auto issue = [&](int buf, int tb) {
@@ -270,7 +275,7 @@ __global__ __launch_bounds__(NT) void gemm_glds_kernel(BArgs a) {
         if (!AK) { const int row = wm + i * 32 + li; a_off[i] = row * KB; a_sw[i] = (row >> 1) & 7; }
         else {
             const int col = wm + i * 32 + 16 * t_mh + 4 * t_p, kr = 8 * t_h + t_q;
-            const int sw = (BM == 128) ? (kr & 3) : ((kr >> 1) & 1);
+            const int sw = (BM >= 128) ? (kr & 3) : ((kr >> 1) & 1);
             a_off[i] = kr * BM + (((col >> 5) ^ sw) << 5) + (col & 31); a_sw[i] = 0;
         }
     }
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(NT) void gemm_glds_kernel(BArgs a) {
         if (!BKM) { const int row = wn + j * 32 + li; b_off[j] = row * KB; b_sw[j] = (row >> 1) & 7; }
         else {
             const int col = wn + j * 32 + 16 * t_mh + 4 * t_p, kr = 8 * t_h + t_q;
-            const int sw = (BN == 128) ? (kr & 3) : ((kr >> 1) & 1);
+            const int sw = (BN >= 128) ? (kr & 3) : ((kr >> 1) & 1);
             b_off[j] = kr * BN + (((col >> 5) ^ sw) << 5) + (col & 31); b_sw[j] = 0;
         }
     }
@@ -358,7 +363,8 @@ __global__ __launch_bounds__(NT) void gemm_glds_kernel(BArgs a) {
             nxt = (nxt + 1 == S) ? 0 : nxt + 1;
         }
     }
-    store_tile<BM, BN, TC, 2 * STAGE>(a, acc, smem, bm, bn, bz, wm, wn, tid, lane);     // the launch allocates at least the epilogue's staging size
+    if constexpr (WR == 2 && WC == 2) store_tile<BM, BN, TC, 2 * STAGE>(a, acc, smem, bm, bn, bz, wm, wn, tid, lane);
+    else store_tile_w<BM, BN, WR, WC, TC>(a, acc, smem, bm, bn, bz, wm, wn, wrow, tid, lane);      // the launch allocates at least the epilogue's staging size
 }
 
 static const char* gname(int am, int bm) {
@@ -370,7 +376,7 @@ static const char* gname(int am, int bm) {
     return "tn";
 }
 
-template <int BM, int BN, int AM, int BMo, typename TC>
+template <int BM, int BN, int WR, int WC, int AM, int BMo, typename TC>
 static int rung(const BArgs& k, hipStream_t st) {
     dim3 grid(cdiv(k.N, BN), cdiv(k.M, BM), k.nsplit);
     char pname[128];
@@ -381,16 +387,19 @@ static int rung(const BArgs& k, hipStream_t st) {
     }
     ProfScope prof(pname, 2.0 * k.M * k.N * k.K, 2.0 * k.M * k.K + 2.0 * k.N * k.K + (double)sizeof(TC) * k.M * k.N, st);
     size_t lds = (size_t)k.nstage * (BM + BN) * 64 * sizeof(__bf16);
-    // the epilogue stages the result tile in the same memory: bf16 tile (+ statistics) or half an fp32 tile
-    const size_t epi_lds = (sizeof(TC) == 2) ? (size_t)BM * (BN + 8) * 2 + 2 * BN * 2 * 4 : (size_t)(BM / 2) * (BN + 4) * 4;
+    // the epilogue stages the result tile in the same memory: bf16 tile (+ statistics) or a wave row of the fp32 tile
+    const size_t epi_lds = (WR == 2 && WC == 2) ? ((sizeof(TC) == 2) ? (size_t)BM * (BN + 8) * 2 + 2 * BN * 2 * 4 : (size_t)(BM / 2) * (BN + 4) * 4)
+                                                : store_lds_bytes<BM, BN, WR, WC, TC>();
     if (lds < epi_lds) lds = epi_lds;
-    static bool attr_set = false;        // per instantiation: allow the deepest ring (128 KiB of dynamic LDS)
+    constexpr size_t LDS_DYN_MAX = 160 * 1024 - 2560;       // the whole LDS less the kernel's static part (the weight-gradient pixel tables: 2 KiB)
+    SAT_REQUIRE(lds <= LDS_DYN_MAX, "gemm_glds: %zu bytes of LDS for a %dx%d tile with %d stages", lds, BM, BN, k.nstage);
+    static bool attr_set = false;        // per instantiation: allow the whole LDS (160 KiB of dynamic LDS)
     if (!attr_set) {
-        SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BM, BN, AM, BMo, TC>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          4 * (BM + BN) * 64 * (int)sizeof(__bf16)));
+        SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BM, BN, WR, WC, AM, BMo, TC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)LDS_DYN_MAX));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, AM, BMo, TC>), grid, dim3(NT), lds, st, k);
+    hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WR, WC, AM, BMo, TC>), grid, dim3(64 * WR * WC), lds, st, k);
     SAT_TRY(launch_ok("gemm_glds_kernel"));
     if (k.nsplit > 1) {
         long total = (long)k.M * k.N;
@@ -401,22 +410,25 @@ static int rung(const BArgs& k, hipStream_t st) {
     return SAT_OK;
 }
 
+// tile forms: 0 = 64x64, 1 = 128x128, 2 = 128x64 (4 waves); 3 = 256x128, 4 = 256x256 (8 waves, one workgroup per CU)
+enum { TILE_64 = 0, TILE_128 = 1, TILE_128x64 = 2, TILE_256x128 = 3, TILE_256 = 4 };
 template <int AM, int BMo, typename TC>
-static int rung_tiles(const BArgs& k, int BMt, hipStream_t st, int* bm_used) {
-    if (BMt == 128) { if (bm_used) *bm_used = 128; return rung<128, 128, AM, BMo, TC>(k, st); }
-    // 64 output columns (the ResNet stage-1 layers) over many rows: 128-row tiles halve the workgroup count and the filter-tile
-    // re-reads of the 64x64 form (per k-tile 24 KB for 128x64 products instead of 2 x 16 KB)
-    static const int tall = getenv("SAT_GLDS_TALL") ? atoi(getenv("SAT_GLDS_TALL")) : 2;      // 0 off, 1 row-major A only, 2 also k-major A (1x1 weight gradients)
-    if (tall && BMo != B_CONV_WGRAD && k.N <= 64 && (AM == A_KMAJOR ? (tall > 1 && k.M >= 128) : k.M >= 8192)) {
-        if (bm_used) *bm_used = 128;
-        return rung<128, 64, AM, BMo, TC>(k, st);
+static int rung_tiles(const BArgs& k, int tile, hipStream_t st, int* bm_used) {
+    switch (tile) {
+        case TILE_256: if (bm_used) *bm_used = 256; return rung<256, 256, 4, 2, AM, BMo, TC>(k, st);
+        case TILE_256x128: if (bm_used) *bm_used = 256; return rung<256, 128, 4, 2, AM, BMo, TC>(k, st);
+        case TILE_128: if (bm_used) *bm_used = 128; return rung<128, 128, 2, 2, AM, BMo, TC>(k, st);
+        case TILE_128x64: if (bm_used) *bm_used = 128; return rung<128, 64, 2, 2, AM, BMo, TC>(k, st);
+        default: if (bm_used) *bm_used = 64; return rung<64, 64, 2, 2, AM, BMo, TC>(k, st);
     }
-    if (bm_used) *bm_used = 64;
-    return rung<64, 64, AM, BMo, TC>(k, st);
 }
+
+int& glds_force_tile() { static int v = getenv("SAT_GLDS_TILE") ? atoi(getenv("SAT_GLDS_TILE")) : -1; return v; }
+int& glds_stages8() { static int v = getenv("SAT_GLDS_STAGES8") ? atoi(getenv("SAT_GLDS_STAGES8")) : 0; return v; }
 
 // -1: this problem does not fit the direct-to-LDS forms (caller keeps the register-staged kernel)
 int launch_gemm_glds(const BArgs& k0, int amode, int bmode, int c_bf16, int BMt, hipStream_t st, int* bm_used) {
+    const int force_tile = glds_force_tile();      // dev: force a tile form (enum above); SAT_GLDS_TILE or sat_debug_option("glds_tile", n)
     static const int off = getenv("SAT_NO_GLDS") ? atoi(getenv("SAT_NO_GLDS")) : 0;
     static const int force_stages = getenv("SAT_GLDS_STAGES") ? atoi(getenv("SAT_GLDS_STAGES")) : 0;
     static const int deep_from = getenv("SAT_GLDS_DEEP_FROM") ? atoi(getenv("SAT_GLDS_DEEP_FROM")) : 1 << 30;
@@ -434,6 +446,17 @@ int launch_gemm_glds(const BArgs& k0, int amode, int bmode, int c_bf16, int BMt,
     k.rotate = rotate;
     if (k.nstage < 1) k.nstage = 1;
     if (k.nstage > 4) k.nstage = 4;
+    // tile form (the caller's BMt says 64- or 128-wide): 128x64 for the 64-column outputs over many rows (halves the workgroup count
+    // and the filter-tile re-reads of the 64x64 form), 8-wave forms on request
+    static const int tall = getenv("SAT_GLDS_TALL") ? atoi(getenv("SAT_GLDS_TALL")) : 2;      // 0 off, 1 row-major A only, 2 also k-major A (1x1 weight gradients)
+    int tile = (BMt >= 256) ? (BMt == 256 ? TILE_256 : TILE_256x128) : (BMt == 128 ? TILE_128 : TILE_64);      // BMt: 64, 128, 256 (= 256x256), 257 (= 256x128)
+    if (tile == TILE_64 && tall && bmode != B_CONV_WGRAD && k.N <= 64 && (amode == A_KMAJOR ? (tall > 1 && k.M >= 128) : k.M >= 8192)) tile = TILE_128x64;
+    if (force_tile >= 0) tile = force_tile;
+    if (tile == TILE_256 || tile == TILE_256x128) {          // one workgroup per CU: the ring may be three deep on 256x128 (144 KiB), two on 256x256
+        const int maxs = (tile == TILE_256) ? 2 : 3;
+        const int deep8 = glds_stages8();
+        if (ktiles > 1) k.nstage = deep8 ? (deep8 < maxs ? deep8 : maxs) : (ktiles >= 3 ? maxs : 2);
+    }
     const ConvGeom& g = k.g;
     if (g.sw && g.sw != g.stride) return -1;          // anisotropic stride: register-staged kernel only
     if (k.K % 64 || k.kchunk % 64 || k.a_rows) return -1;
@@ -457,7 +480,7 @@ int launch_gemm_glds(const BArgs& k0, int amode, int bmode, int c_bf16, int BMt,
     }
     if (a_el >= lim || b_el >= lim) return -1;
     if ((amode == A_KMAJOR && k.M < 8) || (bmode != B_ROW && k.N < 8)) return -1;
-#define SAT_GCASE(AMV, BMV, TC) return rung_tiles<AMV, BMV, TC>(k, BMt, st, bm_used);
+#define SAT_GCASE(AMV, BMV, TC) return rung_tiles<AMV, BMV, TC>(k, tile, st, bm_used);
     if (amode == A_CONV_FWD && bmode == B_ROW && c_bf16) SAT_GCASE(A_CONV_FWD, B_ROW, __bf16)
     if (amode == A_ROW && bmode == B_ROW && c_bf16) SAT_GCASE(A_ROW, B_ROW, __bf16)
     if (amode == A_ROW && bmode == B_ROW && !c_bf16) SAT_GCASE(A_ROW, B_ROW, float)

@@ -126,9 +126,14 @@ BF16_CASES = {
 def test_bf16_mode_against_the_bf16_rounding_oracle(size):
     """hip_precision="bf16" (BASELINE configs[1]) has no reference counterpart (the reference only has fp16 AMP).  Its yardstick
     is the CPU oracle with bf16 rounding applied at the SAME storage points (oracle/bf16_emulation.py: activations, filter copies, GEMM
-    operands), so ReLU / max-pool decisions agree and what is left is accumulation order.  Stated tolerance: loss 2e-3 relative, logits
-    2e-2 of their range, alphas 2e-3 absolute, every gradient tensor 5e-2 relative L2 (3e-2 on the damped nets).  Against the plain fp32
-    oracle the same run is only required to stay within the coarse envelope of the design (loss 3e-2)."""
+    operands).  Forward: ReLU / max-pool decisions agree, so loss, logits and attention weights are compared DIRECTLY with that oracle
+    (loss 2e-3 relative, logits 2e-2 of their range, alphas 2e-3 absolute).  Backward: the gradient that enters the encoder carries a
+    large per-channel common mode (spatial mean of InitLSTM, attention context) that the first BatchNorm backward subtracts again; stored
+    in bf16, what is left of it is rounding noise of the common mode, so two correct bf16 implementations - this one and the CPU
+    emulation - differ by tens of percent on encoder gradients once their inputs differ in the last fp32 bits (the layer-, block- and
+    whole-encoder tests in test_gpu_encoder.py compare backward passes from IDENTICAL bf16 inputs and are the tight ones: 3e-2).  Here
+    the criterion is the cost of the storage format itself, measured by the emulation: for every gradient tensor the HIP path's error
+    against the fp32 oracle must not exceed twice the emulation's error against the fp32 oracle plus 2e-2."""
     import os
     from oracle import bf16_emulation as B16
     torch.set_num_threads(min(16, os.cpu_count() or 1))
@@ -136,27 +141,33 @@ def test_bf16_mode_against_the_bf16_rounding_oracle(size):
     model, oracle, hp = make(over, damp_residual=damp)
     model.set_precision("bf16")
     img, caps, lengths = batch(hp, B=nb)
-    with torch.no_grad():
-        loss_f32, _ = oracle.step_loss(img, caps, lengths, 1.0)
+    loss_f32, _ = oracle.step_loss(img, caps, lengths, 1.0)
+    loss_f32.backward()
+    g32 = {k: v.detach().clone().double() for k, v in oracle.named_grads().items()}
+    for p in oracle.parameters():
+        p.grad = None
     loss_o, out_o = B16.step_loss(oracle, img, caps, lengths, 1.0)
     loss_o.backward()
     lp, tp, alphas = model.train_batch((img.cuda(), caps.cuda(), lengths), 1.0)
     assert lp.data.dtype == torch.float32 and alphas.dtype == torch.float32
     assert rel(lp.data, out_o["logits_packed"]) <= 2e-2, rel(lp.data, out_o["logits_packed"])
-    assert float((alphas.cpu() - out_o["alphas"]).abs().max()) <= 2e-3
+    assert float((alphas.cpu() - out_o["alphas"].detach()).abs().max()) <= 2e-3
     m = model.training_step((img.cuda(), caps.cuda(), lengths), 0)
     assert abs(m["loss"].item() - loss_o.item()) <= 2e-3 * abs(loss_o.item()), (m["loss"].item(), loss_o.item())
     assert abs(m["loss"].item() - loss_f32.item()) <= 3e-2 * abs(loss_f32.item())
     m["loss"].backward()
     og = oracle.named_grads()
-    tol = 5e-2 if damp is None else 3e-2
-    errs = {}
+    rows = []
     for k, p in model.named_parameters():
         assert p.grad is not None and p.grad.dtype == torch.float32 and torch.isfinite(p.grad).all(), k
-        errs[k] = float((p.grad.cpu().double() - og[k].double()).norm()) / max(1e-9, float(og[k].double().norm()))
-    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:6]
-    print("bf16 mode vs the rounding oracle: worst relative L2 gradient errors", worst)
-    assert worst[0][1] <= tol, worst
+        nrm = max(1e-12, float(g32[k].norm()))
+        e_hip = float((p.grad.cpu().double() - g32[k]).norm()) / nrm            # what bf16 storage costs on the HIP path ...
+        e_emu = float((og[k].double() - g32[k]).norm()) / nrm                   # ... and in the CPU emulation of the same storage points
+        rows.append((e_hip - 2 * e_emu, e_hip, e_emu, k))
+    rows.sort(reverse=True)
+    print("bf16 mode: (HIP error, emulation error) against the fp32 oracle, worst margins:", [(round(a, 4), round(b, 4), k) for _, a, b, k in rows[:5]])
+    print("           largest emulation errors:", sorted([(round(b, 4), k) for _, a, b, k in rows], reverse=True)[:3])
+    assert rows[0][0] <= 2e-2, rows[:4]
 
 
 def test_bf16_filter_copies_stay_current_through_optimizer_steps():
