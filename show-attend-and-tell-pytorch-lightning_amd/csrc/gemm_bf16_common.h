@@ -26,6 +26,7 @@ struct BArgs {
     int wide_slab = 0;    // the same for split-K partials
     int nstage = 2;       // gemm_glds.hip: LDS ring depth
     int rotate = 1 << 20; // gemm_glds.hip: per-workgroup rotation of the k-tile sequence, window in k-tiles (0 = off)
+    int ablate = 0;       // gemm_glds.hip, dev only: timing ablations (results are then garbage)
     float* tile_stats = nullptr;   // optional (wide_store only): per row tile and output column (sum, sum of squares) of the stored bf16 values
 };
 
@@ -382,6 +383,7 @@ __device__ __forceinline__ void xcd_tile(int& bx, int& by, int& bz) {
 int launch_gemm_glds(const BArgs& k, int amode, int bmode, int c_bf16, int BMt, hipStream_t st, int* bm_used = nullptr);
 int& glds_force_tile();      // dev switches (sat_debug_option)
 int& glds_stages8();
+int& glds_ablate();
 int& gemm_tile_override();
 
 }  // namespace sat

@@ -237,7 +237,9 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_glds_kernel(BArgs a) {
     };
 
     // one LDS-DMA wave-instruction of the next tile: A pieces jj < NA, then B pieces
+    const int abl = a.ablate;          // dev: 1 = no operand loads after the prologue, 2 = no MFMAs, 4 = no fragment reads, 8 = no result stores
     auto issue_piece = [&](int buf, int tb, int jj) {
+        if (abl & 1) return;
         __bf16* as = smem + buf * STAGE; __bf16* bs = as + A_EL;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
@@ -336,20 +338,27 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_glds_kernel(BArgs a) {
                     }
                 }
             };
-            load_frags(0, af[0], bf[0]);
+            if (!(abl & 4) || it == 0) load_frags(0, af[0], bf[0]);
 #pragma unroll
             for (int ks = 0; ks < KB / 16; ++ks) {
-                if (ks + 1 < KB / 16) load_frags((ks + 1) * 16, af[(ks + 1) & 1], bf[(ks + 1) & 1]);
+                if (ks + 1 < KB / 16 && (!(abl & 4) || it == 0)) load_frags((ks + 1) * 16, af[(ks + 1) & 1], bf[(ks + 1) & 1]);
                 // this k-step's share of the next tile's LDS-DMA pieces, issued under the MFMAs
                 if (more) {
 #pragma unroll
                     for (int jj = (ks * G) / 4; jj < ((ks + 1) * G) / 4; ++jj) issue_piece(nxt, nxt, jj);          // G pieces spread over the four k-steps
                 }
+                if (!(abl & 2)) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(af[ks & 1][i]), "v"(bf[ks & 1][j]));      // keep the fragment reads alive
+                }
             }
             if (more) advance_tile();
             if (S == 1 && it + 1 < T) {            // one-stage ring with several k-tiles: refill the only stage once every wave has read it
@@ -362,6 +371,13 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_glds_kernel(BArgs a) {
             cur = (cur + 1 == S) ? 0 : cur + 1;
             nxt = (nxt + 1 == S) ? 0 : nxt + 1;
         }
+    }
+    if (abl & 8) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
     }
     if constexpr (WR == 2 && WC == 2) store_tile<BM, BN, TC, 2 * STAGE>(a, acc, smem, bm, bn, bz, wm, wn, tid, lane);
     else store_tile_w<BM, BN, WR, WC, TC>(a, acc, smem, bm, bn, bz, wm, wn, wrow, tid, lane);      // the launch allocates at least the epilogue's staging size
@@ -424,6 +440,7 @@ static int rung_tiles(const BArgs& k, int tile, hipStream_t st, int* bm_used) {
 }
 
 int& glds_force_tile() { static int v = getenv("SAT_GLDS_TILE") ? atoi(getenv("SAT_GLDS_TILE")) : -1; return v; }
+int& glds_ablate() { static int v = getenv("SAT_GLDS_ABLATE") ? atoi(getenv("SAT_GLDS_ABLATE")) : 0; return v; }
 int& glds_stages8() { static int v = getenv("SAT_GLDS_STAGES8") ? atoi(getenv("SAT_GLDS_STAGES8")) : 0; return v; }
 
 // -1: this problem does not fit the direct-to-LDS forms (caller keeps the register-staged kernel)
@@ -444,6 +461,7 @@ int launch_gemm_glds(const BArgs& k0, int amode, int bmode, int c_bf16, int BMt,
     static const int s1_upto = getenv("SAT_GLDS_S1_UPTO") ? atoi(getenv("SAT_GLDS_S1_UPTO")) : 1;
     k.nstage = force_stages ? force_stages : (ktiles >= deep_from ? 4 : ((ktiles == 1 || (c_bf16 && ktiles <= s1_upto)) ? 1 : 2));
     k.rotate = rotate;
+    k.ablate = glds_ablate();
     if (k.nstage < 1) k.nstage = 1;
     if (k.nstage > 4) k.nstage = 4;
     // tile form (the caller's BMt says 64- or 128-wide): 128x64 for the 64-column outputs over many rows (halves the workgroup count
