@@ -25,6 +25,8 @@
 // tap, tracked incrementally); everything else stays on gemm_bf16.hip.
 #include <stdlib.h>
 
+#include <initializer_list>
+
 #include "gemm_bf16_common.h"
 #include "profile.h"
 
@@ -68,6 +70,15 @@ __device__ __forceinline__ unsigned tap_mask(int rlo, int rhi, int clo, int chi,
     return m;
 }
 
+// timing ablations: the value stays live although nothing consumes it (a "v" operand does not parse in the host pass, where the
+// kernel body would then be dropped without a diagnostic)
+template <typename T> __device__ __forceinline__ void keep_alive(const T& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::"v"(v));
+#endif
+}
+template <typename T, typename U> __device__ __forceinline__ void keep_alive(const T& v, const U& w) { keep_alive(v); keep_alive(w); }
+
 struct PixEnt { int off; unsigned mask; };   // wgrad: byte offset of the input pixel under tap (0,0) of an output pixel, valid taps
 
 // WR x WC waves per workgroup; wave (wr, wc) owns the (BM / WR) x (BN / WC) block of the tile.  2 x 2 waves on 128x128 (and 128x64,
@@ -76,7 +87,7 @@ struct PixEnt { int off; unsigned mask; };   // wgrad: byte offset of the input 
 template <int BM, int BN, int WR, int WC, int AM, int BMo, typename TC>
 __global__ __launch_bounds__(64 * WR * WC) void gemm_glds_kernel(BArgs a) {
     constexpr int KB = 64;
-    constexpr int NW = WR * WC, NTH = 64 * NW;
+    constexpr int NW = WR * WC;
     constexpr bool AK = (AM == A_KMAJOR);
     constexpr bool BKM = (BMo != B_ROW);
     constexpr bool ACONV = (AM == A_CONV_FWD || AM == A_CONV_DGRAD);
@@ -357,7 +368,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_glds_kernel(BArgs a) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
-                        for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(af[ks & 1][i]), "v"(bf[ks & 1][j]));      // keep the fragment reads alive
+                        for (int j = 0; j < TN; ++j) keep_alive(af[ks & 1][i], bf[ks & 1][j]);      // keep the fragment reads alive
                 }
             }
             if (more) advance_tile();
@@ -376,7 +387,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_glds_kernel(BArgs a) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j]));
+            for (int j = 0; j < TN; ++j) keep_alive(acc[i][j]);
         return;
     }
     if constexpr (WR == 2 && WC == 2) store_tile<BM, BN, TC, 2 * STAGE>(a, acc, smem, bm, bn, bz, wm, wn, tid, lane);
