@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SAT_HIP_ABI_VERSION 15
+#define SAT_HIP_ABI_VERSION 16
 
 int sat_abi_version(void);
 /* dev aid: after every kernel launch wait for the device and print the launch's name to stderr (a device fault then points at the
@@ -308,6 +308,18 @@ int sat_bn_train_fwd_tiles_bf16(const void* x, int64_t rows, int32_t C, const fl
                                 const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* save_mean,
                                 float* save_invstd, const void* residual, int32_t relu, void* y, uint8_t* relu_mask, float* scratch, void* stream);
 int sat_conv2d_dgrad_bf16(const void* dy, const void* w, void* dx, const sat_conv_geom* g, int32_t accumulate, void* stream);
+/* Data gradient that also leaves the BACKWARD statistics of the BatchNorm in front of this convolution: dx is the gradient of that
+ * BatchNorm's (ReLU'd) output, so with its input bn_x (same NHWC shape as dx), the forward's ReLU sign mask (or NULL: no ReLU) and its
+ * saved mean / invstd, the epilogue adds up per row tile and channel (sum g, sum g * xhat), g = the stored dx masked by the sign bits ->
+ * tile_stats[tile][C][2] (sat_conv2d_dgrad_stats_bytes).  sat_bn_train_bwd_tiles_bf16 is sat_bn_train_bwd_t(dtype = bf16) without the
+ * statistics pass over dy and x.  *tile_rows = 0 when the launch could not produce them (stride 2, odd shapes): take sat_bn_train_bwd_t.
+ * With accumulate = 1 the statistics are those of the accumulated dx. */
+size_t sat_conv2d_dgrad_stats_bytes(const sat_conv_geom* g);
+int sat_conv2d_dgrad_bf16_bnstats(const void* dy, const void* w, void* dx, const sat_conv_geom* g, int32_t accumulate, const void* bn_x,
+                                  const uint8_t* bn_relu_mask, const float* bn_mean, const float* bn_invstd, float* tile_stats, int32_t* tile_rows, void* stream);
+int sat_bn_train_bwd_tiles_bf16(const void* dy, const void* x, int64_t rows, int32_t C, const float* tile_stats, int32_t tile_rows, const float* save_mean,
+                                const float* save_invstd, const float* gamma, int32_t relu, void* dx, float* dgamma, float* dbeta, void* dres,
+                                int32_t dres_accumulate, const uint8_t* relu_mask, float* scratch, void* stream);
 int sat_conv2d_wgrad_bf16(const void* dy, const void* x, float* dw, const sat_conv_geom* g, float* slab, int64_t slab_elems, void* stream);
 /* ResNet stem tail in one pass (model.py:19-29 keeps torchvision's bn1 -> relu -> maxpool): BatchNorm(train statistics already in
  * mean / invstd: sat_bn_train_fwd_t with y = NULL computes them and updates the running statistics) + ReLU + MaxPool2d(3, 2, 1)

@@ -26,7 +26,6 @@ int sat_debug_option(const char* name, int32_t value) {
     if (!name) return fail(SAT_EINVAL, "debug_option: null name");
     if (!strcmp(name, "glds_tile")) { glds_force_tile() = value; return SAT_OK; }
     if (!strcmp(name, "glds_stages8")) { glds_stages8() = value; return SAT_OK; }
-    if (!strcmp(name, "glds_ablate")) { glds_ablate() = value; return SAT_OK; }
     if (!strcmp(name, "tile_override")) { gemm_tile_override() = value; return SAT_OK; }
     return fail(SAT_EINVAL, "debug_option: unknown option %s", name);
 }

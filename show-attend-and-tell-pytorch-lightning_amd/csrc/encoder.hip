@@ -826,11 +826,19 @@ int sat_conv2d_fwd_bf16_stats(const void* x, const void* w, void* y, const sat_c
     return SAT_OK;
 }
 
-static int conv_dgrad_any(const void* dy, const void* w, void* dx, const sat_conv_geom* geom, int accumulate, int bf16, void* stream) {
+struct BnBwdStats { const void* x; const unsigned char* mask; const float* mean; const float* invstd; float* tile_stats; int* tile_rows; };
+static int conv_dgrad_any(const void* dy, const void* w, void* dx, const sat_conv_geom* geom, int accumulate, int bf16, void* stream,
+                          const BnBwdStats* bs = nullptr) {
     ConvGeom g; SAT_TRY(conv_geom(geom, g, bf16 ? 8 : 4));
     if (!dy || !w || !dx) return fail(SAT_EINVAL, "conv2d_dgrad: null pointer");
     GemmArgs a; a.a_bf16 = a.b_bf16 = a.c_bf16 = a.bf16_mfma = bf16;
     a.accumulate = accumulate; a.C = dx; a.ldc = g.C; a.g = g;
+    if (bs) {
+        *bs->tile_rows = 0;
+        if (bf16 && !(g.stride == 2)) {          // (the stride-2 parity classes write interleaved rows: no tile statistics there)
+            a.bn_x = bs->x; a.bn_mask = bs->mask; a.bn_mean = bs->mean; a.bn_invstd = bs->invstd; a.tile_stats = bs->tile_stats; a.tile_rows = bs->tile_rows;
+        }
+    }
     if (g.R == 1 && g.S == 1 && g.stride == 1 && g.pad == 0) {
         a.M = g.N * g.H * g.W; a.N = g.C; a.K = g.K; a.A = dy; a.lda = g.K; a.amode = A_ROW; a.B = w; a.ldb = g.C; a.bmode = B_KMAJOR;
     } else if (bf16 && g.stride == 2) {
@@ -860,6 +868,19 @@ int sat_conv2d_dgrad(const float* dy, const float* w, float* dx, const sat_conv_
 }
 int sat_conv2d_dgrad_bf16(const void* dy, const void* w, void* dx, const sat_conv_geom* geom, int accumulate, void* stream) {
     return conv_dgrad_any(dy, w, dx, geom, accumulate, 1, stream);
+}
+size_t sat_conv2d_dgrad_stats_bytes(const sat_conv_geom* geom) {
+    ConvGeom g; if (conv_geom(geom, g, 8) != SAT_OK) return 0;
+    return (size_t)cdiv((long)g.N * g.H * g.W, 64L) * g.C * 2 * sizeof(float);
+}
+int sat_conv2d_dgrad_bf16_bnstats(const void* dy, const void* w, void* dx, const sat_conv_geom* geom, int accumulate, const void* bn_x, const uint8_t* bn_relu_mask,
+                                  const float* bn_mean, const float* bn_invstd, float* tile_stats, int32_t* tile_rows, void* stream) {
+    if (!bn_x || !bn_mean || !bn_invstd || !tile_stats || !tile_rows) return fail(SAT_EINVAL, "conv2d_dgrad_bf16_bnstats: null pointer");
+    int tr = 0;
+    BnBwdStats bs{bn_x, bn_relu_mask, bn_mean, bn_invstd, tile_stats, &tr};
+    SAT_TRY(conv_dgrad_any(dy, w, dx, geom, accumulate, 1, stream, &bs));
+    *tile_rows = tr;
+    return SAT_OK;
 }
 
 static int conv_wgrad_any(const void* dy, const void* x, float* dw, const sat_conv_geom* geom, float* slab, int64_t slab_elems, int bf16, void* stream) {
@@ -990,7 +1011,7 @@ static int bn_eval_fwd_t(const T* x, int64_t rows, int32_t C, const float* runni
 template <typename T>
 static int bn_train_bwd_t(const T* dy, const T* x, const T* y, int64_t rows, int32_t C, const float* save_mean, const float* save_invstd,
                           const float* gamma, int32_t relu, T* dx, float* dgamma, float* dbeta, T* dres, int32_t dres_accumulate,
-                          const uint8_t* relu_mask, float* scratch, hipStream_t st) {
+                          const uint8_t* relu_mask, float* scratch, hipStream_t st, const float* tile_stats = nullptr, int tile_rows = 0) {
     if (!dy || !x || !save_mean || !save_invstd || !gamma || !dx || !dgamma || !dbeta || !scratch) return fail(SAT_EINVAL, "bn_train_bwd: null pointer");
     if (relu && !y && !relu_mask) return fail(SAT_EINVAL, "bn_train_bwd: relu needs the forward output or its sign mask");
     SAT_REQUIRE(!relu_mask || C % 8 == 0, "bn_train_bwd: the ReLU sign mask needs C %% 8 == 0 (C=%d)", C);
@@ -999,7 +1020,16 @@ static int bn_train_bwd_t(const T* dy, const T* x, const T* y, int64_t rows, int
     SAT_REQUIRE(C % E == 0, "bn_train_bwd: C=%d must be a multiple of %d for this storage type", C, E);
     int CV, nparts; long rp; bn_grid(rows, C, E, CV, rp, nparts, 1);
     double* p0 = reinterpret_cast<double*>(scratch); double* p1 = p0 + (long)nparts * C;
-    {
+    if (tile_stats) {        // (sum g, sum g * xhat) per row tile came out of the epilogue of the data-gradient launch that wrote dy: no pass over dy / x
+        SAT_REQUIRE(tile_rows > 0, "bn_train_bwd: tile_rows=%d", tile_rows);
+        const int ntiles = (int)cdiv(rows, (long)tile_rows);
+        int np = cdiv(ntiles, 64); if (np > nparts) np = nparts; if (np < 1) np = 1;
+        const int per = cdiv(ntiles, np); np = cdiv(ntiles, per);
+        p1 = p0 + (long)np * C;
+        hipLaunchKernelGGL(bn_tile_reduce_kernel, dim3(cdiv(C, 32), np), dim3(256), 0, st, tile_stats, ntiles, C, per, p0, p1);
+        SAT_TRY(launch_ok("bn_tile_reduce (backward)"));
+        nparts = np;
+    } else {
         ProfScope prof("bn_stats_bwd", 0.0, (double)rows * C * (sizeof(T) * 2 + (relu ? (relu_mask ? 0.125 : (double)sizeof(T)) : 0.0)), st);
         static const int inter = getenv("SAT_BN_INTERLEAVE") ? atoi(getenv("SAT_BN_INTERLEAVE")) : 1;      // row groups dealt round-robin to the parts (-5 %)
         hipLaunchKernelGGL((bn_colstats_kernel<1, T>), dim3(cdiv(C / E, CV), nparts), dim3(256), 0, st, x, dy, y, relu_mask, save_mean, save_invstd, relu, (long)rows, C, CV, inter ? -1L : rp, p0, p1);
@@ -1129,6 +1159,14 @@ int sat_bn_train_bwd_t(int32_t dtype, const void* dy, const void* x, const void*
     SAT_BY_DTYPE(dtype,
         bn_train_bwd_t<float>((const float*)dy, (const float*)x, (const float*)y, rows, C, save_mean, save_invstd, gamma, relu, (float*)dx, dgamma, dbeta, (float*)dres, dres_accumulate, relu_mask, scratch, (hipStream_t)stream),
         bn_train_bwd_t<bf>((const bf*)dy, (const bf*)x, (const bf*)y, rows, C, save_mean, save_invstd, gamma, relu, (bf*)dx, dgamma, dbeta, (bf*)dres, dres_accumulate, relu_mask, scratch, (hipStream_t)stream));
+}
+int sat_bn_train_bwd_tiles_bf16(const void* dy, const void* x, int64_t rows, int32_t C, const float* tile_stats, int32_t tile_rows, const float* save_mean,
+                                const float* save_invstd, const float* gamma, int32_t relu, void* dx, float* dgamma, float* dbeta, void* dres,
+                                int32_t dres_accumulate, const uint8_t* relu_mask, float* scratch, void* stream) {
+    if (!tile_stats || tile_rows <= 0) return fail(SAT_EINVAL, "bn_train_bwd_tiles_bf16: no tile statistics");
+    if (relu && !relu_mask) return fail(SAT_EINVAL, "bn_train_bwd_tiles_bf16: relu needs the forward's sign mask");
+    return bn_train_bwd_t<bf>((const bf*)dy, (const bf*)x, (const bf*)nullptr, rows, C, save_mean, save_invstd, gamma, relu, (bf*)dx, dgamma, dbeta, (bf*)dres,
+                              dres_accumulate, relu_mask, scratch, (hipStream_t)stream, tile_stats, tile_rows);
 }
 int sat_bn_train_bwd(const float* dy, const float* x, const float* y, int64_t rows, int32_t C, const float* save_mean, const float* save_invstd,
                      const float* gamma, int32_t relu, float* dx, float* dgamma, float* dbeta, float* dres, int32_t dres_accumulate,

@@ -55,6 +55,8 @@ struct GemmArgs {
     int c0 = 0, c1 = 0;
     ConvGeom g = {};
     float* slab = nullptr; long slab_elems = 0;   // split-K scratch (optional)
+    // bf16 data-gradient launches: BatchNorm-backward form of the tile statistics (see BArgs::bn_x in gemm_bf16_common.h)
+    const void* bn_x = nullptr; const unsigned char* bn_mask = nullptr; const float* bn_mean = nullptr; const float* bn_invstd = nullptr;
     float* tile_stats = nullptr; int* tile_rows = nullptr;   // bf16 kernels: per-row-tile column statistics of the stored result (see gemm_bf16_common.h); *tile_rows = rows per tile chosen, 0 if not produced
 };
 

@@ -26,8 +26,11 @@ struct BArgs {
     int wide_slab = 0;    // the same for split-K partials
     int nstage = 2;       // gemm_glds.hip: LDS ring depth
     int rotate = 1 << 20; // gemm_glds.hip: per-workgroup rotation of the k-tile sequence, window in k-tiles (0 = off)
-    int ablate = 0;       // gemm_glds.hip, dev only: timing ablations (results are then garbage)
     float* tile_stats = nullptr;   // optional (wide_store only): per row tile and output column (sum, sum of squares) of the stored bf16 values
+    // BatchNorm-backward form of the tile statistics (data-gradient launches): with bn_x set, the per-tile pair is
+    // (sum g, sum g * xhat) with g = stored value (masked by the ReLU sign bits when bn_mask is set) and xhat = (bn_x - mean) * invstd,
+    // i.e. the partials of dbeta / dgamma of the BatchNorm whose OUTPUT gradient this launch writes.  bn_x / bn_mask share C's layout.
+    const __bf16* bn_x = nullptr; const unsigned char* bn_mask = nullptr; const float* bn_mean = nullptr; const float* bn_invstd = nullptr;
 };
 
 template <typename T> struct VecN { static constexpr int n = 16 / sizeof(T); };
@@ -65,6 +68,60 @@ __device__ __forceinline__ void put(const BArgs& a, int row, int col, float v) {
 }
 
 
+// BatchNorm-backward statistics in the write phase of a data-gradient tile (BArgs::bn_x).  Every thread of the write loop owns one
+// 8-column group of the tile (NTHR % (BN / 8) == 0) over BM * (BN / 8) / NTHR rows: it adds g and g * xhat of the values it has just
+// stored (the bf16-rounded, accumulated ones: exactly what the BatchNorm backward will read back), the threads of a column group are
+// combined by wave shuffles and through `sbuf` ([waves][BN][2] floats behind the staged tile) in a fixed order, and the tile's
+// (sum g, sum g * xhat) per column lands in tile_stats[tile][column] like the forward statistics do.
+template <int BN, int NTHR>
+struct BnAcc {
+    static constexpr int VPR = BN / 8, NWV = NTHR / 64;
+    static_assert(NTHR % VPR == 0 && 64 % VPR == 0, "a thread keeps one column group");
+    float s1[8], s2[8], mu[8], is[8];
+    bool on;
+    __device__ __forceinline__ BnAcc(const BArgs& a, int bn, int tid) {
+        on = a.bn_x != nullptr && a.tile_stats != nullptr;
+        const int col = bn + (tid % VPR) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            s1[e] = 0.f; s2[e] = 0.f;
+            const bool ok = on && col + e < a.N;
+            mu[e] = ok ? a.bn_mean[col + e] : 0.f; is[e] = ok ? a.bn_invstd[col + e] : 0.f;
+        }
+    }
+    __device__ __forceinline__ void add(const BArgs& a, const bf16x8& o, long elem) {
+        if (!on) return;
+        const bf16x8 xv = *reinterpret_cast<const bf16x8*>(a.bn_x + elem);
+        const unsigned mb = a.bn_mask ? a.bn_mask[elem >> 3] : 0xFFu;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float g = ((mb >> e) & 1u) ? (float)o[e] : 0.f;
+            s1[e] += g; s2[e] = fmaf(g, ((float)xv[e] - mu[e]) * is[e], s2[e]);
+        }
+    }
+    __device__ __forceinline__ void finish(const BArgs& a, float* sbuf, int tile, int bn, int tid) {
+        if (!on) return;
+        const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int o = VPR; o < 64; o <<= 1) { s1[e] += __shfl_xor(s1[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
+        }
+        if (lane < VPR) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { float* q = sbuf + ((long)wave * BN + lane * 8 + e) * 2; q[0] = s1[e]; q[1] = s2[e]; }
+        }
+        __syncthreads();
+        if (tid < BN && bn + tid < a.N) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWV; ++w) { t1 += sbuf[((long)w * BN + tid) * 2]; t2 += sbuf[((long)w * BN + tid) * 2 + 1]; }
+            float* o = a.tile_stats + ((long)tile * a.N + bn + tid) * 2;
+            o[0] = t1; o[1] = t2;
+        }
+    }
+};
+
 // Accumulator tile -> C.  acc[i][j] is the 32x32 MFMA block (i, j) of this wave's (BM/2 x BN/2) quadrant at (wm, wn);
 // C/D layout of v_mfma_f32_32x32x16_bf16: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
 // `smem` is the kernel's operand staging area (free once the k loop is over), `smem_elems` its size in bf16.
@@ -80,12 +137,12 @@ __device__ __forceinline__ void store_tile(const BArgs& a, f32x16 (&acc)[BM / 64
         static_assert(BM * LDC <= SMEM_ELEMS, "C tile must fit the staging buffers");
         __bf16* cs = smem;
         __syncthreads();
-        if (a.tile_stats) {
+        if (a.tile_stats && !a.bn_x) {
             // BatchNorm statistics of the tile while it is still in registers (one HBM pass less for the layer that follows):
             // per output column the sum and the sum of squares of the ROUNDED (stored) values over this tile's rows, in fp32
             // (<= 128 terms each); the tiles are combined in double by bn_tile_reduce_kernel (encoder.hip).
             float* sbuf = reinterpret_cast<float*>(smem + BM * LDC);           // [2 wave rows][BN][2], behind the staged tile
-            static_assert(BM * LDC * 2 + 2 * BN * 2 * 4 <= SMEM_ELEMS * 2, "tile statistics must fit behind the staged C tile");
+            static_assert(BM * LDC * 2 + 4 * BN * 2 * 4 <= SMEM_ELEMS * 2 || SMEM_ELEMS == 0, "tile statistics must fit behind the staged C tile");
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 float s1 = 0.f, s2 = 0.f;
@@ -132,6 +189,7 @@ __device__ __forceinline__ void store_tile(const BArgs& a, f32x16 (&acc)[BM / 64
                 }
         __syncthreads();
         constexpr int VPR = BN / 8;
+        BnAcc<BN, NT> bacc(a, bn, tid);
 #pragma unroll
         for (int j = 0; j < BM * VPR / NT; ++j) {
             int v = tid + j * NT, lr = v / VPR, lc = (v % VPR) * 8;
@@ -146,8 +204,10 @@ __device__ __forceinline__ void store_tile(const BArgs& a, f32x16 (&acc)[BM / 64
                     for (int e = 0; e < 8; ++e) o[e] = (__bf16)((float)o[e] + (float)old[e]);
                 }
                 *reinterpret_cast<bf16x8*>(dst) = o;
+                bacc.add(a, o, orow * a.ldc + col);
             }
         }
+        bacc.finish(a, reinterpret_cast<float*>(smem + BM * LDC), bm / BM, bn, tid);
         return;
     }
     if ((a.nsplit > 1) ? a.wide_slab : (sizeof(TC) == 4 && a.wide_store)) {
@@ -208,7 +268,7 @@ __device__ __forceinline__ void store_tile(const BArgs& a, f32x16 (&acc)[BM / 64
 // The same write-out for a workgroup of WR x WC waves (wave (wr, wc) owns the (BM / WR) x (BN / WC) block at (wm, wn) of the tile;
 // acc[i][j] its 32x32 MFMA blocks): gemm_glds.hip's 8-wave tiles.  `smem` must hold the staged tile (see store_lds_bytes).
 template <int BM, int BN, int WR, int WC, typename TC> constexpr size_t store_lds_bytes() {
-    return sizeof(TC) == 2 ? (size_t)BM * (BN + 8) * 2 + (size_t)WR * BN * 2 * 4 : (size_t)(BM / WR) * (BN + 4) * 4;
+    return sizeof(TC) == 2 ? (size_t)BM * (BN + 8) * 2 + (size_t)WR * WC * BN * 2 * 4 : (size_t)(BM / WR) * (BN + 4) * 4;
 }
 template <int BM, int BN, int WR, int WC, typename TC>
 __device__ __forceinline__ void store_tile_w(const BArgs& a, f32x16 (&acc)[BM / WR / 32][BN / WC / 32], __bf16* smem, int bm, int bn, int bz, int wm, int wn,
@@ -219,7 +279,7 @@ __device__ __forceinline__ void store_tile_w(const BArgs& a, f32x16 (&acc)[BM / 
         constexpr int LDC = BN + 8;
         __bf16* cs = smem;
         __syncthreads();
-        if (a.tile_stats) {
+        if (a.tile_stats && !a.bn_x) {
             float* sbuf = reinterpret_cast<float*>(smem + BM * LDC);           // [WR wave rows][BN][2], behind the staged tile
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -266,6 +326,7 @@ __device__ __forceinline__ void store_tile_w(const BArgs& a, f32x16 (&acc)[BM / 
                 }
         __syncthreads();
         constexpr int VPR = BN / 8;
+        BnAcc<BN, NTH> bacc(a, bn, tid);
 #pragma unroll
         for (int j = 0; j < BM * VPR / NTH; ++j) {
             int v = tid + j * NTH, lr = v / VPR, lc = (v % VPR) * 8;
@@ -280,8 +341,10 @@ __device__ __forceinline__ void store_tile_w(const BArgs& a, f32x16 (&acc)[BM / 
                     for (int e = 0; e < 8; ++e) o[e] = (__bf16)((float)o[e] + (float)old[e]);
                 }
                 *reinterpret_cast<bf16x8*>(dst) = o;
+                bacc.add(a, o, orow * a.ldc + col);
             }
         }
+        bacc.finish(a, reinterpret_cast<float*>(smem + BM * LDC), bm / BM, bn, tid);
         return;
     }
     if ((a.nsplit > 1) ? a.wide_slab : (sizeof(TC) == 4 && a.wide_store)) {

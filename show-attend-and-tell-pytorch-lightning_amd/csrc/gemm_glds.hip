@@ -30,6 +30,10 @@
 #include "gemm_bf16_common.h"
 #include "profile.h"
 
+#ifndef SAT_GLDS_ABLATE
+#define SAT_GLDS_ABLATE 0        // timing ablations, dev builds only (results are garbage): see tools/ablate_gemm.py
+#endif
+
 namespace sat {
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -248,9 +252,9 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_glds_kernel(BArgs a) {
     };
 
     // one LDS-DMA wave-instruction of the next tile: A pieces jj < NA, then B pieces
-    const int abl = a.ablate;          // dev: 1 = no operand loads after the prologue, 2 = no MFMAs, 4 = no fragment reads, 8 = no result stores
+    constexpr int abl = SAT_GLDS_ABLATE;          // dev builds (make ABLATE=bits): 1 = no operand loads, 2 = no MFMAs, 4 = no fragment reads, 8 = no result stores
     auto issue_piece = [&](int buf, int tb, int jj) {
-        if (abl & 1) return;
+        if constexpr (abl & 1) return;
         __bf16* as = smem + buf * STAGE; __bf16* bs = as + A_EL;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
@@ -358,7 +362,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_glds_kernel(BArgs a) {
 #pragma unroll
                     for (int jj = (ks * G) / 4; jj < ((ks + 1) * G) / 4; ++jj) issue_piece(nxt, nxt, jj);          // G pieces spread over the four k-steps
                 }
-                if (!(abl & 2)) {
+                if constexpr (!(abl & 2)) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -383,7 +387,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_glds_kernel(BArgs a) {
             nxt = (nxt + 1 == S) ? 0 : nxt + 1;
         }
     }
-    if (abl & 8) {
+    if constexpr (abl & 8) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -415,7 +419,7 @@ static int rung(const BArgs& k, hipStream_t st) {
     ProfScope prof(pname, 2.0 * k.M * k.N * k.K, 2.0 * k.M * k.K + 2.0 * k.N * k.K + (double)sizeof(TC) * k.M * k.N, st);
     size_t lds = (size_t)k.nstage * (BM + BN) * 64 * sizeof(__bf16);
     // the epilogue stages the result tile in the same memory: bf16 tile (+ statistics) or a wave row of the fp32 tile
-    const size_t epi_lds = (WR == 2 && WC == 2) ? ((sizeof(TC) == 2) ? (size_t)BM * (BN + 8) * 2 + 2 * BN * 2 * 4 : (size_t)(BM / 2) * (BN + 4) * 4)
+    const size_t epi_lds = (WR == 2 && WC == 2) ? ((sizeof(TC) == 2) ? (size_t)BM * (BN + 8) * 2 + 4 * BN * 2 * 4 : (size_t)(BM / 2) * (BN + 4) * 4)
                                                 : store_lds_bytes<BM, BN, WR, WC, TC>();
     if (lds < epi_lds) lds = epi_lds;
     constexpr size_t LDS_DYN_MAX = 160 * 1024 - 2560;       // the whole LDS less the kernel's static part (the weight-gradient pixel tables: 2 KiB)
@@ -451,7 +455,7 @@ static int rung_tiles(const BArgs& k, int tile, hipStream_t st, int* bm_used) {
 }
 
 int& glds_force_tile() { static int v = getenv("SAT_GLDS_TILE") ? atoi(getenv("SAT_GLDS_TILE")) : -1; return v; }
-int& glds_ablate() { static int v = getenv("SAT_GLDS_ABLATE") ? atoi(getenv("SAT_GLDS_ABLATE")) : 0; return v; }
+int& glds_ablate() { static int v = SAT_GLDS_ABLATE; return v; }
 int& glds_stages8() { static int v = getenv("SAT_GLDS_STAGES8") ? atoi(getenv("SAT_GLDS_STAGES8")) : 0; return v; }
 
 // -1: this problem does not fit the direct-to-LDS forms (caller keeps the register-staged kernel)
@@ -472,7 +476,6 @@ int launch_gemm_glds(const BArgs& k0, int amode, int bmode, int c_bf16, int BMt,
     static const int s1_upto = getenv("SAT_GLDS_S1_UPTO") ? atoi(getenv("SAT_GLDS_S1_UPTO")) : 1;
     k.nstage = force_stages ? force_stages : (ktiles >= deep_from ? 4 : ((ktiles == 1 || (c_bf16 && ktiles <= s1_upto)) ? 1 : 2));
     k.rotate = rotate;
-    k.ablate = glds_ablate();
     if (k.nstage < 1) k.nstage = 1;
     if (k.nstage > 4) k.nstage = 4;
     // tile form (the caller's BMt says 64- or 128-wide): 128x64 for the 64-column outputs over many rows (halves the workgroup count

@@ -123,14 +123,31 @@ def conv_fwd_stats(x, w, stride, pad, stride_w=0):
     return y, ((stats, rows.value) if rows.value > 0 else None)
 
 
-def conv_dgrad(dy, w, x_shape, stride, pad, out=None, accumulate=False):
+#: backward BatchNorm statistics from the epilogue of the data-gradient launch that produces the BatchNorm's output gradient
+#: (tests switch it off to compare with the separate statistics pass)
+_BN_BWD_EPILOGUE = os.environ.get("SAT_BN_BWD_EPILOGUE", "1") != "0"
+
+
+def conv_dgrad(dy, w, x_shape, stride, pad, out=None, accumulate=False, bn=None):
+    """``bn`` = (bn_input, (mean, invstd[, relu_mask])) of the BatchNorm(+ReLU) whose OUTPUT is this convolution's input: the launch then
+    also leaves that BatchNorm's backward statistics per row tile (bf16 storage, stride 1) and the call returns (dx, tiles) with
+    tiles = (tile_stats, tile_rows) for ``bn_bwd(..., tiles=tiles)``, or (dx, None) when the launch could not produce them."""
     N, H, W, Cc = x_shape
     K, _, R, S = w.shape
     dx = out if out is not None else torch.empty(N, H, W, Cc, dtype=dy.dtype, device=dy.device)
     g = _geom(N, H, W, Cc, K, R, S, stride, pad)
-    fn = L.lib().sat_conv2d_dgrad_bf16 if _is_bf(dy) else L.lib().sat_conv2d_dgrad
+    lib = L.lib()
+    if bn is not None:
+        bx, st = bn
+        if _BN_BWD_EPILOGUE and _is_bf(dy) and stride == 1 and bx is not None and bx.dtype == BF16 and tuple(bx.shape) == tuple(dx.shape) and bx.is_contiguous():
+            stats = torch.empty(lib.sat_conv2d_dgrad_stats_bytes(C.byref(g)) // 4, dtype=torch.float32, device=dy.device)
+            rows = C.c_int32(0)
+            L.check(lib.sat_conv2d_dgrad_bf16_bnstats(L.ptr(dy), L.ptr(_krsc(w)), L.ptr(dx), C.byref(g), int(accumulate), L.ptr(bx), L.ptr(st[2] if len(st) > 2 else None),
+                                                      L.ptr(st[0]), L.ptr(st[1]), L.ptr(stats), C.byref(rows), L.stream_ptr()), "sat_conv2d_dgrad_bf16_bnstats")
+            return dx, ((stats, rows.value) if rows.value > 0 else None)
+    fn = lib.sat_conv2d_dgrad_bf16 if _is_bf(dy) else lib.sat_conv2d_dgrad
     L.check(fn(L.ptr(dy), L.ptr(_krsc(w)), L.ptr(dx), C.byref(g), int(accumulate), L.stream_ptr()), "sat_conv2d_dgrad")
-    return dx
+    return (dx, None) if bn is not None else dx
 
 
 _slabs = {}
@@ -204,12 +221,18 @@ def bn_fwd(x, bn, residual=None, relu=True, training=True, want_mask=False, tile
     return y, None
 
 
-def bn_bwd(dy, x, y, stats, bn, relu, dres=None, dres_accumulate=False):
+def bn_bwd(dy, x, y, stats, bn, relu, dres=None, dres_accumulate=False, tiles=None):
+    """``tiles``: backward statistics per row tile from the data-gradient launch that wrote ``dy`` (``conv_dgrad(..., bn=...)``)."""
     lib = L.lib()
     Cc = x.shape[-1]; rows = x.numel() // Cc
     dx = torch.empty_like(x)
     dgamma, dbeta = L.grad_buffer(bn.weight), L.grad_buffer(bn.bias)
     scratch = torch.empty(lib.sat_bn_scratch_bytes(rows, Cc) // 8 + 1, dtype=torch.float64, device=x.device)
+    if tiles is not None and _is_bf(x) and (not relu or len(stats) > 2):
+        L.check(lib.sat_bn_train_bwd_tiles_bf16(L.ptr(dy), L.ptr(x), rows, Cc, L.ptr(tiles[0]), int(tiles[1]), L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(bn.weight),
+                                                int(relu), L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dres), int(dres_accumulate),
+                                                L.ptr(stats[2] if len(stats) > 2 else None), L.ptr(scratch), L.stream_ptr()), "sat_bn_train_bwd_tiles_bf16")
+        return dx, dgamma, dbeta
     L.check(lib.sat_bn_train_bwd_t(int(_is_bf(x)), L.ptr(dy), L.ptr(x), L.ptr(y), rows, Cc, L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(bn.weight),
                                    int(relu), L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dres), int(dres_accumulate),
                                    L.ptr(stats[2] if len(stats) > 2 else None), L.ptr(scratch), L.stream_ptr()), "sat_bn_train_bwd")
@@ -296,36 +319,45 @@ def _block_fwd(blk, x, training, W=None):
     return r
 
 
-def _block_bwd(r, dout, grads, need_dx, W=None):
+def _block_bwd(r, dout, grads, need_dx, W=None, dout_tiles=None, prev=None):
+    """Backward of one residual block.  ``dout_tiles``: backward statistics of this block's last BatchNorm that came with ``dout``
+    (produced by the block behind it); ``prev``: the record of the block in front, whose last BatchNorm's statistics the launch that
+    writes this block's input gradient can produce.  Returns (dx, tiles for ``prev``'s last BatchNorm or None)."""
     W = W or (lambda p: p)
     blk = r.blk
     g = torch.empty_like(r.out)                      # gradient of the residual branch (= dout masked by the final ReLU)
     if blk.kind == "basic":
-        dx2, grads[blk.bn2.weight], grads[blk.bn2.bias] = bn_bwd(dout, r.c2, r.out, r.s2, blk.bn2, True, dres=g)
+        dx2, grads[blk.bn2.weight], grads[blk.bn2.bias] = bn_bwd(dout, r.c2, r.out, r.s2, blk.bn2, True, dres=g, tiles=dout_tiles)
         grads[blk.conv2.weight] = conv_wgrad(dx2, r.a1, blk.conv2.weight, 1, 1, param=blk.conv2.weight)
-        da1 = conv_dgrad(dx2, W(blk.conv2.weight), r.a1.shape, 1, 1)
+        da1, t1 = conv_dgrad(dx2, W(blk.conv2.weight), r.a1.shape, 1, 1, bn=(r.c1, r.s1))
         first_w, first_stride, first_pad = blk.conv1.weight, blk.stride, 1
     else:
-        dx3, grads[blk.bn3.weight], grads[blk.bn3.bias] = bn_bwd(dout, r.c3, r.out, r.s3, blk.bn3, True, dres=g)
+        dx3, grads[blk.bn3.weight], grads[blk.bn3.bias] = bn_bwd(dout, r.c3, r.out, r.s3, blk.bn3, True, dres=g, tiles=dout_tiles)
         grads[blk.conv3.weight] = conv_wgrad(dx3, r.a2, blk.conv3.weight, 1, 0, param=blk.conv3.weight)
-        da2 = conv_dgrad(dx3, W(blk.conv3.weight), r.a2.shape, 1, 0)
-        dx2, grads[blk.bn2.weight], grads[blk.bn2.bias] = bn_bwd(da2, r.c2, r.a2, r.s2, blk.bn2, True)
+        da2, t2 = conv_dgrad(dx3, W(blk.conv3.weight), r.a2.shape, 1, 0, bn=(r.c2, r.s2))
+        dx2, grads[blk.bn2.weight], grads[blk.bn2.bias] = bn_bwd(da2, r.c2, r.a2, r.s2, blk.bn2, True, tiles=t2)
         grads[blk.conv2.weight] = conv_wgrad(dx2, r.a1, blk.conv2.weight, blk.stride, 1, param=blk.conv2.weight)
-        da1 = conv_dgrad(dx2, W(blk.conv2.weight), r.a1.shape, blk.stride, 1)
+        da1, t1 = conv_dgrad(dx2, W(blk.conv2.weight), r.a1.shape, blk.stride, 1, bn=(r.c1, r.s1))
         first_w, first_stride, first_pad = blk.conv1.weight, 1, 0
-    dx1, grads[blk.bn1.weight], grads[blk.bn1.bias] = bn_bwd(da1, r.c1, r.a1, r.s1, blk.bn1, True)
+    dx1, grads[blk.bn1.weight], grads[blk.bn1.bias] = bn_bwd(da1, r.c1, r.a1, r.s1, blk.bn1, True, tiles=t1)
     grads[first_w] = conv_wgrad(dx1, r.x, first_w, first_stride, first_pad, param=first_w)
     if blk.downsample is not None:
         dxd, grads[blk.downsample[1].weight], grads[blk.downsample[1].bias] = bn_bwd(g, r.cd, None, r.sd, blk.downsample[1], False)
         grads[blk.downsample[0].weight] = conv_wgrad(dxd, r.x, blk.downsample[0].weight, blk.stride, 0, param=blk.downsample[0].weight)
         if not need_dx:
-            return None
+            return None, None
         dx = conv_dgrad(dx1, W(first_w), r.x.shape, first_stride, first_pad)
         # the strided 1x1 shortcut only reaches the even pixels: accumulate it on top (the other parity classes are skipped)
-        return conv_dgrad(dxd, W(blk.downsample[0].weight), r.x.shape, blk.stride, 0, out=dx, accumulate=True)
+        return conv_dgrad(dxd, W(blk.downsample[0].weight), r.x.shape, blk.stride, 0, out=dx, accumulate=True), None
     if not need_dx:
-        return None
-    return conv_dgrad(dx1, W(first_w), r.x.shape, first_stride, first_pad, out=g, accumulate=True)   # identity path + conv path
+        return None, None
+    # identity path + conv path; the launch that writes the sum also leaves the statistics of the previous block's last BatchNorm
+    pbn = None
+    if prev is not None and prev.out is r.x:
+        pbn = (prev.c3, prev.s3) if prev.kind == "bottleneck" else (prev.c2, prev.s2)
+    if pbn is not None:
+        return conv_dgrad(dx1, W(first_w), r.x.shape, first_stride, first_pad, out=g, accumulate=True, bn=pbn)
+    return conv_dgrad(dx1, W(first_w), r.x.shape, first_stride, first_pad, out=g, accumulate=True), None
 
 
 class EncoderFn(torch.autograd.Function):
@@ -473,8 +505,9 @@ class EncoderFn(torch.autograd.Function):
             bounds, acc = [], 0
             for n in n_per_stage:
                 acc += n; bounds.append(acc)
+            tiles = None
             for idx in range(len(recs) - 1, -1, -1):
-                d = _block_bwd(recs[idx], d, grads, True, Wt)
+                d, tiles = _block_bwd(recs[idx], d, grads, True, Wt, dout_tiles=tiles, prev=(recs[idx - 1] if idx > 0 else None))
                 if cb is not None and idx in (bounds[2], bounds[1], bounds[0]):      # a ResNet stage just finished
                     cb(dict(grads))
             if "a0" not in t:

@@ -213,7 +213,7 @@ def test_residual_block_fwd_bwd(E, kind, cin, planes, stride):
     rec = E._block_fwd(blk, xd, True)
     close(nchw(rec.out), y, 2e-5, "block out")
     grads = {}
-    dx = E._block_bwd(rec, nhwc(dy).cuda(), grads, True)
+    dx, _ = E._block_bwd(rec, nhwc(dy).cuda(), grads, True)
     close(nchw(dx), x.grad, 1e-4, "block dx")
     refp = dict(ref.named_parameters())
     for k, p in blk.named_parameters():
@@ -351,7 +351,7 @@ def test_residual_block_bf16_storage(E, kind, cin, planes, stride):
     l2 = lambda a, b: float((a.detach().float().cpu() - b.detach()).norm() / b.detach().norm())
     assert l2(nchw(rec.out), y) <= 5e-3
     grads = {}
-    dx = E._block_bwd(rec, nhwc(dy).cuda().to(torch.bfloat16), grads, True, Wt)
+    dx, _ = E._block_bwd(rec, nhwc(dy).cuda().to(torch.bfloat16), grads, True, Wt)
     errs = {"dx": l2(nchw(dx), x.grad)}
     refp = dict(ref.named_parameters())
     for k, p in blk.named_parameters():
@@ -401,6 +401,48 @@ def test_whole_encoder_bf16_storage_against_the_rounding_oracle(E, arch, es, px,
                    for k, p in enc.named_parameters()), reverse=True)
     print("bf16 encoder: (HIP vs fp32, emulation vs fp32, HIP vs emulation) worst margins", [(round(a, 4), round(b, 4), round(c, 4), k) for _, a, b, c, k in rows[:4]])
     assert rows[0][0] <= 2e-2, rows[:4]
+
+
+@pytest.mark.parametrize("kind,cin,planes,nb,hw", [("bottleneck", 256, 64, 8, 32), ("bottleneck", 512, 128, 5, 17), ("basic", 64, 64, 6, 24)])
+def test_bn_backward_statistics_from_the_dgrad_epilogue_equal_the_statistics_pass(E, monkeypatch, kind, cin, planes, nb, hw):
+    """bf16 mode: the data-gradient launch that writes a BatchNorm's output gradient also leaves (sum g, sum g * xhat) per row tile
+    (conv_dgrad(..., bn=...)), and bn_bwd(..., tiles=...) skips its statistics pass over dy and x.  Two residual blocks in a row (the second
+    block's input-gradient launch - an accumulating one - produces the first block's last BatchNorm's statistics): every gradient of the fused
+    path against the path with the separate statistics kernel.  Same stored values on both sides, so the only difference is the summation
+    order of the statistics: dgamma / dbeta 1e-5 relative, dx and the filter gradients within bf16 rounding of the changed statistics."""
+    from oracle import sat_oracle as O
+    torch.manual_seed(cin + planes)
+    g = torch.Generator().manual_seed(7 + cin)
+    blocks = [E.Block(kind, cin, planes, 1, 64), E.Block(kind, cin, planes, 1, 64)]
+    for b in blocks:
+        with torch.no_grad():
+            for p in b.parameters():
+                if p.dim() == 1:
+                    p.copy_(torch.rand(p.shape, generator=g) + 0.5)
+        E._channels_last_(b); b.cuda().train()
+    x = torch.randn(nb, hw, hw, cin, generator=g).cuda().to(torch.bfloat16)
+    dy = torch.randn(nb, hw, hw, cin, generator=g).cuda().to(torch.bfloat16)
+    cache = {}
+    Wt = lambda p: cache.setdefault(p, E.cast_bf16(p))              # noqa: E731
+
+    def run(fused):
+        monkeypatch.setattr(E, "_BN_BWD_EPILOGUE", fused)
+        r0 = E._block_fwd(blocks[0], x, True, Wt); r1 = E._block_fwd(blocks[1], r0.out, True, Wt)
+        grads = {}
+        d, tiles = E._block_bwd(r1, dy, grads, True, Wt, dout_tiles=None, prev=r0)
+        assert (tiles is not None) == fused
+        d, t0 = E._block_bwd(r0, d, grads, True, Wt, dout_tiles=tiles, prev=None)
+        assert t0 is None
+        return d.float(), {k: v.float().clone() for k, v in grads.items()}
+
+    dx_a, ga = run(True)
+    dx_b, gb = run(False)
+    names = {p: "%d.%s" % (i, k) for i, b in enumerate(blocks) for k, p in b.named_parameters()}
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))           # noqa: E731
+    for p in ga:
+        tol = 1e-5 if p.dim() == 1 else 2e-3
+        assert rel(ga[p], gb[p]) <= tol, (names[p], rel(ga[p], gb[p]))
+    assert rel(dx_a, dx_b) <= 2e-3, rel(dx_a, dx_b)
 
 
 @pytest.mark.parametrize("N,H,W,C,K,R,stride,pad", [(4, 16, 16, 64, 64, 3, 1, 1), (3, 9, 9, 64, 256, 1, 1, 0), (2, 20, 20, 8, 64, 7, 2, 3),
