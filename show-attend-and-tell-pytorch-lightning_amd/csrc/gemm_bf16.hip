@@ -387,7 +387,7 @@ static int launch_gemm_bf16_tile(const GemmArgs& g, int tile_mode, hipStream_t s
     if (g.tile_stats && g.tile_rows && g.c_bf16 && k.wide_store && !g.accumulate && !g.g.cls && !g.bn_x) { k.tile_stats = g.tile_stats; *g.tile_rows = tbm; }
     // BatchNorm-backward statistics of a data-gradient launch (accumulating launches included: the statistics see the final values)
     if (g.tile_stats && g.tile_rows && g.bn_x && g.bn_mean && g.bn_invstd && g.c_bf16 && k.wide_store && k.nsplit == 1 && !g.g.cls && g.ldc == g.N &&
-        g.epi == EPI_NONE && al16(g.bn_x)) {
+        g.epi == EPI_NONE && al16(g.bn_x) && BMt != 256) {
         k.tile_stats = g.tile_stats; *g.tile_rows = tbm;
         k.bn_x = reinterpret_cast<const __bf16*>(g.bn_x); k.bn_mask = g.bn_mask; k.bn_mean = g.bn_mean; k.bn_invstd = g.bn_invstd;
     }

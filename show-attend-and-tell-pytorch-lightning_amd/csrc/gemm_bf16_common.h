@@ -73,14 +73,17 @@ __device__ __forceinline__ void put(const BArgs& a, int row, int col, float v) {
 // stored (the bf16-rounded, accumulated ones: exactly what the BatchNorm backward will read back), the threads of a column group are
 // combined by wave shuffles and through `sbuf` ([waves][BN][2] floats behind the staged tile) in a fixed order, and the tile's
 // (sum g, sum g * xhat) per column lands in tile_stats[tile][column] like the forward statistics do.
-template <int BN, int NTHR>
+template <int BM, int BN, int NTHR>
 struct BnAcc {
-    static constexpr int VPR = BN / 8, NWV = NTHR / 64;
+    static constexpr int VPR = BN / 8, NWV = NTHR / 64, NJ0 = BM * VPR / NTHR;
+    static constexpr bool BUILT = NJ0 <= 8;          // the 256x256 form (16 segments per thread on top of 128 accumulator registers) is not: the launcher never asks it
+    static constexpr int NJ = BUILT ? NJ0 : 1;
     static_assert(NTHR % VPR == 0 && 64 % VPR == 0, "a thread keeps one column group");
     float s1[8], s2[8], mu[8], is[8];
+    bf16x8 xv[NJ]; unsigned mb[NJ];          // the thread's segments of the BatchNorm input and their sign bits, fetched before the write phase
     bool on;
     __device__ __forceinline__ BnAcc(const BArgs& a, int bn, int tid) {
-        on = a.bn_x != nullptr && a.tile_stats != nullptr;
+        on = BUILT && a.bn_x != nullptr && a.tile_stats != nullptr;
         const int col = bn + (tid % VPR) * 8;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -89,14 +92,24 @@ struct BnAcc {
             mu[e] = ok ? a.bn_mean[col + e] : 0.f; is[e] = ok ? a.bn_invstd[col + e] : 0.f;
         }
     }
-    __device__ __forceinline__ void add(const BArgs& a, const bf16x8& o, long elem) {
+    // issue the loads of every row segment this thread will write (rows past M: nothing to add, sign bits 0)
+    __device__ __forceinline__ void prefetch(const BArgs& a, int bm, int bn, int tid) {
         if (!on) return;
-        const bf16x8 xv = *reinterpret_cast<const bf16x8*>(a.bn_x + elem);
-        const unsigned mb = a.bn_mask ? a.bn_mask[elem >> 3] : 0xFFu;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int v = tid + j * NTHR, row = bm + v / VPR, col = bn + (v % VPR) * 8;
+            const bool ok = row < a.M && col < a.N;
+            const long elem = ok ? (long)row * a.ldc + col : 0;
+            xv[j] = *reinterpret_cast<const bf16x8*>(a.bn_x + elem);
+            mb[j] = ok ? (a.bn_mask ? (unsigned)a.bn_mask[elem >> 3] : 0xFFu) : 0u;
+        }
+    }
+    __device__ __forceinline__ void add(int j, const bf16x8& o) {
+        if (!on || j >= NJ) return;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float g = ((mb >> e) & 1u) ? (float)o[e] : 0.f;
-            s1[e] += g; s2[e] = fmaf(g, ((float)xv[e] - mu[e]) * is[e], s2[e]);
+            const float g = ((mb[j] >> e) & 1u) ? (float)o[e] : 0.f;
+            s1[e] += g; s2[e] = fmaf(g, ((float)xv[j][e] - mu[e]) * is[e], s2[e]);
         }
     }
     __device__ __forceinline__ void finish(const BArgs& a, float* sbuf, int tile, int bn, int tid) {
@@ -136,6 +149,8 @@ __device__ __forceinline__ void store_tile(const BArgs& a, f32x16 (&acc)[BM / 64
         constexpr int LDC = BN + 8;
         static_assert(BM * LDC <= SMEM_ELEMS, "C tile must fit the staging buffers");
         __bf16* cs = smem;
+        BnAcc<BM, BN, NT> bacc(a, bn, tid);
+        bacc.prefetch(a, bm, bn, tid);           // in flight while the tile is staged
         __syncthreads();
         if (a.tile_stats && !a.bn_x) {
             // BatchNorm statistics of the tile while it is still in registers (one HBM pass less for the layer that follows):
@@ -189,7 +204,6 @@ __device__ __forceinline__ void store_tile(const BArgs& a, f32x16 (&acc)[BM / 64
                 }
         __syncthreads();
         constexpr int VPR = BN / 8;
-        BnAcc<BN, NT> bacc(a, bn, tid);
 #pragma unroll
         for (int j = 0; j < BM * VPR / NT; ++j) {
             int v = tid + j * NT, lr = v / VPR, lc = (v % VPR) * 8;
@@ -204,7 +218,7 @@ __device__ __forceinline__ void store_tile(const BArgs& a, f32x16 (&acc)[BM / 64
                     for (int e = 0; e < 8; ++e) o[e] = (__bf16)((float)o[e] + (float)old[e]);
                 }
                 *reinterpret_cast<bf16x8*>(dst) = o;
-                bacc.add(a, o, orow * a.ldc + col);
+                bacc.add(j, o);
             }
         }
         bacc.finish(a, reinterpret_cast<float*>(smem + BM * LDC), bm / BM, bn, tid);
@@ -278,6 +292,8 @@ __device__ __forceinline__ void store_tile_w(const BArgs& a, f32x16 (&acc)[BM / 
     if (sizeof(TC) == 2 && a.wide_store) {
         constexpr int LDC = BN + 8;
         __bf16* cs = smem;
+        BnAcc<BM, BN, NTH> bacc(a, bn, tid);
+        bacc.prefetch(a, bm, bn, tid);           // in flight while the tile is staged
         __syncthreads();
         if (a.tile_stats && !a.bn_x) {
             float* sbuf = reinterpret_cast<float*>(smem + BM * LDC);           // [WR wave rows][BN][2], behind the staged tile
@@ -326,7 +342,6 @@ __device__ __forceinline__ void store_tile_w(const BArgs& a, f32x16 (&acc)[BM / 
                 }
         __syncthreads();
         constexpr int VPR = BN / 8;
-        BnAcc<BN, NTH> bacc(a, bn, tid);
 #pragma unroll
         for (int j = 0; j < BM * VPR / NTH; ++j) {
             int v = tid + j * NTH, lr = v / VPR, lc = (v % VPR) * 8;
@@ -341,7 +356,7 @@ __device__ __forceinline__ void store_tile_w(const BArgs& a, f32x16 (&acc)[BM / 
                     for (int e = 0; e < 8; ++e) o[e] = (__bf16)((float)o[e] + (float)old[e]);
                 }
                 *reinterpret_cast<bf16x8*>(dst) = o;
-                bacc.add(a, o, orow * a.ldc + col);
+                bacc.add(j, o);
             }
         }
         bacc.finish(a, reinterpret_cast<float*>(smem + BM * LDC), bm / BM, bn, tid);
