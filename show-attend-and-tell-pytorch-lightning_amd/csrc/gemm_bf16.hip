@@ -327,8 +327,14 @@ static int launch_gemm_bf16_tile(const GemmArgs& g, int tile_mode, hipStream_t s
 static int pick_wide_tile(const GemmArgs& g) {
     static const int wide = getenv("SAT_WIDE_TILES") ? atoi(getenv("SAT_WIDE_TILES")) : 1;
     if (!wide || !g.a_bf16 || !g.b_bf16 || g.a_rows || g.c_rows || g.K % 64) return 0;
-    if (g.M < 256 || g.N < 128) return 0;
-    return 0;     // (set by measurement below)
+    // measured on the C2 step's convolutions (tools/sweep_tiles.py, resnet50, 128 images):
+    //   weight gradients with >= 256 filters and >= 256 filter columns: 256x256 (-10 .. -22 %; the operand panels are re-read half as often)
+    //   forward 3x3 / 1x1 forms with >= 256 filters over >= 8192 pixels:    256x128 (-4 .. -9 %)
+    //   data gradients: no form wins
+    if (g.amode == A_KMAJOR && !g.c_bf16) return (g.M >= 256 && g.N >= 256 && g.K >= 4096) ? 256 : 0;
+    if ((g.amode == A_CONV_FWD || (g.amode == A_ROW && g.bmode == B_ROW)) && g.c_bf16 && !g.accumulate)
+        return (g.N >= 256 && g.M >= 8192 && (long)cdiv(g.M, 256) * cdiv(g.N, 128) >= 128) ? 257 : 0;
+    return 0;
 }
 
 int launch_gemm_bf16(const GemmArgs& g, hipStream_t st) {
