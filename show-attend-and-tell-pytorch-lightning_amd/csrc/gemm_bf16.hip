@@ -325,7 +325,10 @@ static int launch_gemm_bf16_tile(const GemmArgs& g, int tile_mode, hipStream_t s
 // 8-wave tile forms of gemm_glds.hip (256x256 / 256x128, one workgroup per CU): chosen where they cut the L2 -> LDS operand traffic
 // of the 128x128 form - every operand tile is re-read once per tile of the OTHER dimension - and still fill the chip.
 static int pick_wide_tile(const GemmArgs& g) {
-    static const int wide = getenv("SAT_WIDE_TILES") ? atoi(getenv("SAT_WIDE_TILES")) : 1;
+    // Off by default: the forms win -4 .. -22 % launch by launch on cold caches (tools/sweep_tiles.py) but the whole C2 step does not
+    // get faster with them (25.1 vs 25.0 ms, bench.py A/B on one box): inside the step the operands of these launches are L2 / MALL
+    // resident from their producers and the 128x128 form's two workgroups per CU overlap better.  SAT_WIDE_TILES=1 turns them on.
+    static const int wide = getenv("SAT_WIDE_TILES") ? atoi(getenv("SAT_WIDE_TILES")) : 0;
     if (!wide || !g.a_bf16 || !g.b_bf16 || g.a_rows || g.c_rows || g.K % 64) return 0;
     // measured on the C2 step's convolutions (tools/sweep_tiles.py, resnet50, 128 images):
     //   weight gradients with >= 256 filters and >= 256 filter columns: 256x256 (-10 .. -22 %; the operand panels are re-read half as often)
