@@ -886,6 +886,7 @@ int sat_conv2d_dgrad_bf16_bnstats(const void* dy, const void* w, void* dx, const
 static int conv_wgrad_any(const void* dy, const void* x, float* dw, const sat_conv_geom* geom, float* slab, int64_t slab_elems, int bf16, void* stream) {
     ConvGeom g; SAT_TRY(conv_geom(geom, g, bf16 ? 8 : 4));
     if (!dy || !x || !dw) return fail(SAT_EINVAL, "conv2d_wgrad: null pointer");
+    if (bf16 && wgrad3x3_eligible(g)) return launch_wgrad3x3(dy, x, dw, g, slab, (long)slab_elems, (hipStream_t)stream);      // all nine taps per workgroup (wgrad3x3.hip)
     GemmArgs a; a.a_bf16 = a.b_bf16 = a.bf16_mfma = bf16; a.c_bf16 = 0;
     a.M = g.K; a.N = g.R * g.S * g.C; a.K = g.N * g.P * g.Q;
     a.A = dy; a.lda = g.K; a.amode = A_KMAJOR; a.C = dw; a.ldc = a.N; a.g = g; a.slab = slab; a.slab_elems = slab_elems;

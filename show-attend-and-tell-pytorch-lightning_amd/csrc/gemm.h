@@ -65,6 +65,9 @@ struct GemmArgs {
 int launch_gemm(const GemmArgs& a, hipStream_t stream);
 int launch_gemm_bf16(const GemmArgs& a, hipStream_t stream);
 int gemm_bf16_eligible(const GemmArgs& a);
+// wgrad3x3.hip: weight gradient of a 3x3 / stride 1 / pad 1 convolution with all nine taps per workgroup (bf16 activations, fp32 result)
+int wgrad3x3_eligible(const ConvGeom& g);
+int launch_wgrad3x3(const void* dy, const void* x, float* dw, const ConvGeom& g, float* slab, long slab_elems, hipStream_t st);
 // Bytes of split-K scratch that lets launch_gemm fill the chip for this shape (0 = none needed).
 size_t gemm_slab_bytes(int M, int N, int K);
 
