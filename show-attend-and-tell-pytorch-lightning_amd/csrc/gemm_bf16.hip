@@ -280,12 +280,7 @@ static int runb(const BArgs& k, hipStream_t st) {
     ProfScope prof(pname, 2.0 * k.M * k.N * k.K, (double)sizeof(TA) * k.M * k.K + (double)sizeof(TB) * k.N * k.K + (double)sizeof(TC) * k.M * k.N, st);
     hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, KB, AM, BMo, TA, TB, TC>), grid, dim3(NT), 0, st, k);
     SAT_TRY(launch_ok("gemm_bf16_kernel"));
-    if (k.nsplit > 1) {
-        long total = (long)k.M * k.N;
-        if (k.wide_slab) hipLaunchKernelGGL(splitk_reduce_b4_kernel<TC>, dim3(cdiv(total / 4, 256)), dim3(256), 0, st, k);
-        else hipLaunchKernelGGL(splitk_reduce_b_kernel<TC>, dim3(cdiv(total, 256)), dim3(256), 0, st, k);
-        SAT_TRY(launch_ok("splitk_reduce_b"));
-    }
+    if (k.nsplit > 1) SAT_TRY(launch_splitk_reduce<TC>(k, st));
     return SAT_OK;
 }
 

@@ -1,6 +1,8 @@
 // Shared pieces of the bf16-MFMA GEMM kernels (gemm_bf16.hip: register-staged operands; gemm_glds.hip: operands
 // copied HBM -> LDS by the load unit): argument block, epilogue functions, accumulator write-out.
 #pragma once
+#include <stdlib.h>
+
 #include "gemm.h"
 
 namespace sat {
@@ -442,6 +444,49 @@ __global__ void splitk_reduce_b4_kernel(BArgs a) {
     } else {
         put<TC>(a, row, col, v.x); put<TC>(a, row, col + 1, v.y); put<TC>(a, row, col + 2, v.z); put<TC>(a, row, col + 3, v.w);
     }
+}
+
+// Many splits into a small result (the stage-1 weight gradients: 100 - 250 slabs of 16 K elements): the loop above leaves a few
+// dozen workgroups walking the slabs one after the other.  Here 16 lanes share a 16-byte output vector: lane l adds slabs l, l + 16,
+// ... (in that order), the 16 partial sums are combined in lane order through LDS.  Fixed order, so still deterministic.
+template <typename TC>
+__global__ __launch_bounds__(256) void splitk_reduce_z16_kernel(BArgs a) {
+    __shared__ float4 part[16][16];
+    const int ev = threadIdx.x & 15, zl = threadIdx.x >> 4;
+    const long idx4 = (long)blockIdx.x * 16 + ev;
+    const long total4 = (long)a.M * a.N / 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (idx4 < total4) {
+        const float4* s4 = reinterpret_cast<const float4*>(a.slab);
+#pragma unroll 4
+        for (int z = zl; z < a.nsplit; z += 16) { const float4 t = s4[(long)z * total4 + idx4]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+    }
+    part[zl][ev] = v;
+    __syncthreads();
+    if (zl != 0 || idx4 >= total4) return;
+#pragma unroll
+    for (int l = 1; l < 16; ++l) { const float4 t = part[l][ev]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+    const long e = idx4 * 4; const int row = (int)(e / a.N), col = (int)(e % a.N);
+    if (sizeof(TC) == 4 && a.wide_store && !a.g.cls) {
+        float* dst = reinterpret_cast<float*>(a.C) + (long)row * a.ldc + col;
+        if (a.accumulate) { const float4 old = *reinterpret_cast<const float4*>(dst); v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w; }
+        if (a.epi != EPI_NONE) { v.x = ep_value(a, row, col, v.x); v.y = ep_value(a, row, col + 1, v.y); v.z = ep_value(a, row, col + 2, v.z); v.w = ep_value(a, row, col + 3, v.w); }
+        *reinterpret_cast<float4*>(dst) = v;
+    } else {
+        put<TC>(a, row, col, v.x); put<TC>(a, row, col + 1, v.y); put<TC>(a, row, col + 2, v.z); put<TC>(a, row, col + 3, v.w);
+    }
+}
+
+// the reduction launch after a split-K GEMM
+template <typename TC>
+inline int launch_splitk_reduce(const BArgs& k, hipStream_t st) {
+    const long total = (long)k.M * k.N;
+    static const int z16 = getenv("SAT_REDUCE_Z16") ? atoi(getenv("SAT_REDUCE_Z16")) : 1;
+    if (k.wide_slab && z16 && k.nsplit >= 32 && total / 4 / 256 < 256)
+        hipLaunchKernelGGL(splitk_reduce_z16_kernel<TC>, dim3(cdiv(total / 4, 16)), dim3(256), 0, st, k);
+    else if (k.wide_slab) hipLaunchKernelGGL(splitk_reduce_b4_kernel<TC>, dim3(cdiv(total / 4, 256)), dim3(256), 0, st, k);
+    else hipLaunchKernelGGL(splitk_reduce_b_kernel<TC>, dim3(cdiv(total, 256)), dim3(256), 0, st, k);
+    return launch_ok("splitk_reduce_b");
 }
 
 // XCD-aware tile order: the dispatcher deals workgroups round-robin over the 8 XCDs (each with its own L2), so

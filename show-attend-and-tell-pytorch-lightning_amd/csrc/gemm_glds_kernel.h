@@ -433,12 +433,7 @@ static int rung(const BArgs& k, hipStream_t st) {
     }
     hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WR, WC, AM, BMo, TC>), grid, dim3(64 * WR * WC), lds, st, k);
     SAT_TRY(launch_ok("gemm_glds_kernel"));
-    if (k.nsplit > 1) {
-        long total = (long)k.M * k.N;
-        if (k.wide_slab) hipLaunchKernelGGL(splitk_reduce_b4_kernel<TC>, dim3(cdiv(total / 4, 256)), dim3(256), 0, st, k);
-        else hipLaunchKernelGGL(splitk_reduce_b_kernel<TC>, dim3(cdiv(total, 256)), dim3(256), 0, st, k);
-        SAT_TRY(launch_ok("splitk_reduce_b"));
-    }
+    if (k.nsplit > 1) SAT_TRY(launch_splitk_reduce<TC>(k, st));
     return SAT_OK;
 }
 

@@ -28,6 +28,7 @@ namespace {
 constexpr int W3_OOB = (int)0x80000000;
 constexpr int W3_WAVES = 9, W3_THREADS = 64 * W3_WAVES;
 constexpr int W3_MAXP = 4;          // LDS-DMA instructions per wave and k-tile, at most (33 pieces / 9 waves)
+constexpr int W3_STAGES = 3;        // LDS ring: two k-tiles in flight under the one being multiplied (128 VGPRs: one 9-wave workgroup per CU)
 
 __device__ __forceinline__ i32x4 w3_rsrc(const void* base) {
     const unsigned long long b = reinterpret_cast<unsigned long long>(base);
@@ -48,7 +49,7 @@ struct W3Args {
 };
 
 __global__ __launch_bounds__(W3_THREADS) void wgrad3x3_kernel(W3Args a) {
-    extern __shared__ __attribute__((aligned(1024))) __bf16 smem[];      // 2 stages x (dy tile 64 x 64 | halo HP x 64)
+    extern __shared__ __attribute__((aligned(1024))) __bf16 smem[];      // W3_STAGES x (dy tile 64 x 64 | halo HP x 64)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64, bz = blockIdx.z;
     const int W = a.W, H = a.H, C = a.C, K = a.K, nr = a.nr, HW2 = W + 2;
@@ -130,15 +131,26 @@ __global__ __launch_bounds__(W3_THREADS) void wgrad3x3_kernel(W3Args a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    int mine = 0;                                      // LDS-DMA instructions this wave issues per k-tile (3 or 4: wave-uniform)
+#pragma unroll
+    for (int j = 0; j < W3_MAXP; ++j) mine += p_on[j] ? 1 : 0;
+    mine = __builtin_amdgcn_readfirstlane(mine);
     if (u0 < u1) {
         issue(0, u0);
-        int cur = 0;
+        if (u0 + 1 < u1) issue(1, u0 + 1);
+        int cur = 0, nxt = 2;
         for (int u = u0; u < u1; ++u) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // tile u has landed when at most the pieces of tile u + 1 are still outstanding (counted wait: the newer tile stays in flight)
+            if (u + 1 < u1) {
+                if (mine == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else if (mine == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else if (mine == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (u + 1 < u1) issue(cur ^ 1, u + 1);    // every wave has finished reading that stage (it passed the barrier)
+            if (u + 2 < u1) issue(nxt, u + 2);        // the stage of tile u - 1: every wave has finished reading it (it passed the barrier)
             const __bf16* st = smem + cur * STAGE;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -161,7 +173,8 @@ __global__ __launch_bounds__(W3_THREADS) void wgrad3x3_kernel(W3Args a) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
             }
-            cur ^= 1;
+            cur = (cur + 1 == W3_STAGES) ? 0 : cur + 1;
+            nxt = (nxt + 1 == W3_STAGES) ? 0 : nxt + 1;
         }
     }
     // ---- write-out: dW[filter][tap][channel] (KRSC) or this split's slab; C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
@@ -203,16 +216,16 @@ int launch_wgrad3x3(const void* dy, const void* x, float* dw, const ConvGeom& g,
     SAT_REQUIRE(8 + a.HP / 8 <= W3_WAVES * W3_MAXP, "wgrad3x3: %d LDS-DMA pieces per k-tile", 8 + a.HP / 8);
     const long tiles = (long)(g.C / 64) * (g.K / 64), out_elems = (long)g.K * 9 * g.C;
     // pixel splits: about two workgroups per CU, at least 8 k-tiles each, partial slabs within the caller's scratch
-    static const int target = getenv("SAT_W3_TARGET") ? atoi(getenv("SAT_W3_TARGET")) : 512;
+    static const int target = getenv("SAT_W3_TARGET") ? atoi(getenv("SAT_W3_TARGET")) : 256;      // one 9-wave workgroup per CU
     long z = target / tiles; if (z < 1) z = 1;
     if (z > a.units / 8) z = a.units / 8 > 0 ? a.units / 8 : 1;
     while (z > 1 && (!slab || z * out_elems > slab_elems)) --z;
     a.per = (int)cdiv(a.units, z); a.Z = (int)cdiv(a.units, a.per);
     a.out = a.Z > 1 ? slab : dw;
-    const size_t lds = 2 * (size_t)(64 * 64 + a.HP * 64) * sizeof(__bf16);
+    const size_t lds = W3_STAGES * (size_t)(64 * 64 + a.HP * 64) * sizeof(__bf16);
     static bool attr_set = false;
     if (!attr_set) {
-        SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr_set = true;
     }
     {
@@ -228,8 +241,7 @@ int launch_wgrad3x3(const void* dy, const void* x, float* dw, const ConvGeom& g,
         if (a.Z > 1) {
             BArgs k{};
             k.M = g.K; k.N = 9 * g.C; k.C = dw; k.ldc = 9 * g.C; k.slab = slab; k.nsplit = a.Z; k.wide_store = 1; k.wide_slab = 1; k.epi = EPI_NONE;
-            hipLaunchKernelGGL(splitk_reduce_b4_kernel<float>, dim3(cdiv(out_elems / 4, 256)), dim3(256), 0, st, k);
-            SAT_TRY(launch_ok("splitk_reduce_b (wgrad3x3)"));
+            SAT_TRY(launch_splitk_reduce<float>(k, st));
         }
     }
     return SAT_OK;
