@@ -445,7 +445,7 @@ def test_bn_backward_statistics_from_the_dgrad_epilogue_equal_the_statistics_pas
     names = {p: "%d.%s" % (i, k) for i, b in enumerate(blocks) for k, p in b.named_parameters()}
     rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))           # noqa: E731
     for p in ga:
-        tol = 1e-4 if p.dim() == 1 else 2e-3
+        tol = 5e-4 if p.dim() == 1 else 2e-3        # (the first BatchNorms of the chain also see dx values whose bf16 rounding flipped)
         assert rel(ga[p], gb[p]) <= tol, (names[p], rel(ga[p], gb[p]))
     assert rel(dx_a, dx_b) <= 2e-3, rel(dx_a, dx_b)
 
