@@ -287,8 +287,8 @@ def main():
     if os.environ.get("SAT_BENCH_NO_INREGION") == "1":       # dev: A/B the cost of the in-region event pairs
         dom_name = None
     # an event pair costs the command processor ~2 us; the contraction core has ~280 launches per step, so it is instrumented on
-    # every INSTR_EVERY-th timed step only (all of its launches of that step): the other families have <= 52 launches per step
-    instr_every = 4 if dom_name == "gemm_*" else 1
+    # every 10th timed step only (all of its launches of that step): the other families have <= 52 launches per step
+    instr_every = 10 if dom_name == "gemm_*" else 1
     instr_steps = 0
     if dom_name:
         _lib.profile_start(only=dom_name)
