@@ -253,7 +253,8 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(BArgs a) {
         }
     }
 
-    store_tile<BM, BN, TC, 2 * STAGE>(a, acc, smem, bm, bn, bz, wm, wn, tid, lane);
+    BnAcc<BM, BN, NT> bnacc(a, bn, tid);
+    store_tile<BM, BN, TC, 2 * STAGE>(a, acc, smem, bm, bn, bz, wm, wn, tid, lane, bnacc, false);
 }
 
 static const char* mname(int am, int bm) {

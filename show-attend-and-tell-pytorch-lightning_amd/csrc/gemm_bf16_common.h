@@ -142,7 +142,7 @@ struct BnAcc {
 // `smem` is the kernel's operand staging area (free once the k loop is over), `smem_elems` its size in bf16.
 template <int BM, int BN, typename TC, int SMEM_ELEMS>
 __device__ __forceinline__ void store_tile(const BArgs& a, f32x16 (&acc)[BM / 64][BN / 64], __bf16* smem, int bm, int bn, int bz, int wm, int wn,
-                                           int tid, int lane) {
+                                           int tid, int lane, BnAcc<BM, BN, NT>& bacc, bool prefetched /* statistics operands fetched by the caller already */) {
     constexpr int TM = BM / 64, TN = BN / 64;
     const int li = lane & 31, lh = lane >> 5;
     if (sizeof(TC) == 2 && a.wide_store) {
@@ -151,8 +151,7 @@ __device__ __forceinline__ void store_tile(const BArgs& a, f32x16 (&acc)[BM / 64
         constexpr int LDC = BN + 8;
         static_assert(BM * LDC <= SMEM_ELEMS, "C tile must fit the staging buffers");
         __bf16* cs = smem;
-        BnAcc<BM, BN, NT> bacc(a, bn, tid);
-        bacc.prefetch(a, bm, bn, tid);           // in flight while the tile is staged
+        if (!prefetched) bacc.prefetch(a, bm, bn, tid);           // in flight while the tile is staged
         __syncthreads();
         if (a.tile_stats && !a.bn_x) {
             // BatchNorm statistics of the tile while it is still in registers (one HBM pass less for the layer that follows):
@@ -288,14 +287,13 @@ template <int BM, int BN, int WR, int WC, typename TC> constexpr size_t store_ld
 }
 template <int BM, int BN, int WR, int WC, typename TC>
 __device__ __forceinline__ void store_tile_w(const BArgs& a, f32x16 (&acc)[BM / WR / 32][BN / WC / 32], __bf16* smem, int bm, int bn, int bz, int wm, int wn,
-                                             int wrow, int tid, int lane) {
+                                             int wrow, int tid, int lane, BnAcc<BM, BN, 64 * WR * WC>& bacc, bool prefetched) {
     constexpr int TM = BM / WR / 32, TN = BN / WC / 32, NTH = 64 * WR * WC;
     const int li = lane & 31, lh = lane >> 5;
     if (sizeof(TC) == 2 && a.wide_store) {
         constexpr int LDC = BN + 8;
         __bf16* cs = smem;
-        BnAcc<BM, BN, NTH> bacc(a, bn, tid);
-        bacc.prefetch(a, bm, bn, tid);           // in flight while the tile is staged
+        if (!prefetched) bacc.prefetch(a, bm, bn, tid);           // in flight while the tile is staged
         __syncthreads();
         if (a.tile_stats && !a.bn_x) {
             float* sbuf = reinterpret_cast<float*>(smem + BM * LDC);           // [WR wave rows][BN][2], behind the staged tile
