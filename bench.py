@@ -367,7 +367,7 @@ def main():
                     "step_mfma_frac": round(step_tflop / (ms * 1e-3) / peak, 4)}
             meta = [r for r in pmc_rows if r["family"] == "__meta__"]
             if meta:
-                gb = sum(r["hbm_bytes_per_launch"] * r["launches"] for r in pmc_rows if r["family"] != "__meta__") / meta[0]["steps"] / 1e9
+                gb = meta[0]["hbm_gb_per_step"]
                 roof["step_hbm_gb"] = round(gb, 2)
                 roof["step_hbm_frac"] = round(gb / (ms * 1e-3) / PEAK_HBM_GBS, 4)
         line = {"metric": "captions/sec (train step) at B=128, 256px, seq_len=22", "value": round(caps_per_s, 1), "unit": "captions/s",

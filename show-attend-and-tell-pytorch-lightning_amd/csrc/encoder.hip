@@ -274,6 +274,61 @@ __global__ __launch_bounds__(256) void bn_tile_reduce_kernel(const float* __rest
     }
 }
 
+// The same reduction with the finalize step folded in: every block publishes its partial (agent-scope release), draws a ticket per
+// channel group, and the block that draws the last ticket of its group reads all partials back (agent-scope acquire) and finishes - in
+// a FIXED order that does not depend on which block came last, so results stay bit-reproducible.  Saves the separate finalize launch
+// (5 - 9 us of dependent-launch latency each, ~80 of them per C2 step).  `cnt`: one zeroed int per channel group; the last block re-arms it.
+//   mode 0 (forward) : mean / invstd (+ running statistics)   mode 1 (backward): dbeta = sum g, dgamma = sum g * xhat
+__global__ __launch_bounds__(256) void bn_tile_reduce_finish_kernel(const float* __restrict__ tiles, int ntiles, int C, int tiles_per, double* __restrict__ part0,
+                                                                    double* __restrict__ part1, int* __restrict__ cnt, int mode, long rows, float eps, float momentum,
+                                                                    float* __restrict__ out0, float* __restrict__ out1, float* __restrict__ running_mean,
+                                                                    float* __restrict__ running_var) {
+    __shared__ double sh[2][8][32];
+    __shared__ int s_last;
+    const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
+    const int t0 = blockIdx.y * tiles_per, t1 = min(ntiles, t0 + tiles_per);
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int t = t0 + pl; t < t1; t += 8) { const float2 v = reinterpret_cast<const float2*>(tiles)[(long)t * C + c]; s += (double)v.x; q += (double)v.y; }
+    sh[0][pl][cl] = s; sh[1][pl][cl] = q;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+        double ss = 0.0, qq = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { ss += sh[0][k][cl]; qq += sh[1][k][cl]; }
+        part0[(long)blockIdx.y * C + c] = ss; part1[(long)blockIdx.y * C + c] = qq;
+    }
+    __threadfence();                                   // release: this block's partials are visible device-wide before its ticket
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(&cnt[blockIdx.x], 1) == (int)gridDim.y - 1);
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();                                   // acquire: the other blocks' partials
+    if (threadIdx.x == 0) cnt[blockIdx.x] = 0;         // re-armed for the next launch on this scratch
+    const int np = gridDim.y;
+    s = 0.0; q = 0.0;
+    if (c < C)
+        for (int p = pl; p < np; p += 8) { s += __builtin_nontemporal_load(&part0[(long)p * C + c]); q += __builtin_nontemporal_load(&part1[(long)p * C + c]); }
+    __syncthreads();
+    sh[0][pl][cl] = s; sh[1][pl][cl] = q;
+    __syncthreads();
+    if (pl != 0 || c >= C) return;
+    double ss = 0.0, qq = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { ss += sh[0][k][cl]; qq += sh[1][k][cl]; }
+    if (mode == 1) { out0[c] = (float)ss; out1[c] = (float)qq; return; }      // dbeta, dgamma
+    const double n = (double)rows;
+    double var = (qq - ss * ss / n) / n; if (var < 0.0) var = 0.0;
+    const double mu = ss / n;
+    out0[c] = (float)mu;
+    out1[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unb = rows > 1 ? var * n / (n - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+
 // Finalise: one 64-lane wave per channel sums the partials (lane-strided, then a fixed xor tree).
 // forward : mean / biased variance -> invstd, running stats (momentum, unbiased variance) as nn.BatchNorm2d
 __device__ __forceinline__ double wave_sum_d(double v) {
@@ -946,7 +1001,7 @@ extern "C" size_t sat_bn_scratch_bytes(int64_t rows, int32_t C) {
         if (nparts > np) np = nparts;
         if (C % 8 == 0) { bn_grid(rows, C, 8, CV, rp, nparts, bwd); if (nparts > np) np = nparts; }
     }
-    return (size_t)np * C * 2 * sizeof(double) + 64;
+    return (size_t)np * C * 2 * sizeof(double) + 64 + ((size_t)cdiv(C, 32) * sizeof(int) + 63) / 64 * 64;      // partials + one ticket per 32 channels
 }
 
 template <typename T>
@@ -979,6 +1034,19 @@ static int bn_train_fwd_t(const T* x, int64_t rows, int32_t C, const float* gamm
         int np = cdiv(ntiles, 64); if (np > nparts) np = nparts; if (np < 1) np = 1;          // partials fit the scratch sized for nparts
         const int per = cdiv(ntiles, np); np = cdiv(ntiles, per);
         p1 = p0 + (long)np * C;
+        static const int fin = getenv("SAT_BN_TICKET") ? atoi(getenv("SAT_BN_TICKET")) : 1;
+        if (fin) {          // reduce + finalize in one launch (the last block of a channel group finishes)
+            int* cnt = reinterpret_cast<int*>(p0 + (long)nparts * C * 2 + 8);
+            SAT_CHECK_HIP(hipMemsetAsync(cnt, 0, (size_t)cdiv(C, 32) * sizeof(int), st));
+            hipLaunchKernelGGL(bn_tile_reduce_finish_kernel, dim3(cdiv(C, 32), np), dim3(256), 0, st, tile_stats, ntiles, C, per, p0, p1, cnt, 0, (long)rows, eps, momentum,
+                               save_mean, save_invstd, running_mean, running_var);
+            SAT_TRY(launch_ok("bn_tile_reduce_finish"));
+            if (!y) return SAT_OK;
+            long totalv = rows * (C / E);
+            ProfScope prof("bn_apply_fwd", 0.0, (double)rows * C * (sizeof(T) * (residual ? 3 : 2) + (relu_mask ? 0.125 : 0.0)), st);
+            hipLaunchKernelGGL((bn_apply_kernel<T, false>), dim3(cdiv(totalv, 256)), dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta, residual, relu, y, relu_mask, totalv, C / E, -1.0f);
+            return launch_ok("bn_apply");
+        }
         hipLaunchKernelGGL(bn_tile_reduce_kernel, dim3(cdiv(C, 32), np), dim3(256), 0, st, tile_stats, ntiles, C, per, p0, p1);
         SAT_TRY(launch_ok("bn_tile_reduce"));
         nparts = np; shift_src = nullptr;
@@ -1021,14 +1089,25 @@ static int bn_train_bwd_t(const T* dy, const T* x, const T* y, int64_t rows, int
     SAT_REQUIRE(C % E == 0, "bn_train_bwd: C=%d must be a multiple of %d for this storage type", C, E);
     int CV, nparts; long rp; bn_grid(rows, C, E, CV, rp, nparts, 1);
     double* p0 = reinterpret_cast<double*>(scratch); double* p1 = p0 + (long)nparts * C;
+    bool tiles_done = false;
     if (tile_stats) {        // (sum g, sum g * xhat) per row tile came out of the epilogue of the data-gradient launch that wrote dy: no pass over dy / x
         SAT_REQUIRE(tile_rows > 0, "bn_train_bwd: tile_rows=%d", tile_rows);
         const int ntiles = (int)cdiv(rows, (long)tile_rows);
         int np = cdiv(ntiles, 64); if (np > nparts) np = nparts; if (np < 1) np = 1;
         const int per = cdiv(ntiles, np); np = cdiv(ntiles, per);
         p1 = p0 + (long)np * C;
-        hipLaunchKernelGGL(bn_tile_reduce_kernel, dim3(cdiv(C, 32), np), dim3(256), 0, st, tile_stats, ntiles, C, per, p0, p1);
-        SAT_TRY(launch_ok("bn_tile_reduce (backward)"));
+        static const int fin = getenv("SAT_BN_TICKET") ? atoi(getenv("SAT_BN_TICKET")) : 1;
+        if (fin) {
+            int* cnt = reinterpret_cast<int*>(p0 + (long)nparts * C * 2 + 8);
+            SAT_CHECK_HIP(hipMemsetAsync(cnt, 0, (size_t)cdiv(C, 32) * sizeof(int), st));
+            hipLaunchKernelGGL(bn_tile_reduce_finish_kernel, dim3(cdiv(C, 32), np), dim3(256), 0, st, tile_stats, ntiles, C, per, p0, p1, cnt, 1, (long)rows, 0.f, 0.f,
+                               dbeta, dgamma, (float*)nullptr, (float*)nullptr);
+            SAT_TRY(launch_ok("bn_tile_reduce_finish (backward)"));
+            tiles_done = true;
+        } else {
+            hipLaunchKernelGGL(bn_tile_reduce_kernel, dim3(cdiv(C, 32), np), dim3(256), 0, st, tile_stats, ntiles, C, per, p0, p1);
+            SAT_TRY(launch_ok("bn_tile_reduce (backward)"));
+        }
         nparts = np;
     } else {
         ProfScope prof("bn_stats_bwd", 0.0, (double)rows * C * (sizeof(T) * 2 + (relu ? (relu_mask ? 0.125 : (double)sizeof(T)) : 0.0)), st);
@@ -1036,8 +1115,10 @@ static int bn_train_bwd_t(const T* dy, const T* x, const T* y, int64_t rows, int
         hipLaunchKernelGGL((bn_colstats_kernel<1, T>), dim3(cdiv(C / E, CV), nparts), dim3(256), 0, st, x, dy, y, relu_mask, save_mean, save_invstd, relu, (long)rows, C, CV, inter ? -1L : rp, p0, p1);
         SAT_TRY(launch_ok("bn_colstats<1>"));
     }
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, p0, p1, nparts, C, dbeta, dgamma);
-    SAT_TRY(launch_ok("bn_bwd_finalize"));
+    if (!tiles_done) {
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, p0, p1, nparts, C, dbeta, dgamma);
+        SAT_TRY(launch_ok("bn_bwd_finalize"));
+    }
     long totalv = rows * (C / E);
     ProfScope prof("bn_apply_bwd", 0.0, (double)rows * C * (sizeof(T) * (3 + (dres ? (dres_accumulate ? 2 : 1) : 0)) + (relu ? (relu_mask ? 0.125 : (double)sizeof(T)) : 0.0)), st);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(cdiv(totalv, 256)), dim3(256), 0, st, x, dy, y, relu_mask, save_mean, save_invstd, gamma, dbeta, dgamma, relu,
