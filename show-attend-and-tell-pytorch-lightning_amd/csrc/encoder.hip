@@ -274,8 +274,8 @@ __global__ __launch_bounds__(256) void bn_tile_reduce_kernel(const float* __rest
     }
 }
 
-// The same reduction with the finalize step folded in: every block publishes its partial (agent-scope release), draws a ticket per
-// channel group, and the block that draws the last ticket of its group reads all partials back (agent-scope acquire) and finishes - in
+// The same reduction with the finalize step folded in: every block publishes its partial (write-through stores, drained), draws a ticket per
+// channel group, and the block that draws the last ticket of its group reads all partials back (L1-bypassing loads) and finishes - in
 // a FIXED order that does not depend on which block came last, so results stay bit-reproducible.  Saves the separate finalize launch
 // (5 - 9 us of dependent-launch latency each, ~80 of them per C2 step).  `cnt`: one zeroed int per channel group; the last block re-arms it.
 //   mode 0 (forward) : mean / invstd (+ running statistics)   mode 1 (backward): dbeta = sum g, dgamma = sum g * xhat
@@ -296,19 +296,26 @@ __global__ __launch_bounds__(256) void bn_tile_reduce_finish_kernel(const float*
         double ss = 0.0, qq = 0.0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) { ss += sh[0][k][cl]; qq += sh[1][k][cl]; }
-        part0[(long)blockIdx.y * C + c] = ss; part1[(long)blockIdx.y * C + c] = qq;
+        // published write-through (agent-scope relaxed stores = sc1): no release fence, which on this chip writes back the whole L2
+        // (the first version with __threadfence() cost more than the launch it saved)
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(&part0[(long)blockIdx.y * C + c]), (unsigned long long)__double_as_longlong(ss), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(&part1[(long)blockIdx.y * C + c]), (unsigned long long)__double_as_longlong(qq), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     }
-    __threadfence();                                   // release: this block's partials are visible device-wide before its ticket
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores before the block's ticket
     __syncthreads();
-    if (threadIdx.x == 0) s_last = (atomicAdd(&cnt[blockIdx.x], 1) == (int)gridDim.y - 1);
+    if (threadIdx.x == 0) s_last = (__hip_atomic_fetch_add(&cnt[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.y - 1);
     __syncthreads();
     if (!s_last) return;
-    __threadfence();                                   // acquire: the other blocks' partials
-    if (threadIdx.x == 0) cnt[blockIdx.x] = 0;         // re-armed for the next launch on this scratch
+    if (threadIdx.x == 0) __hip_atomic_store(&cnt[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);         // re-armed for the next launch on this scratch
     const int np = gridDim.y;
     s = 0.0; q = 0.0;
     if (c < C)
-        for (int p = pl; p < np; p += 8) { s += __builtin_nontemporal_load(&part0[(long)p * C + c]); q += __builtin_nontemporal_load(&part1[(long)p * C + c]); }
+        for (int p = pl; p < np; p += 8) {           // agent-scope loads (sc1) bypass this CU's L1: every one of them
+            s += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&part0[(long)p * C + c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            q += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&part1[(long)p * C + c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
     __syncthreads();
     sh[0][pl][cl] = s; sh[1][pl][cl] = q;
     __syncthreads();
