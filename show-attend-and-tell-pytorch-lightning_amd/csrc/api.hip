@@ -8,6 +8,11 @@
 
 namespace sat {
 static thread_local char g_err[512] = {0};
+int& dev_switch(int which) {
+    static int v[SW_COUNT] = {getenv("SAT_BN_TICKET") ? atoi(getenv("SAT_BN_TICKET")) : 1, getenv("SAT_NO_WGRAD3X3") ? !atoi(getenv("SAT_NO_WGRAD3X3")) : 1,
+                              getenv("SAT_REDUCE_Z16") ? atoi(getenv("SAT_REDUCE_Z16")) : 1, getenv("SAT_WIDE_TILES") ? atoi(getenv("SAT_WIDE_TILES")) : 0};
+    return v[which];
+}
 int& trace_launches() { static int on = getenv("SAT_TRACE_LAUNCH") ? 1 : 0; return on; }
 char* last_error_buf() { return g_err; }
 int fail(int code, const char* fmt, ...) {
@@ -24,6 +29,10 @@ int sat_abi_version(void) { return SAT_HIP_ABI_VERSION; }
 int sat_debug_trace_launches(int32_t on) { sat::trace_launches() = on ? 1 : 0; return SAT_OK; }
 int sat_debug_option(const char* name, int32_t value) {
     if (!name) return fail(SAT_EINVAL, "debug_option: null name");
+    if (!strcmp(name, "bn_ticket")) { dev_switch(SW_BN_TICKET) = value; return SAT_OK; }
+    if (!strcmp(name, "wgrad3x3")) { dev_switch(SW_WGRAD3X3) = value; return SAT_OK; }
+    if (!strcmp(name, "reduce_z16")) { dev_switch(SW_REDUCE_Z16) = value; return SAT_OK; }
+    if (!strcmp(name, "wide_tiles")) { dev_switch(SW_WIDE_TILES) = value; return SAT_OK; }
     if (!strcmp(name, "glds_tile")) { glds_force_tile() = value; return SAT_OK; }
     if (!strcmp(name, "glds_stages8")) { glds_stages8() = value; return SAT_OK; }
     if (!strcmp(name, "tile_override")) { gemm_tile_override() = value; return SAT_OK; }

@@ -1041,7 +1041,7 @@ static int bn_train_fwd_t(const T* x, int64_t rows, int32_t C, const float* gamm
         int np = cdiv(ntiles, 64); if (np > nparts) np = nparts; if (np < 1) np = 1;          // partials fit the scratch sized for nparts
         const int per = cdiv(ntiles, np); np = cdiv(ntiles, per);
         p1 = p0 + (long)np * C;
-        static const int fin = getenv("SAT_BN_TICKET") ? atoi(getenv("SAT_BN_TICKET")) : 1;
+        const int fin = dev_switch(SW_BN_TICKET);
         if (fin) {          // reduce + finalize in one launch (the last block of a channel group finishes)
             int* cnt = reinterpret_cast<int*>(p0 + (long)nparts * C * 2 + 8);
             SAT_CHECK_HIP(hipMemsetAsync(cnt, 0, (size_t)cdiv(C, 32) * sizeof(int), st));
@@ -1103,7 +1103,7 @@ static int bn_train_bwd_t(const T* dy, const T* x, const T* y, int64_t rows, int
         int np = cdiv(ntiles, 64); if (np > nparts) np = nparts; if (np < 1) np = 1;
         const int per = cdiv(ntiles, np); np = cdiv(ntiles, per);
         p1 = p0 + (long)np * C;
-        static const int fin = getenv("SAT_BN_TICKET") ? atoi(getenv("SAT_BN_TICKET")) : 1;
+        const int fin = dev_switch(SW_BN_TICKET);
         if (fin) {
             int* cnt = reinterpret_cast<int*>(p0 + (long)nparts * C * 2 + 8);
             SAT_CHECK_HIP(hipMemsetAsync(cnt, 0, (size_t)cdiv(C, 32) * sizeof(int), st));

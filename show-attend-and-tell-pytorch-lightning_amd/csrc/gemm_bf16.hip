@@ -324,7 +324,7 @@ static int pick_wide_tile(const GemmArgs& g) {
     // Off by default: the forms win -4 .. -22 % launch by launch on cold caches (tools/sweep_tiles.py) but the whole C2 step does not
     // get faster with them (25.1 vs 25.0 ms, bench.py A/B on one box): inside the step the operands of these launches are L2 / MALL
     // resident from their producers and the 128x128 form's two workgroups per CU overlap better.  SAT_WIDE_TILES=1 turns them on.
-    static const int wide = getenv("SAT_WIDE_TILES") ? atoi(getenv("SAT_WIDE_TILES")) : 0;
+    const int wide = dev_switch(SW_WIDE_TILES);
     if (!wide || !g.a_bf16 || !g.b_bf16 || g.a_rows || g.c_rows || g.K % 64) return 0;
     // measured on the C2 step's convolutions (tools/sweep_tiles.py, resnet50, 128 images):
     //   weight gradients with >= 256 filters and >= 256 filter columns: 256x256 (-10 .. -22 %; the operand panels are re-read half as often)

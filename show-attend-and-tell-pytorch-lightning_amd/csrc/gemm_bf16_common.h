@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_z16_kernel(BArgs a) {
 template <typename TC>
 inline int launch_splitk_reduce(const BArgs& k, hipStream_t st) {
     const long total = (long)k.M * k.N;
-    static const int z16 = getenv("SAT_REDUCE_Z16") ? atoi(getenv("SAT_REDUCE_Z16")) : 1;
+    const int z16 = dev_switch(SW_REDUCE_Z16);
     if (k.wide_slab && z16 && k.nsplit >= 32 && total / 4 / 256 < 256)
         hipLaunchKernelGGL(splitk_reduce_z16_kernel<TC>, dim3(cdiv(total / 4, 16)), dim3(256), 0, st, k);
     else if (k.wide_slab) hipLaunchKernelGGL(splitk_reduce_b4_kernel<TC>, dim3(cdiv(total / 4, 256)), dim3(256), 0, st, k);

@@ -196,8 +196,7 @@ __global__ __launch_bounds__(W3_THREADS) void wgrad3x3_kernel(W3Args a) {
 
 // 0 when the geometry is not this kernel's (the caller keeps the implicit-GEMM form)
 int wgrad3x3_eligible(const ConvGeom& g) {
-    static const int off = getenv("SAT_NO_WGRAD3X3") ? atoi(getenv("SAT_NO_WGRAD3X3")) : 0;
-    if (off) return 0;
+    if (!dev_switch(SW_WGRAD3X3)) return 0;
     if (g.R != 3 || g.S != 3 || g.stride != 1 || g.pad != 1 || (g.sw && g.sw != 1)) return 0;
     if (g.C % 64 || g.K % 64) return 0;
     if (g.H != g.P || g.W != g.Q) return 0;

@@ -1,0 +1,55 @@
+"""Dev tool: A/B of run-time switches on the whole C2 train step inside ONE process (variants alternate round by round, so clock /
+thermal drift and box-to-box differences cancel; the per-process bench.py A/B has +-0.5 ms of noise).
+usage: python tools/ab_step.py name=value[,name=value...] ...   (each argument = one variant; 'base' = defaults)
+switches: sat_debug_option names (bn_ticket, wgrad3x3, reduce_z16, wide_tiles, glds_tile, ...) and py:bn_bwd_epilogue"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+import sat_amd  # noqa
+from sat_amd import _lib as L, model as M, encoder as E
+
+cfg = os.environ.get("CFG", "c2")
+hp, T, B, R = bench.hparams(cfg)
+torch.manual_seed(42)
+model = M.SAT(**hp).cuda().train(); model.set_precision("bf16")
+model.__dict__["_sat_global_step"] = 2
+opt = model.configure_optimizers()
+img, caps, lengths = bench.synthetic_batch(B, R, T, hp["vocab_size"], 1234, False)
+img, caps = img.cuda(), caps.cuda()
+DEFAULTS = {"bn_ticket": 1, "wgrad3x3": 1, "reduce_z16": 1, "wide_tiles": 0, "py:bn_bwd_epilogue": 1}
+
+
+def apply(settings):
+    for k, v in {**DEFAULTS, **settings}.items():
+        if k.startswith("py:"):
+            setattr(E, "_BN_BWD_EPILOGUE", bool(v))
+        else:
+            L.check(L.lib().sat_debug_option(k.encode(), int(v)), k)
+
+
+def step():
+    opt.zero_grad(set_to_none=True)
+    out = model.training_step((img, caps, lengths), 0); out["loss"].backward(); opt.step()
+
+
+variants = []
+for a in sys.argv[1:]:
+    variants.append((a, {} if a == "base" else {kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.split(",")}))
+for _ in range(30):
+    step()
+torch.cuda.synchronize()
+rounds, per = int(os.environ.get("ROUNDS", "8")), int(os.environ.get("PER", "10"))
+times = {n: [] for n, _ in variants}
+for r in range(rounds):
+    for n, s in variants:
+        apply(s)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(per):
+            step()
+        torch.cuda.synchronize(); times[n].append((time.perf_counter() - t0) / per * 1e3)
+for n, ts in times.items():
+    ts = sorted(ts)
+    print("%-40s median %.3f ms  min %.3f  max %.3f" % (n, ts[len(ts) // 2], ts[0], ts[-1]))
