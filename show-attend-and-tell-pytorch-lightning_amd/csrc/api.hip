@@ -9,7 +9,7 @@
 namespace sat {
 static thread_local char g_err[512] = {0};
 int& dev_switch(int which) {
-    static int v[SW_COUNT] = {getenv("SAT_BN_TICKET") ? atoi(getenv("SAT_BN_TICKET")) : 1, getenv("SAT_NO_WGRAD3X3") ? !atoi(getenv("SAT_NO_WGRAD3X3")) : 1,
+    static int v[SW_COUNT] = {getenv("SAT_BN_TICKET") ? atoi(getenv("SAT_BN_TICKET")) : 0, getenv("SAT_NO_WGRAD3X3") ? !atoi(getenv("SAT_NO_WGRAD3X3")) : 1,
                               getenv("SAT_REDUCE_Z16") ? atoi(getenv("SAT_REDUCE_Z16")) : 1, getenv("SAT_WIDE_TILES") ? atoi(getenv("SAT_WIDE_TILES")) : 0};
     return v[which];
 }

@@ -278,6 +278,8 @@ __global__ __launch_bounds__(256) void bn_tile_reduce_kernel(const float* __rest
 // channel group, and the block that draws the last ticket of its group reads all partials back (L1-bypassing loads) and finishes - in
 // a FIXED order that does not depend on which block came last, so results stay bit-reproducible.  Saves the separate finalize launch
 // (5 - 9 us of dependent-launch latency each, ~80 of them per C2 step).  `cnt`: one zeroed int per channel group; the last block re-arms it.
+// OFF by default (SAT_BN_TICKET=1 / sat_debug_option("bn_ticket", 1)): measured inside the C2 step it costs +0.14 ms (tools/ab_step.py:
+// 24.22 vs 24.08 ms) - the write-through stores, the ticket and the last block's serial tail outweigh the launch they save.
 //   mode 0 (forward) : mean / invstd (+ running statistics)   mode 1 (backward): dbeta = sum g, dgamma = sum g * xhat
 __global__ __launch_bounds__(256) void bn_tile_reduce_finish_kernel(const float* __restrict__ tiles, int ntiles, int C, int tiles_per, double* __restrict__ part0,
                                                                     double* __restrict__ part1, int* __restrict__ cnt, int mode, long rows, float eps, float momentum,

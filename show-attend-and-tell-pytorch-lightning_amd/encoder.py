@@ -153,8 +153,8 @@ def conv_dgrad(dy, w, x_shape, stride, pad, out=None, accumulate=False, bn=None)
 _slabs = {}
 
 
-def _slab(device, nbytes):
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+def _slab(device, nbytes, tag="main"):
+    key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
     cur = _slabs.get(key)
     if cur is None or cur.numel() * 4 < nbytes:
         cur = torch.empty(max(nbytes // 4, 4 << 20), dtype=torch.float32, device=device)
@@ -162,23 +162,71 @@ def _slab(device, nbytes):
     return cur
 
 
-def conv_wgrad(dy, x, w, stride, pad, stride_w=0, param=None):
+#: weight gradients of the residual blocks on a second HIP stream: they feed nothing on the backward chain (only the optimizer), and
+#: most of the chain's kernels leave matrix cores / HBM half idle, so the two streams fill each other's gaps
+_WGRAD_STREAM = os.environ.get("SAT_WGRAD_STREAM", "1") != "0"
+_side_streams = {}
+
+
+class _SideQueue:
+    """Second stream for the weight gradients of one encoder backward.  ``launch(fn, *inputs)``: fn runs with the side stream current,
+    after everything enqueued on the main stream so far; ``join()``: the main stream waits for everything launched here."""
+
+    def __init__(self, device, enabled):
+        self.enabled = bool(enabled)
+        if not self.enabled:
+            return
+        self.main = torch.cuda.current_stream(device)
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        self.side = _side_streams.get(key)
+        if self.side is None:
+            self.side = _side_streams[key] = torch.cuda.Stream(device)
+        self.dirty = False
+
+    def launch(self, fn, *inputs):
+        if not self.enabled:
+            return fn()
+        ev = torch.cuda.Event(); ev.record(self.main)
+        self.side.wait_event(ev)
+        with torch.cuda.stream(self.side):
+            out = fn()
+        for t in inputs:                       # the caching allocator must not hand these blocks out again before the side stream is done
+            if t is not None:
+                t.record_stream(self.side)
+        self.dirty = True
+        return out
+
+    def join(self):
+        if self.enabled and self.dirty:
+            ev = torch.cuda.Event(); ev.record(self.side)
+            self.main.wait_event(ev)
+            self.dirty = False
+
+
+def conv_wgrad(dy, x, w, stride, pad, stride_w=0, param=None, queue=None):
     """fp32 gradient of the (K,C,R,S) filter, whatever the activation storage.  ``param``: the filter parameter itself, when the
-    gradient may be written to its data-parallel bucket slice (``_lib.grad_buffer``)."""
+    gradient may be written to its data-parallel bucket slice (``_lib.grad_buffer``).  ``queue``: a ``_SideQueue`` - the launch then goes
+    to its side stream (the result is allocated on the calling stream; the caller joins the queue before anything reads it)."""
     N, H, W, Cc = x.shape
     K, _, R, S = w.shape
     g = _geom(N, H, W, Cc, K, R, S, stride, pad, stride_w)
     lib = L.lib()
     nbytes = max(lib.sat_conv2d_wgrad_slab_bytes(C.byref(g)), 128 << 20)
-    slab = _slab(x.device, nbytes)
+    side = queue is not None and queue.enabled
+    slab = _slab(x.device, nbytes, "side" if side else "main")
     fn = lib.sat_conv2d_wgrad_bf16 if _is_bf(x) else lib.sat_conv2d_wgrad
     out = L.grad_buffer(param) if param is not None else None                 # (K,C,R,S), KRSC memory when the parameter is
-    if out is not None and tuple(out.shape) == (K, Cc, R, S) and out.permute(0, 2, 3, 1).is_contiguous():
-        L.check(fn(L.ptr(dy), L.ptr(x), L.ptr(out), C.byref(g), L.ptr(slab), slab.numel(), L.stream_ptr()), "sat_conv2d_wgrad")
-        return out
-    dw = torch.empty(K, R, S, Cc, dtype=torch.float32, device=x.device)       # KRSC
-    L.check(fn(L.ptr(dy), L.ptr(x), L.ptr(dw), C.byref(g), L.ptr(slab), slab.numel(), L.stream_ptr()), "sat_conv2d_wgrad")
-    return dw.permute(0, 3, 1, 2)                                             # (K,C,R,S) view, channels_last memory
+    direct = out is not None and tuple(out.shape) == (K, Cc, R, S) and out.permute(0, 2, 3, 1).is_contiguous()
+    dst = out if direct else torch.empty(K, R, S, Cc, dtype=torch.float32, device=x.device)       # KRSC
+
+    def run():
+        L.check(fn(L.ptr(dy), L.ptr(x), L.ptr(dst), C.byref(g), L.ptr(slab), slab.numel(), L.stream_ptr()), "sat_conv2d_wgrad")
+
+    if side:
+        queue.launch(run, dy, x, dst)
+    else:
+        run()
+    return out if direct else dst.permute(0, 3, 1, 2)                         # (K,C,R,S) view, channels_last memory
 
 
 #: the stem's bn1 -> relu -> maxpool as one pass (tests switch it off to compare with the three separate kernels)
@@ -319,7 +367,7 @@ def _block_fwd(blk, x, training, W=None):
     return r
 
 
-def _block_bwd(r, dout, grads, need_dx, W=None, dout_tiles=None, prev=None):
+def _block_bwd(r, dout, grads, need_dx, W=None, dout_tiles=None, prev=None, queue=None):
     """Backward of one residual block.  ``dout_tiles``: backward statistics of this block's last BatchNorm that came with ``dout``
     (produced by the block behind it); ``prev``: the record of the block in front, whose last BatchNorm's statistics the launch that
     writes this block's input gradient can produce.  Returns (dx, tiles for ``prev``'s last BatchNorm or None)."""
@@ -328,22 +376,22 @@ def _block_bwd(r, dout, grads, need_dx, W=None, dout_tiles=None, prev=None):
     g = torch.empty_like(r.out)                      # gradient of the residual branch (= dout masked by the final ReLU)
     if blk.kind == "basic":
         dx2, grads[blk.bn2.weight], grads[blk.bn2.bias] = bn_bwd(dout, r.c2, r.out, r.s2, blk.bn2, True, dres=g, tiles=dout_tiles)
-        grads[blk.conv2.weight] = conv_wgrad(dx2, r.a1, blk.conv2.weight, 1, 1, param=blk.conv2.weight)
+        grads[blk.conv2.weight] = conv_wgrad(dx2, r.a1, blk.conv2.weight, 1, 1, param=blk.conv2.weight, queue=queue)
         da1, t1 = conv_dgrad(dx2, W(blk.conv2.weight), r.a1.shape, 1, 1, bn=(r.c1, r.s1))
         first_w, first_stride, first_pad = blk.conv1.weight, blk.stride, 1
     else:
         dx3, grads[blk.bn3.weight], grads[blk.bn3.bias] = bn_bwd(dout, r.c3, r.out, r.s3, blk.bn3, True, dres=g, tiles=dout_tiles)
-        grads[blk.conv3.weight] = conv_wgrad(dx3, r.a2, blk.conv3.weight, 1, 0, param=blk.conv3.weight)
+        grads[blk.conv3.weight] = conv_wgrad(dx3, r.a2, blk.conv3.weight, 1, 0, param=blk.conv3.weight, queue=queue)
         da2, t2 = conv_dgrad(dx3, W(blk.conv3.weight), r.a2.shape, 1, 0, bn=(r.c2, r.s2))
         dx2, grads[blk.bn2.weight], grads[blk.bn2.bias] = bn_bwd(da2, r.c2, r.a2, r.s2, blk.bn2, True, tiles=t2)
-        grads[blk.conv2.weight] = conv_wgrad(dx2, r.a1, blk.conv2.weight, blk.stride, 1, param=blk.conv2.weight)
+        grads[blk.conv2.weight] = conv_wgrad(dx2, r.a1, blk.conv2.weight, blk.stride, 1, param=blk.conv2.weight, queue=queue)
         da1, t1 = conv_dgrad(dx2, W(blk.conv2.weight), r.a1.shape, blk.stride, 1, bn=(r.c1, r.s1))
         first_w, first_stride, first_pad = blk.conv1.weight, 1, 0
     dx1, grads[blk.bn1.weight], grads[blk.bn1.bias] = bn_bwd(da1, r.c1, r.a1, r.s1, blk.bn1, True, tiles=t1)
-    grads[first_w] = conv_wgrad(dx1, r.x, first_w, first_stride, first_pad, param=first_w)
+    grads[first_w] = conv_wgrad(dx1, r.x, first_w, first_stride, first_pad, param=first_w, queue=queue)
     if blk.downsample is not None:
         dxd, grads[blk.downsample[1].weight], grads[blk.downsample[1].bias] = bn_bwd(g, r.cd, None, r.sd, blk.downsample[1], False)
-        grads[blk.downsample[0].weight] = conv_wgrad(dxd, r.x, blk.downsample[0].weight, blk.stride, 0, param=blk.downsample[0].weight)
+        grads[blk.downsample[0].weight] = conv_wgrad(dxd, r.x, blk.downsample[0].weight, blk.stride, 0, param=blk.downsample[0].weight, queue=queue)
         if not need_dx:
             return None, None
         dx = conv_dgrad(dx1, W(first_w), r.x.shape, first_stride, first_pad)
@@ -506,9 +554,11 @@ class EncoderFn(torch.autograd.Function):
             for n in n_per_stage:
                 acc += n; bounds.append(acc)
             tiles = None
+            queue = _SideQueue(d.device, _WGRAD_STREAM and bf)
             for idx in range(len(recs) - 1, -1, -1):
-                d, tiles = _block_bwd(recs[idx], d, grads, True, Wt, dout_tiles=tiles, prev=(recs[idx - 1] if idx > 0 else None))
+                d, tiles = _block_bwd(recs[idx], d, grads, True, Wt, dout_tiles=tiles, prev=(recs[idx - 1] if idx > 0 else None), queue=queue)
                 if cb is not None and idx in (bounds[2], bounds[1], bounds[0]):      # a ResNet stage just finished
+                    queue.join()
                     cb(dict(grads))
             if "a0" not in t:
                 dc0, grads[enc[2].weight], grads[enc[2].bias] = stem_tail_bwd(d, t["c0"], t["s0"], enc[2])
@@ -529,6 +579,7 @@ class EncoderFn(torch.autograd.Function):
             else:
                 L.check(lib.sat_pad_channels_3to4(L.ptr(dwp), L.ptr(dw3), enc[1].out_channels * 49, 1, st), "sat_pad_channels_3to4")
             grads[enc[1].weight] = dw3
+            queue.join()
         ctx.t = ctx.recs = ctx.Wt = None
         return (None, None, *[grads.get(p) if p.requires_grad else None for p in ctx.params])
 
