@@ -165,6 +165,7 @@ def _slab(device, nbytes, tag="main"):
 #: weight gradients of the residual blocks on a second HIP stream: they feed nothing on the backward chain (only the optimizer), and
 #: most of the chain's kernels leave matrix cores / HBM half idle, so the two streams fill each other's gaps
 _WGRAD_STREAM = os.environ.get("SAT_WGRAD_STREAM", "1") != "0"
+_WGRAD_STREAMS = int(os.environ.get("SAT_WGRAD_STREAMS", "1"))          # side streams the launches are dealt to in turn
 _side_streams = {}
 
 
@@ -178,29 +179,39 @@ class _SideQueue:
             return
         self.main = torch.cuda.current_stream(device)
         key = device.index if device.index is not None else torch.cuda.current_device()
-        self.side = _side_streams.get(key)
-        if self.side is None:
-            self.side = _side_streams[key] = torch.cuda.Stream(device)
-        self.dirty = False
+        n = max(1, _WGRAD_STREAMS)
+        while len(_side_streams.setdefault(key, [])) < n:
+            _side_streams[key].append(torch.cuda.Stream(device))
+        self.sides = _side_streams[key][:n]
+        self.turn = 0
+        self.dirty = [False] * n
+
+    def slot(self):
+        """index of the side stream the next launch goes to (its split-K scratch is per stream)"""
+        return self.turn % len(self.sides)
 
     def launch(self, fn, *inputs):
         if not self.enabled:
             return fn()
+        i = self.slot(); side = self.sides[i]; self.turn += 1
         ev = torch.cuda.Event(); ev.record(self.main)
-        self.side.wait_event(ev)
-        with torch.cuda.stream(self.side):
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
             out = fn()
         for t in inputs:                       # the caching allocator must not hand these blocks out again before the side stream is done
             if t is not None:
-                t.record_stream(self.side)
-        self.dirty = True
+                t.record_stream(side)
+        self.dirty[i] = True
         return out
 
     def join(self):
-        if self.enabled and self.dirty:
-            ev = torch.cuda.Event(); ev.record(self.side)
-            self.main.wait_event(ev)
-            self.dirty = False
+        if not self.enabled:
+            return
+        for i, side in enumerate(self.sides):
+            if self.dirty[i]:
+                ev = torch.cuda.Event(); ev.record(side)
+                self.main.wait_event(ev)
+                self.dirty[i] = False
 
 
 def conv_wgrad(dy, x, w, stride, pad, stride_w=0, param=None, queue=None):
@@ -213,7 +224,7 @@ def conv_wgrad(dy, x, w, stride, pad, stride_w=0, param=None, queue=None):
     lib = L.lib()
     nbytes = max(lib.sat_conv2d_wgrad_slab_bytes(C.byref(g)), 128 << 20)
     side = queue is not None and queue.enabled
-    slab = _slab(x.device, nbytes, "side" if side else "main")
+    slab = _slab(x.device, nbytes, "side%d" % queue.slot() if side else "main")
     fn = lib.sat_conv2d_wgrad_bf16 if _is_bf(x) else lib.sat_conv2d_wgrad
     out = L.grad_buffer(param) if param is not None else None                 # (K,C,R,S), KRSC memory when the parameter is
     direct = out is not None and tuple(out.shape) == (K, Cc, R, S) and out.permute(0, 2, 3, 1).is_contiguous()
