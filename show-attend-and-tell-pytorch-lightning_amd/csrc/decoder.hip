@@ -1041,14 +1041,16 @@ int sigmoid_bwd(const float* dy, const float* y, float* dpre, long n, hipStream_
 int ce_fwd(const float* logits, const int* targets, int P, int V, float smoothing, float* lse_rows, float* loss_rows, int* correct_rows, float* out, hipStream_t st) {
     SAT_REQUIRE(P > 0 && V > 0, "ce_fwd: empty input (P=%d V=%d)", P, V);
     SAT_REQUIRE(smoothing >= 0.f && smoothing < 1.f, "ce_fwd: smoothing %g out of range", smoothing);
-    hipLaunchKernelGGL(ce_rows_kernel, dim3(P), dim3(256), 0, st, logits, targets, V, smoothing, lse_rows, loss_rows, correct_rows);
+    if (V % 4 == 0 && (uintptr_t)logits % 16 == 0) hipLaunchKernelGGL(ce_rows_kernel<4>, dim3(P), dim3(256), 0, st, logits, targets, V, smoothing, lse_rows, loss_rows, correct_rows);
+    else hipLaunchKernelGGL(ce_rows_kernel<1>, dim3(P), dim3(256), 0, st, logits, targets, V, smoothing, lse_rows, loss_rows, correct_rows);
     SAT_TRY(launch_ok("ce_rows"));
     hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(256), 0, st, loss_rows, correct_rows, P, out);
     return launch_ok("ce_finish");
 }
 int ce_bwd(const float* logits, const int* targets, const float* lse_rows, int P, int V, float smoothing, const float* gscale, float* dlogits, hipStream_t st) {
     SAT_REQUIRE(P > 0 && V > 0, "ce_bwd: empty input");
-    hipLaunchKernelGGL(ce_grad_kernel, dim3(P), dim3(256), 0, st, logits, targets, lse_rows, V, smoothing, 1.0f / (float)P, gscale, dlogits);
+    if (V % 4 == 0 && (uintptr_t)logits % 16 == 0 && (uintptr_t)dlogits % 16 == 0) hipLaunchKernelGGL(ce_grad_kernel<4>, dim3(P), dim3(256), 0, st, logits, targets, lse_rows, V, smoothing, 1.0f / (float)P, gscale, dlogits);
+    else hipLaunchKernelGGL(ce_grad_kernel<1>, dim3(P), dim3(256), 0, st, logits, targets, lse_rows, V, smoothing, 1.0f / (float)P, gscale, dlogits);
     return launch_ok("ce_grad");
 }
 int ds_fwd(const float* alphas, int N, int T1, int L, float gamma, float* asum, float* part, float* out, hipStream_t st) {

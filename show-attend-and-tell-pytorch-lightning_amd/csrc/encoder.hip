@@ -401,6 +401,58 @@ __global__ __launch_bounds__(256) void bn_tile_finalize_kernel(const float* __re
         }
     }
 }
+// Tile statistics -> final per-channel values in ONE launch at any tile count (default; SAT_BN_ONEPASS=0 restores the reduce + finalize pair).
+// A block owns CPB channels (one CPB * 8-byte run of the [tile][channel](sum, sq) array) and 256 / CPB tile lanes with U loads in flight each,
+// so even the 56x56 stage (1568 tiles) is two round trips long; lanes are combined by a fixed xor tree, the waves through LDS in wave
+// order - the result does not depend on timing.  Blocks stay at 256 threads: a 1024-thread block waits for a whole free CU, and with the
+// weight-gradient GEMMs running beside it on the side stream that wait was 20 - 100 us (measured).
+// mode 0: mean / invstd (+ running statistics), mode 1: dbeta = sum g, dgamma = sum g xhat.
+template <int CPB, int U>
+__global__ __launch_bounds__(256) void bn_tile_finish_kernel(const float* __restrict__ tiles, int ntiles, int C, int mode, long rows, float eps, float momentum,
+                                                             float* __restrict__ out0, float* __restrict__ out1, float* __restrict__ running_mean,
+                                                             float* __restrict__ running_var) {
+    constexpr int NT = 256, TL = NT / CPB, NW = NT / 64;
+    __shared__ double sh[2][NW][CPB];
+    const int cl = threadIdx.x % CPB, tl = threadIdx.x / CPB, c = blockIdx.x * CPB + cl, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int t0 = tl; t0 < ntiles; t0 += TL * U) {
+            float2 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const int t = t0 + TL * u; v[u] = t < ntiles ? reinterpret_cast<const float2*>(tiles)[(long)t * C + c] : make_float2(0.f, 0.f); }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { s += (double)v[u].x; q += (double)v[u].y; }
+        }
+#pragma unroll
+    for (int o = CPB; o < 64; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    if (lane < CPB) { sh[0][wave][lane] = s; sh[1][wave][lane] = q; }
+    __syncthreads();
+    if (threadIdx.x >= CPB || c >= C) return;
+    double ss = 0.0, qq = 0.0;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) { ss += sh[0][k][cl]; qq += sh[1][k][cl]; }
+    if (mode == 1) { out0[c] = (float)ss; out1[c] = (float)qq; return; }
+    const double n = (double)rows;
+    double var = (qq - ss * ss / n) / n; if (var < 0.0) var = 0.0;
+    const double mu = ss / n;
+    out0[c] = (float)mu;
+    out1[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unb = rows > 1 ? var * n / (n - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+// measured per launch inside the C2 step: <8, 8> 5.7 us (fused kernel before: 9.1), <4, 16> 9.3 us (reduce + finalize pair: 10.8 forward, 16.4
+// backward); above 2048 tiles a 2-channel form took 20 us against the pair's 11 - 16, so those keep the pair.
+static inline bool bn_tile_finish_ok(int ntiles) { return ntiles <= 2048; }
+static inline void launch_bn_tile_finish(const float* tiles, int ntiles, int C, int mode, long rows, float eps, float momentum, float* out0, float* out1,
+                                         float* running_mean, float* running_var, hipStream_t st) {
+    if (ntiles > 256)
+        hipLaunchKernelGGL((bn_tile_finish_kernel<4, 16>), dim3(cdiv(C, 4)), dim3(256), 0, st, tiles, ntiles, C, mode, rows, eps, momentum, out0, out1, running_mean, running_var);
+    else
+        hipLaunchKernelGGL((bn_tile_finish_kernel<8, 8>), dim3(cdiv(C, 8)), dim3(256), 0, st, tiles, ntiles, C, mode, rows, eps, momentum, out0, out1, running_mean, running_var);
+}
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part0, const double* __restrict__ part1, int nparts, int C,
                                        float* __restrict__ dbeta, float* __restrict__ dgamma) {
     const int lane = threadIdx.x & 63, c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -1030,6 +1082,15 @@ static int bn_train_fwd_t(const T* x, int64_t rows, int32_t C, const float* gamm
         SAT_REQUIRE(tile_rows > 0, "bn_train_fwd: tile_rows=%d", tile_rows);
         const int ntiles = (int)cdiv(rows, (long)tile_rows);
         static const int fuse_upto = getenv("SAT_BN_FUSE_TILES") ? atoi(getenv("SAT_BN_FUSE_TILES")) : 256;
+        if (dev_switch(SW_BN_ONEPASS) && bn_tile_finish_ok(ntiles)) {
+            launch_bn_tile_finish(tile_stats, ntiles, C, 0, (long)rows, eps, momentum, save_mean, save_invstd, running_mean, running_var, st);
+            SAT_TRY(launch_ok("bn_tile_finish"));
+            if (!y) return SAT_OK;                   // statistics only: the caller normalises inside its own kernel (stem tail)
+            long totalv = rows * (C / E);
+            ProfScope prof("bn_apply_fwd", 0.0, (double)rows * C * (sizeof(T) * (residual ? 3 : 2) + (relu_mask ? 0.125 : 0.0)), st);
+            hipLaunchKernelGGL((bn_apply_kernel<T, false>), dim3(cdiv(totalv, 256)), dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta, residual, relu, y, relu_mask, totalv, C / E, -1.0f);
+            return launch_ok("bn_apply");
+        }
         if (ntiles <= fuse_upto) {
             hipLaunchKernelGGL(bn_tile_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, tile_stats, ntiles, C, (long)rows, eps, momentum, save_mean, save_invstd,
                                running_mean, running_var);
@@ -1106,7 +1167,11 @@ static int bn_train_bwd_t(const T* dy, const T* x, const T* y, int64_t rows, int
         const int per = cdiv(ntiles, np); np = cdiv(ntiles, per);
         p1 = p0 + (long)np * C;
         const int fin = dev_switch(SW_BN_TICKET);
-        if (fin) {
+        if (dev_switch(SW_BN_ONEPASS) && bn_tile_finish_ok(ntiles)) {
+            launch_bn_tile_finish(tile_stats, ntiles, C, 1, (long)rows, 0.f, 0.f, dbeta, dgamma, nullptr, nullptr, st);
+            SAT_TRY(launch_ok("bn_tile_finish (backward)"));
+            tiles_done = true;
+        } else if (fin) {
             int* cnt = reinterpret_cast<int*>(p0 + (long)nparts * C * 2 + 8);
             SAT_CHECK_HIP(hipMemsetAsync(cnt, 0, (size_t)cdiv(C, 32) * sizeof(int), st));
             hipLaunchKernelGGL(bn_tile_reduce_finish_kernel, dim3(cdiv(C, 32), np), dim3(256), 0, st, tile_stats, ntiles, C, per, p0, p1, cnt, 1, (long)rows, 0.f, 0.f,

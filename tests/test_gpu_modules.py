@@ -194,6 +194,27 @@ def test_g6_label_smoothing_kernel_against_the_reference_fixture(M, golden_dir, 
     assert abs(float(crit.last_accuracy) - acc) < 1e-6
 
 
+@pytest.mark.parametrize("P,V", [(7, 10000), (5, 1003), (3, 4), (9, 4100), (2, 1)])
+def test_label_smoothing_kernel_vector_and_scalar_paths(M, P, V):
+    """util.py:105-112 at vocabulary sizes on both sides of the 16-byte path (V % 4 == 0) and with tied maxima (argmax = first index,
+    as torch): loss / gradient against float64 torch on the CPU, tolerance 5e-6 relative to the largest entry."""
+    torch.manual_seed(P * 131 + V)
+    x = (torch.randn(P, V) * 3.0)
+    if V >= 4:
+        x[0, V // 2] = x[0].max() + 1.0; x[0, V - 1] = x[0, V // 2]              # a tie: the first one counts
+    t = torch.randint(0, V, (P,)); t[0] = V // 2
+    xg = x.cuda().requires_grad_()
+    crit = M.LabelSmoothing(0.1)
+    loss = crit(xg, t.cuda()); (loss * 1.7).backward()
+    xd = x.double().requires_grad_()
+    lp = torch.log_softmax(xd, -1)
+    ref = (0.9 * (-lp.gather(1, t[:, None])[:, 0]) + 0.1 * (-lp.mean(-1))).mean()
+    (ref * 1.7).backward()
+    close(loss, ref.detach().float(), tol=5e-6, what="loss"); close(xg.grad, xd.grad.float(), tol=5e-6, what="gradient")
+    acc = float((x.argmax(1) == t).float().mean())
+    assert abs(float(crit.last_accuracy) - acc) < 1e-6
+
+
 def test_attention_step_fwd_bound_exactly_as_integration_md(golden_dir):
     """INTEGRATION.md section 2, verbatim: a bare ctypes binding of sat_attention_precompute / sat_attention_step_fwd inside a module
     with the reference's SoftAttention signature, checked against fixture G1."""
