@@ -7,9 +7,11 @@ match.  The children only hold parameters; ``forward`` runs the HIP 
 annotations as a (B, D, h, w) tensor in channels-last memory, i.e. (B, h*w, D) row-major underneath.
 """
 import ctypes as C
+import glob
 import os
 
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from . import _lib as L
@@ -614,14 +616,73 @@ class HipEncoder(nn.Sequential):
         return EncoderFn.apply(img, self, *params)
 
 
+def _pretrained_file(arch, pretrained):
+    """``pretrained`` (model.py:18): the reference downloads torchvision's ImageNet weights.  There is no network here: a path
+    (``pretrained="/x/resnet50.pth"``) or, for ``True``, ``$SAT_PRETRAINED_DIR`` / ``$TORCH_HOME/hub/checkpoints`` /
+    ``~/.cache/torch/hub/checkpoints`` searched for torchvision's file name (``<arch>-<hash>.pth``) or ``<arch>.pth``."""
+    if not pretrained:
+        return None
+    if isinstance(pretrained, (str, os.PathLike)):
+        if not os.path.isfile(pretrained):
+            raise FileNotFoundError("pretrained=%r: no such file" % (pretrained,))
+        return os.fspath(pretrained)
+    dirs = [os.environ.get("SAT_PRETRAINED_DIR"), os.path.join(os.environ.get("TORCH_HOME", os.path.expanduser("~/.cache/torch")), "hub", "checkpoints")]
+    for d in dirs:
+        if d and os.path.isdir(d):
+            hits = sorted(glob.glob(os.path.join(d, arch + "-*.pth")) + glob.glob(os.path.join(d, arch + ".pth")))
+            if hits:
+                return hits[0]
+    raise RuntimeError("pretrained=True: no local torchvision checkpoint for %s (searched %s); there is no download here - pass pretrained=<path> "
+                       "or set SAT_PRETRAINED_DIR" % (arch, [d for d in dirs if d]))
+
+
+def _load_torchvision_trunk(path, conv1, bn1, layers):
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    if isinstance(sd, dict) and "state_dict" in sd and isinstance(sd["state_dict"], dict):
+        sd = sd["state_dict"]
+    sd = {k: v for k, v in sd.items() if not k.startswith("fc.")}          # model.py:29 drops pooling and fc
+    holder = nn.Module()
+    holder.conv1, holder.bn1 = conv1, bn1
+    for i, layer in enumerate(layers):
+        setattr(holder, "layer%d" % (i + 1), layer)
+    missing, unexpected = holder.load_state_dict(sd, strict=False)
+    missing = [k for k in missing if not k.endswith("num_batches_tracked")]          # absent from very old torchvision files
+    if missing or unexpected:
+        raise RuntimeError("pretrained checkpoint %s does not fit: missing %s, unexpected %s" % (path, missing[:5], list(unexpected)[:5]))
+
+
+def _probe_zero_image(conv1, bn1, layers, size):
+    """model.py:46-48 pushes one all-zero image through the train-mode trunk: its only lasting effect is on the BatchNorm buffers.
+    Initialisation-time host arithmetic on a single image (torch CPU ops), not part of the step."""
+    with torch.no_grad():
+        def bn(x, m):
+            return F.batch_norm(x, m.running_mean, m.running_var, m.weight, m.bias, True, m.momentum, m.eps)
+
+        def cv(x, m):
+            return F.conv2d(x, m.weight, None, m.stride, m.padding)
+        x = torch.zeros(1, 3, size, size)
+        x = F.max_pool2d(F.relu(bn(cv(x, conv1), bn1)), 3, 2, 1); bn1.num_batches_tracked += 1
+        for layer in layers:
+            for blk in layer:
+                idn = x
+                if blk.downsample is not None:
+                    idn = bn(cv(x, blk.downsample[0]), blk.downsample[1]); blk.downsample[1].num_batches_tracked += 1
+                y = F.relu(bn(cv(x, blk.conv1), blk.bn1)); blk.bn1.num_batches_tracked += 1
+                if blk.kind == "basic":
+                    y = bn(cv(y, blk.conv2), blk.bn2); blk.bn2.num_batches_tracked += 1
+                else:
+                    y = F.relu(bn(cv(y, blk.conv2), blk.bn2)); blk.bn2.num_batches_tracked += 1
+                    y = bn(cv(y, blk.conv3), blk.bn3); blk.bn3.num_batches_tracked += 1
+                x = F.relu(y + idn)
+
+
 def get_encoder(args):
     """Reference get_encoder (model.py:16-63) for resnet / wide_resnet archs; adds the README's
     ``encoder_size`` resize (readme.md:118-121) when ``args.encoder_size`` is set."""
     arch = args.encoder_arch
     if arch not in RESNETS:
         raise ValueError("Encoder not supported : {}".format(arch))
-    if getattr(args, "pretrained", False):
-        raise RuntimeError("pretrained=True needs a download; load weights with load_state_dict instead")
+    ckpt = _pretrained_file(arch, getattr(args, "pretrained", False))
     kind, depths, wpg = RESNETS[arch]
     conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False); bn1 = nn.BatchNorm2d(64)
     layers, cin = [], 64
@@ -639,10 +700,19 @@ def get_encoder(args):
                 nn.init.kaiming_normal_(sub.weight, mode="fan_out", nonlinearity="relu")
     # model.py:46-48 pushes a zero image through the train-mode trunk to read its output shape.  With zero
     # biases every BatchNorm sees an all-zero batch: running_mean stays 0, running_var becomes 0.9, one batch tracked.
-    for mod in [bn1, *layers]:
-        for sub in mod.modules():
-            if isinstance(sub, nn.BatchNorm2d):
-                sub.running_var.fill_(0.9); sub.num_batches_tracked.fill_(1)
+    if ckpt is None:
+        for mod in [bn1, *layers]:
+            for sub in mod.modules():
+                if isinstance(sub, nn.BatchNorm2d):
+                    sub.running_var.fill_(0.9); sub.num_batches_tracked.fill_(1)
+    else:
+        # model.py:18-24: torchvision weights, every trunk parameter frozen (the 1x1 projection added below stays trainable);
+        # then the same zero-image probe, which with real weights moves every running statistic by one momentum step
+        _load_torchvision_trunk(ckpt, conv1, bn1, layers)
+        for mod in [conv1, bn1, *layers]:
+            for prm in mod.parameters():
+                prm.requires_grad = False
+        _probe_zero_image(conv1, bn1, layers, int(args.input_size))
     inp = int(args.input_size)
     s = (inp + 2 * 3 - 7) // 2 + 1; s = (s + 2 - 3) // 2 + 1
     for _ in range(3):

@@ -110,6 +110,42 @@ def test_frozen_encoder_and_state_dict_roundtrip():
     assert torch.equal(a, b)
 
 
+def test_pretrained_trunk_from_a_local_checkpoint_trains_only_what_the_reference_trains(tmp_path):
+    """model.py:18-24: pretrained=<torchvision-format file> loads the trunk and freezes it; one step against the oracle holding the
+    same state (annotations-side parameters: projection and decoder gradients, fp32 mode, 1e-3 of the largest entry)."""
+    import sat_amd  # noqa: F401
+    from sat_amd import model as M
+    from oracle import sat_oracle as O
+    import os
+    torch.manual_seed(11)
+    net = O.ResNetOracle("resnet18")
+    with torch.no_grad():
+        for mod in net.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.uniform_(0.5, 1.5); mod.bias.uniform_(-0.3, 0.3); mod.running_mean.uniform_(-0.2, 0.2); mod.running_var.uniform_(0.5, 2.0)
+    path = os.path.join(str(tmp_path), "resnet18-feedbeef.pth")
+    torch.save(net.state_dict(), path)
+    over = dict(encoder_arch="resnet18", encoder_dim=32, input_size=64, encoder_size=3, vocab_size=120, embed_dim=24, attention_dim=16, decoder_dim=40,
+                deep_output=True, decoder_tf="always")
+    hp = O.default_hparams(**over); hp.pretrained = path
+    torch.manual_seed(3)
+    model = M.SAT(**vars(hp))
+    oracle = O.OracleSAT(O.default_hparams(**over), {k: v.clone() for k, v in model.state_dict().items()})
+    model = model.cuda().train()
+    frozen = {k for k, p in model.named_parameters() if not p.requires_grad}
+    assert frozen == {k for k, _ in model.named_parameters() if k.startswith("encoder.") and not k.startswith("encoder.9.")}
+    img, caps, lengths = batch(hp)
+    out = model.training_step((img.cuda(), caps.cuda(), lengths), 0); out["loss"].backward()
+    loss, _ = oracle.step_loss(img.clone(), caps, lengths, epsilon=1.0); loss.backward()
+    assert rel(out["loss"], loss) < 1e-4
+    og = oracle.named_grads()
+    for k, p in model.named_parameters():
+        if k in frozen:
+            assert p.grad is None, k
+        else:
+            assert rel(p.grad, og[k]) < 1e-3, (k, rel(p.grad, og[k]))
+
+
 BF16_CASES = {
     # name: (hparams, images, residual damping)
     "small": (dict(decoder_tf="always", encoder_dim=32, embed_dim=32, attention_dim=16, decoder_dim=64, vocab_size=128, input_size=128, encoder_size=None), 16, 0.25),

@@ -89,3 +89,60 @@ def test_bench_starts_its_own_ranks_without_touching_the_gpu(monkeypatch, capsys
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "2", "--steps", "3"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     assert capsys.readouterr().out.strip() == '{"metric": "m", "value": 1}'
+
+
+def _torchvision_style_checkpoint(tmp_path, arch, name):
+    """a checkpoint with torchvision's key names (conv1.*, bn1.*, layerN.*, fc.*) and non-trivial BatchNorm state"""
+    torch.manual_seed(5)
+    net = O.ResNetOracle(arch)
+    with torch.no_grad():
+        for mod in net.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.uniform_(0.5, 1.5); mod.bias.uniform_(-0.3, 0.3); mod.running_mean.uniform_(-0.2, 0.2); mod.running_var.uniform_(0.5, 2.0)
+    path = os.path.join(str(tmp_path), name)
+    torch.save(net.state_dict(), path)
+    return net, path
+
+
+@pytest.mark.parametrize("how", ["path", "directory"])
+def test_pretrained_encoder_loads_a_local_torchvision_checkpoint_and_freezes_the_trunk(tmp_path, monkeypatch, how):
+    """model.py:18-24 + :46-48: weights from the checkpoint, every trunk parameter frozen, the 1x1 projection trainable, and the BatchNorm
+    buffers after the zero-image probe equal to what the same probe leaves in a plain torch trunk holding the same weights."""
+    from types import SimpleNamespace
+    from sat_amd import encoder as E
+    net, path = _torchvision_style_checkpoint(tmp_path, "resnet18", "resnet18-0123abcd.pth")
+    args = SimpleNamespace(encoder_arch="resnet18", input_size=64, encoder_dim=32, encoder_size=None, mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225])
+    if how == "path":
+        args.pretrained = path
+    else:
+        args.pretrained = True; monkeypatch.setenv("SAT_PRETRAINED_DIR", str(tmp_path))
+    enc = E.get_encoder(args)
+    trunk = torch.nn.Sequential(net.conv1, net.bn1, net.relu, net.maxpool, net.layer1, net.layer2, net.layer3, net.layer4).train()
+    want = {k: v.clone() for k, v in net.state_dict().items() if not k.startswith("fc.")}
+    trunk(torch.zeros(1, 3, 64, 64))                                           # the reference's probe (model.py:46-48)
+    after = {k: v for k, v in net.state_dict().items() if not k.startswith("fc.")}
+    index = {"conv1": "1", "bn1": "2", "layer1": "5", "layer2": "6", "layer3": "7", "layer4": "8"}
+    got = enc.state_dict()
+    moved = 0
+    for k, v in after.items():
+        head, _, rest = k.partition(".")
+        g = got[index[head] + "." + rest]
+        assert torch.allclose(g.float(), v.float(), rtol=1e-5, atol=1e-6), k
+        moved += int(("running" in k) and not torch.equal(v, want[k]))
+    assert moved > 30                                                           # the probe really changed the buffers
+    frozen = [n for n, p in enc.named_parameters() if not p.requires_grad]
+    free = [n for n, p in enc.named_parameters() if p.requires_grad]
+    assert free == ["9.weight", "9.bias"] and len(frozen) == len(list(net.parameters())) - 2
+    assert not enc.trunk_trainable
+
+
+def test_pretrained_without_a_local_file_says_so(tmp_path, monkeypatch):
+    from types import SimpleNamespace
+    from sat_amd import encoder as E
+    monkeypatch.setenv("SAT_PRETRAINED_DIR", str(tmp_path)); monkeypatch.setenv("TORCH_HOME", str(tmp_path))
+    args = SimpleNamespace(encoder_arch="resnet18", input_size=64, encoder_dim=None, encoder_size=None, mean=[0.5] * 3, std=[0.2] * 3, pretrained=True)
+    with pytest.raises(RuntimeError, match="no local torchvision checkpoint"):
+        E.get_encoder(args)
+    args.pretrained = os.path.join(str(tmp_path), "nope.pth")
+    with pytest.raises(FileNotFoundError):
+        E.get_encoder(args)
