@@ -23,6 +23,7 @@ struct Ws {
     float *SC, *DA;                                              // attention: raw scores / score gradients of one step (N, L)
     // backward scratch
     float *dA, *dHout, *dZout, *DZ, *DHC, *dXZ, *dHc, *dCc, *dU, *dwf_part, *dY, *colpart, *dinit_img, *df, *dmean, *slab;
+    char *zero_begin, *zero_end;                                 // [dHout .. dwf_part]: what decoder_bwd zeroes in one memset
     long slab_elems;
 };
 
@@ -72,15 +73,17 @@ Ws layout(const sat_decoder_dims& d, char* base) {
     w.emb_list = (int*)take((size_t)T1 * N);
     w.SC = (float*)take((size_t)N * d.L); w.DA = (float*)take((size_t)N * d.L);
     w.dA = (float*)take((size_t)(d.P > 0 ? d.P : 1) * d.m);
-    w.dHout = (float*)take((size_t)T1 * N * d.n);
-    w.dZout = (float*)take((size_t)T1 * N * d.D);
     w.DZ = (float*)take((size_t)T1 * N * d.D);
     w.DHC = (float*)take((size_t)T1 * N * HCW);
     w.dXZ = (float*)take((size_t)N * d.D);
+    // the accumulators the backward pass starts from zero, adjacent: one memset (zero_begin .. zero_end)
+    w.dHout = (float*)take((size_t)T1 * N * d.n); w.zero_begin = (char*)w.dHout;
+    w.dZout = (float*)take((size_t)T1 * N * d.D);
     w.dHc = (float*)take((size_t)NL * N * d.n);
     w.dCc = (float*)take((size_t)NL * N * d.n);
     w.dU = (float*)take((size_t)d.B * d.L * d.A);
     w.dwf_part = (float*)take((size_t)d.B * d.A);
+    w.zero_end = base ? base + off : (char*)nullptr;
     w.dY = (float*)take((size_t)T1 * N * d.m);
     long maxrows = d.P > T1 * N ? d.P : T1 * N; if (maxrows < d.B * (long)d.L) maxrows = d.B * (long)d.L;
     long maxcols = d.V > HCW ? d.V : HCW;
@@ -293,13 +296,10 @@ int decoder_fwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
     for (int t = 0; t < ts; ++t) SAT_REQUIRE(b.teacher_host[t] || t > 0, "decoder: step 0 must be teacher forced");
 
     // packed parameters: Wcat = [W_d ; W_beta ; W_hh] (HCW, n), bcat = [0 ; b_beta ; b_ih + b_hh]
-    SAT_CHECK_HIP(hipMemcpyAsync(w.Wcat, p.att_dec, (size_t)A * n * 4, hipMemcpyDeviceToDevice, st));
-    SAT_CHECK_HIP(hipMemcpyAsync(w.Wcat + (long)A * n, p.beta_w, (size_t)D * n * 4, hipMemcpyDeviceToDevice, st));
-    SAT_CHECK_HIP(hipMemcpyAsync(w.Wcat + (long)(A + D) * n, p.w_hh, (size_t)4 * n * n * 4, hipMemcpyDeviceToDevice, st));
-    SAT_CHECK_HIP(hipMemsetAsync(w.bcat, 0, (size_t)A * 4, st));
-    SAT_CHECK_HIP(hipMemcpyAsync(w.bcat + A, p.beta_b, (size_t)D * 4, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(add_kernel, dim3(cdiv(4 * n, 256)), dim3(256), 0, st, w.bcat + A + D, p.b_ih, p.b_hh, (long)4 * n);
-    SAT_TRY(launch_ok("bias add"));
+    const bool use_b = w.Hb != nullptr && attention_split_enabled();
+    hipLaunchKernelGGL(pack_wcat_kernel, dim3(cdiv((long)HCW * n + HCW, 256)), dim3(256), 0, st, p.att_dec, p.beta_w, p.w_hh, p.beta_b, p.b_ih, p.b_hh, w.Wcat,
+                       use_b ? w.Wcat_b : (__bf16*)nullptr, w.bcat, A, D, n);
+    SAT_TRY(launch_ok("pack Wcat"));
     for (int l = 1; l < NL; ++l) {
         hipLaunchKernelGGL(add_kernel, dim3(cdiv(4 * n, 256)), dim3(256), 0, st, w.bup + (long)(l - 1) * 4 * n, p.up_b_ih[l - 1], p.up_b_hh[l - 1], (long)4 * n);
         SAT_TRY(launch_ok("bias add (stacked layer)"));
@@ -330,9 +330,7 @@ int decoder_fwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
 
     // bf16 mode, one layer: the per-step GEMMs read bf16 copies (state written by the cell kernel, gated context by the attention
     // kernel, weights cast here once) through the direct-to-LDS kernel instead of rounding fp32 operands in registers every step
-    const bool use_b = w.Hb != nullptr && attention_split_enabled();
     if (use_b) {
-        SAT_TRY(cast_bf16(st, w.Wcat, w.Wcat_b, (long)HCW * n));
         hipLaunchKernelGGL(cast_block_bf16_kernel, dim3(cdiv((long)4 * n * (D / 4), 256)), dim3(256), 0, st, p.w_ih + m, (long)(m + D), w.Wz_b, 4 * n, D);
         SAT_TRY(launch_ok("cast W_ih[:, m:]"));
         SAT_TRY(cast_bf16(st, Hs(0, 0), w.Hb, (long)N * n));
@@ -342,11 +340,14 @@ int decoder_fwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
 
     // tokens + embeddings + the embedding half of the LSTM input GEMM for every teacher-forced step, in one batch
     SAT_CHECK_HIP(hipMemsetAsync(w.Tok, 0xFF, (size_t)T1 * N * 4, st));       // -1: no token
-    for (int t = 0; t < ts; ++t)
-        if (b.teacher_host[t]) {
-            hipLaunchKernelGGL(teacher_tokens_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, b.caps, b.lengths, w.Tok + (long)t * N, N, d.T, t);
-            SAT_TRY(launch_ok("teacher_tokens"));
-        }
+    for (int t = 0; t < ts;) {          // one launch per run of teacher-forced steps (the whole caption when epsilon = 1)
+        if (!b.teacher_host[t]) { ++t; continue; }
+        int t1 = t + 1;
+        while (t1 < ts && b.teacher_host[t1]) ++t1;
+        hipLaunchKernelGGL(teacher_tokens_kernel, dim3(cdiv(N, 256), t1 - t), dim3(256), 0, st, b.caps, b.lengths, w.Tok + (long)t * N, N, d.T, t);
+        SAT_TRY(launch_ok("teacher_tokens"));
+        t = t1;
+    }
     auto renorm = [&](const int* tok, int count) -> int {
         if (!(d.embed_max_norm > 0.f)) return SAT_OK;
         hipLaunchKernelGGL(embedding_mark_kernel, dim3(cdiv(count, 256)), dim3(256), 0, st, tok, count, w.flags, d.V);
@@ -426,13 +427,8 @@ int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
     auto dCcs = [&](int l) { return w.dCc + (long)l * N * n; };
     float* const slab = w.slab; const long se = w.slab_elems;
 
-    SAT_CHECK_HIP(hipMemsetAsync(w.dU, 0, (size_t)d.B * d.L * A * 4, st));
-    SAT_CHECK_HIP(hipMemsetAsync(w.dwf_part, 0, (size_t)d.B * A * 4, st));
-    SAT_CHECK_HIP(hipMemsetAsync(w.dHc, 0, (size_t)NL * N * n * 4, st));
-    SAT_CHECK_HIP(hipMemsetAsync(w.dCc, 0, (size_t)NL * N * n * 4, st));
+    SAT_CHECK_HIP(hipMemsetAsync(w.zero_begin, 0, (size_t)(w.zero_end - w.zero_begin), st));       // dHout, dZout, dHc, dCc, dU, dwf_part
     if (NL > 1 && KR < T1 * N) SAT_CHECK_HIP(hipMemsetAsync(w.DGU, 0, (size_t)(NL - 1) * T1 * N * 4 * n * 4, st));
-    SAT_CHECK_HIP(hipMemsetAsync(w.dHout, 0, (size_t)T1 * N * n * 4, st));
-    SAT_CHECK_HIP(hipMemsetAsync(w.dZout, 0, (size_t)T1 * N * D * 4, st));
 
     // ---- output layer, all packed rows at once (DeepOutput backward)
     if (P > 0) {

@@ -104,9 +104,28 @@ __global__ void init_mean_rows_bwd_kernel(const float* __restrict__ drows, float
     dmean[o] = s;
 }
 
+// Packed per-step parameters in one launch: Wcat = [W_d ; W_beta ; W_hh] (A + D + 4n rows of n), its bf16 copy when the per-step GEMMs read
+// bf16 operands, and bcat = [0 ; b_beta ; b_ih + b_hh].
+__global__ void pack_wcat_kernel(const float* __restrict__ att_dec, const float* __restrict__ beta_w, const float* __restrict__ w_hh,
+                                 const float* __restrict__ beta_b, const float* __restrict__ b_ih, const float* __restrict__ b_hh, float* __restrict__ Wcat,
+                                 __bf16* __restrict__ Wcat_b, float* __restrict__ bcat, int A, int D, int n) {
+    const long HCW = (long)A + D + 4L * n, nw = HCW * n, e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < nw) {
+        const long r = e / n;
+        const float v = r < A ? att_dec[e] : (r < A + D ? beta_w[e - (long)A * n] : w_hh[e - (long)(A + D) * n]);
+        Wcat[e] = v;
+        if (Wcat_b) Wcat_b[e] = (__bf16)v;
+    } else if (e < nw + HCW) {
+        const long r = e - nw;
+        bcat[r] = r < A ? 0.f : (r < A + D ? beta_b[r - A] : b_ih[r - A - D] + b_hh[r - A - D]);
+    }
+}
+
 // token ids of step `step` for every caption row (teacher forcing): tok[i] = caps[i*T + step]
+// (grid.y > 1: steps step .. step + grid.y - 1 in one launch, tok advancing by N per step)
 __global__ void teacher_tokens_kernel(const int* __restrict__ caps, const int* __restrict__ lengths, int* __restrict__ tok, int N, int T, int step) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    step += blockIdx.y; tok += (long)blockIdx.y * N;
     if (i < N) tok[i] = (lengths[i] > step) ? caps[(long)i * T + step] : -1;     // finished captions feed nothing
 }
 
