@@ -272,6 +272,20 @@ def main():
         step()
     torch.cuda.synchronize()
     entries = sorted(_lib.profile_stop(), key=lambda e: -e["total_ms"])
+    # the same two steps with the encoder's weight gradients back on the main stream: in the product (and in the timed region) they run on a
+    # second HIP stream beside the data-gradient chain, and two kernels sharing the chip stretch each other's durations - these `alone` figures
+    # are each kernel's duration with the chip to itself (kernel quality), the others what actually ran
+    from sat_amd import encoder as _enc
+    side = _enc._WGRAD_STREAM
+    _enc._WGRAD_STREAM = False
+    step(); torch.cuda.synchronize()
+    _lib.profile_start()
+    for _ in range(prof_steps):
+        step()
+    torch.cuda.synchronize()
+    alone = _lib.profile_stop()
+    _enc._WGRAD_STREAM = side
+    step(); torch.cuda.synchronize()
     # the contraction core is ONE kernel family launched under ~20 template names (tile shape x operand form): rank it as one entry
     gemm = [e for e in entries if e["name"].startswith("gemm_")]
     fams = [e for e in entries if not e["name"].startswith("gemm_")]
@@ -349,6 +363,14 @@ def main():
                         "tflops": round(e["flops"] / (e["total_ms"] * 1e-3) / 1e12, 2) if e["total_ms"] > 0 else None,
                         "gbytes_per_s": round(e["bytes"] / (e["total_ms"] * 1e-3) / 1e9, 1) if e["total_ms"] > 0 else None}
 
+            sel_alone = [e for e in alone if (e["name"].startswith("gemm_") if dom["name"] == "gemm_*" else e["name"] == dom["name"])]
+            alone_row = None
+            if sel_alone and sum(e["total_ms"] for e in sel_alone) > 0:
+                a_ms = sum(e["total_ms"] for e in sel_alone); a_fl = sum(e["flops"] for e in sel_alone); a_by = sum(e["bytes"] for e in sel_alone)
+                a_val = (a_by / (a_ms * 1e-3) / 1e9) if hbm_bound else (a_fl / (a_ms * 1e-3) / 1e12)
+                alone_row = {"kernel": dom["name"], "achieved": round(a_val, 2), "frac": round(a_val / (PEAK_HBM_GBS if hbm_bound else peak), 4),
+                             "ms_per_step": round(a_ms / prof_steps, 3), "avg_launch_us": round(a_ms * 1e3 / sum(e["launches"] for e in sel_alone), 2),
+                             "what": "the same family over %d untimed steps with the second stream off (SAT_WGRAD_STREAM=0): every kernel has the chip to itself" % prof_steps}
             roof = {"bound": "hbm" if hbm_bound else "mfma", "kernel": dom["name"],
                     "achieved": round(gbs if hbm_bound else tf, 2), "peak": PEAK_HBM_GBS if hbm_bound else peak,
                     "unit": "GB/s" if hbm_bound else "TFLOP/s",
@@ -358,9 +380,11 @@ def main():
                     "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"], "flops_per_launch": dom["flops"] / dom["launches"],
                     "measured_on": ("HIP events on the launch stream around every launch of this family inside the timed region (on %d of its steps); "
                                     "`families` / `top`: every instrumented family over %d untimed steps before it; `gemm_*` = every template "
-                                    "of the contraction core (tile shape x operand form) summed" % (dom_steps, prof_steps)),
+                                    "of the contraction core (tile shape x operand form) summed; the encoder's weight-gradient launches run on a second stream beside the "
+                                    "data-gradient chain, so durations here include the stretch of sharing the chip (`alone` = without it)" % (dom_steps, prof_steps)),
                     "families": [row(e) for e in fams[:8]],
                     "top": [row(e) for e in entries[:8]],
+                    "alone": alone_row,
                     # the step as a whole: algorithmic FLOPs of SURVEY 8d (3 x forward contraction work) over the measured step time,
                     # and the HBM bytes of the committed PMC passes over the same step time
                     "step_tflop": round(step_tflop, 3), "step_tflops": round(step_tflop / (ms * 1e-3), 1),
