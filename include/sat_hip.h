@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SAT_HIP_ABI_VERSION 16
+#define SAT_HIP_ABI_VERSION 17
 
 int sat_abi_version(void);
 /* dev aid: after every kernel launch wait for the device and print the launch's name to stderr (a device fault then points at the
@@ -317,6 +317,12 @@ int sat_conv2d_dgrad_bf16(const void* dy, const void* w, void* dx, const sat_con
 size_t sat_conv2d_dgrad_stats_bytes(const sat_conv_geom* g);
 int sat_conv2d_dgrad_bf16_bnstats(const void* dy, const void* w, void* dx, const sat_conv_geom* g, int32_t accumulate, const void* bn_x,
                                   const uint8_t* bn_relu_mask, const float* bn_mean, const float* bn_invstd, float* tile_stats, int32_t* tile_rows, void* stream);
+/* The same launch joining a residual block's identity path: dx = dgrad(dy, w) + add_src, add_src (bf16, dx's shape: the gradient that arrived at
+ * the block's output) gated per element by the bits of add_mask (the block's final ReLU sign mask, or NULL) - the masked gradient is never
+ * written out on its own (torchvision Bottleneck / BasicBlock backward: out = relu(bn(...) + identity), model.py:19-29).  stride 1 only.
+ * bn_x = NULL: no statistics (the other bn_* / tile_* arguments are ignored). */
+int sat_conv2d_dgrad_bf16_fused(const void* dy, const void* w, void* dx, const sat_conv_geom* g, const void* add_src, const uint8_t* add_mask, const void* bn_x,
+                                const uint8_t* bn_relu_mask, const float* bn_mean, const float* bn_invstd, float* tile_stats, int32_t* tile_rows, void* stream);
 int sat_bn_train_bwd_tiles_bf16(const void* dy, const void* x, int64_t rows, int32_t C, const float* tile_stats, int32_t tile_rows, const float* save_mean,
                                 const float* save_invstd, const float* gamma, int32_t relu, void* dx, float* dgamma, float* dbeta, void* dres,
                                 int32_t dres_accumulate, const uint8_t* relu_mask, float* scratch, void* stream);

@@ -944,11 +944,15 @@ int sat_conv2d_fwd_bf16_stats(const void* x, const void* w, void* y, const sat_c
 
 struct BnBwdStats { const void* x; const unsigned char* mask; const float* mean; const float* invstd; float* tile_stats; int* tile_rows; };
 static int conv_dgrad_any(const void* dy, const void* w, void* dx, const sat_conv_geom* geom, int accumulate, int bf16, void* stream,
-                          const BnBwdStats* bs = nullptr) {
+                          const BnBwdStats* bs = nullptr, const void* add_src = nullptr, const uint8_t* add_mask = nullptr) {
     ConvGeom g; SAT_TRY(conv_geom(geom, g, bf16 ? 8 : 4));
     if (!dy || !w || !dx) return fail(SAT_EINVAL, "conv2d_dgrad: null pointer");
     GemmArgs a; a.a_bf16 = a.b_bf16 = a.c_bf16 = a.bf16_mfma = bf16;
     a.accumulate = accumulate; a.C = dx; a.ldc = g.C; a.g = g;
+    if (add_src) {
+        SAT_REQUIRE(bf16 && g.stride == 1, "conv2d_dgrad: add_src needs bf16 storage and stride 1");
+        a.accumulate = 1; a.add_src = add_src; a.add_mask = add_mask;
+    }
     if (bs) {
         *bs->tile_rows = 0;
         if (bf16 && !(g.stride == 2)) {          // (the stride-2 parity classes write interleaved rows: no tile statistics there)
@@ -984,6 +988,17 @@ int sat_conv2d_dgrad(const float* dy, const float* w, float* dx, const sat_conv_
 }
 int sat_conv2d_dgrad_bf16(const void* dy, const void* w, void* dx, const sat_conv_geom* geom, int accumulate, void* stream) {
     return conv_dgrad_any(dy, w, dx, geom, accumulate, 1, stream);
+}
+int sat_conv2d_dgrad_bf16_fused(const void* dy, const void* w, void* dx, const sat_conv_geom* geom, const void* add_src, const uint8_t* add_mask, const void* bn_x,
+                                const uint8_t* bn_relu_mask, const float* bn_mean, const float* bn_invstd, float* tile_stats, int32_t* tile_rows, void* stream) {
+    if (!add_src) return fail(SAT_EINVAL, "conv2d_dgrad_bf16_fused: null add_src (use sat_conv2d_dgrad_bf16[_bnstats])");
+    if (!bn_x) return conv_dgrad_any(dy, w, dx, geom, 1, 1, stream, nullptr, add_src, add_mask);
+    if (!bn_mean || !bn_invstd || !tile_stats || !tile_rows) return fail(SAT_EINVAL, "conv2d_dgrad_bf16_fused: null statistics pointer");
+    int tr = 0;
+    BnBwdStats bs{bn_x, bn_relu_mask, bn_mean, bn_invstd, tile_stats, &tr};
+    SAT_TRY(conv_dgrad_any(dy, w, dx, geom, 1, 1, stream, &bs, add_src, add_mask));
+    *tile_rows = tr;
+    return SAT_OK;
 }
 size_t sat_conv2d_dgrad_stats_bytes(const sat_conv_geom* geom) {
     ConvGeom g; if (conv_geom(geom, g, 8) != SAT_OK) return 0;

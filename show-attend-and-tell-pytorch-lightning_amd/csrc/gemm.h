@@ -57,6 +57,7 @@ struct GemmArgs {
     float* slab = nullptr; long slab_elems = 0;   // split-K scratch (optional)
     // bf16 data-gradient launches: BatchNorm-backward form of the tile statistics (see BArgs::bn_x in gemm_bf16_common.h)
     const void* bn_x = nullptr; const unsigned char* bn_mask = nullptr; const float* bn_mean = nullptr; const float* bn_invstd = nullptr;
+    const void* add_src = nullptr; const unsigned char* add_mask = nullptr;      // accumulate from this tensor (C's layout), gated by mask bits (see BArgs::add_src)
     float* tile_stats = nullptr; int* tile_rows = nullptr;   // bf16 kernels: per-row-tile column statistics of the stored result (see gemm_bf16_common.h); *tile_rows = rows per tile chosen, 0 if not produced
 };
 

@@ -356,6 +356,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
     SAT_REQUIRE(g.A && g.B && g.C, "gemm: null operand");
     if (g.bf16_mfma && gemm_bf16_eligible(g)) return launch_gemm_bf16(g, st);
     SAT_REQUIRE(!g.a_bf16 && !g.b_bf16 && !g.c_bf16, "gemm: bf16 operands need the bf16 MFMA kernel (16-byte gatherable shapes)");
+    SAT_REQUIRE(!g.add_src, "gemm: add_src is a bf16-storage feature");
     KArgs k;
     k.A = (const float*)g.A; k.lda = g.lda; k.a_rows = g.a_rows; k.B = (const float*)g.B; k.ldb = g.ldb;
     k.C = (float*)g.C; k.ldc = g.ldc; k.c_rows = g.c_rows; k.M = g.M; k.N = g.N; k.K = g.K;

@@ -33,6 +33,9 @@ struct BArgs {
     // (sum g, sum g * xhat) with g = stored value (masked by the ReLU sign bits when bn_mask is set) and xhat = (bn_x - mean) * invstd,
     // i.e. the partials of dbeta / dgamma of the BatchNorm whose OUTPUT gradient this launch writes.  bn_x / bn_mask share C's layout.
     const __bf16* bn_x = nullptr; const unsigned char* bn_mask = nullptr; const float* bn_mean = nullptr; const float* bn_invstd = nullptr;
+    // accumulate from ANOTHER tensor of C's layout (wide bf16 store only): C = result + add_src, add_src gated per element by the bits of add_mask
+    // when given - the identity path of a residual block joins its data gradient here without ever being written out masked
+    const __bf16* add_src = nullptr; const unsigned char* add_mask = nullptr;
 };
 
 template <typename T> struct VecN { static constexpr int n = 16 / sizeof(T); };
@@ -214,9 +217,11 @@ __device__ __forceinline__ void store_tile(const BArgs& a, f32x16 (&acc)[BM / 64
                 const long orow = a.g.cls ? class_row(a, row) : (long)row;
                 __bf16* dst = reinterpret_cast<__bf16*>(a.C) + orow * a.ldc + col;
                 if (a.accumulate) {
-                    bf16x8 old = *reinterpret_cast<const bf16x8*>(dst);
+                    const long off = orow * a.ldc + col;
+                    bf16x8 old = *reinterpret_cast<const bf16x8*>((a.add_src ? a.add_src : reinterpret_cast<const __bf16*>(a.C)) + off);
+                    const unsigned mb = a.add_mask ? (unsigned)a.add_mask[off >> 3] : 0xFFu;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (__bf16)((float)o[e] + (float)old[e]);
+                    for (int e = 0; e < 8; ++e) o[e] = (__bf16)((float)o[e] + (((mb >> e) & 1u) ? (float)old[e] : 0.f));
                 }
                 *reinterpret_cast<bf16x8*>(dst) = o;
                 bacc.add(j, o);
@@ -351,9 +356,11 @@ __device__ __forceinline__ void store_tile_w(const BArgs& a, f32x16 (&acc)[BM / 
                 const long orow = a.g.cls ? class_row(a, row) : (long)row;
                 __bf16* dst = reinterpret_cast<__bf16*>(a.C) + orow * a.ldc + col;
                 if (a.accumulate) {
-                    bf16x8 old = *reinterpret_cast<const bf16x8*>(dst);
+                    const long off = orow * a.ldc + col;
+                    bf16x8 old = *reinterpret_cast<const bf16x8*>((a.add_src ? a.add_src : reinterpret_cast<const __bf16*>(a.C)) + off);
+                    const unsigned mb = a.add_mask ? (unsigned)a.add_mask[off >> 3] : 0xFFu;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (__bf16)((float)o[e] + (float)old[e]);
+                    for (int e = 0; e < 8; ++e) o[e] = (__bf16)((float)o[e] + (((mb >> e) & 1u) ? (float)old[e] : 0.f));
                 }
                 *reinterpret_cast<bf16x8*>(dst) = o;
                 bacc.add(j, o);

@@ -130,15 +130,30 @@ def conv_fwd_stats(x, w, stride, pad, stride_w=0):
 _BN_BWD_EPILOGUE = os.environ.get("SAT_BN_BWD_EPILOGUE", "1") != "0"
 
 
-def conv_dgrad(dy, w, x_shape, stride, pad, out=None, accumulate=False, bn=None):
+def conv_dgrad(dy, w, x_shape, stride, pad, out=None, accumulate=False, bn=None, add=None):
     """``bn`` = (bn_input, (mean, invstd[, relu_mask])) of the BatchNorm(+ReLU) whose OUTPUT is this convolution's input: the launch then
     also leaves that BatchNorm's backward statistics per row tile (bf16 storage, stride 1) and the call returns (dx, tiles) with
-    tiles = (tile_stats, tile_rows) for ``bn_bwd(..., tiles=tiles)``, or (dx, None) when the launch could not produce them."""
+    tiles = (tile_stats, tile_rows) for ``bn_bwd(..., tiles=tiles)``, or (dx, None) when the launch could not produce them.
+    ``add`` = (tensor, relu_mask or None): dx = data gradient + tensor gated by the mask bits (bf16 storage, stride 1): the identity path of a
+    residual block (``sat_conv2d_dgrad_bf16_fused``)."""
     N, H, W, Cc = x_shape
     K, _, R, S = w.shape
     dx = out if out is not None else torch.empty(N, H, W, Cc, dtype=dy.dtype, device=dy.device)
     g = _geom(N, H, W, Cc, K, R, S, stride, pad)
     lib = L.lib()
+    if add is not None:
+        src, mask = add
+        assert _is_bf(dy) and stride == 1 and tuple(src.shape) == tuple(dx.shape) and src.is_contiguous() and src.dtype == BF16
+        stats, rows = None, C.c_int32(0)
+        bx = st = None
+        if bn is not None and _BN_BWD_EPILOGUE and bn[0] is not None and bn[0].dtype == BF16 and tuple(bn[0].shape) == tuple(dx.shape) and bn[0].is_contiguous():
+            bx, st = bn
+            stats = torch.empty(lib.sat_conv2d_dgrad_stats_bytes(C.byref(g)) // 4, dtype=torch.float32, device=dy.device)
+        L.check(lib.sat_conv2d_dgrad_bf16_fused(L.ptr(dy), L.ptr(_krsc(w)), L.ptr(dx), C.byref(g), L.ptr(src), L.ptr(mask), L.ptr(bx),
+                                                L.ptr(st[2] if st is not None and len(st) > 2 else None), L.ptr(st[0] if st is not None else None),
+                                                L.ptr(st[1] if st is not None else None), L.ptr(stats), C.byref(rows), L.stream_ptr()), "sat_conv2d_dgrad_bf16_fused")
+        tiles = (stats, rows.value) if (stats is not None and rows.value > 0) else None
+        return (dx, tiles) if bn is not None else dx
     if bn is not None:
         bx, st = bn
         if _BN_BWD_EPILOGUE and _is_bf(dy) and stride == 1 and bx is not None and bx.dtype == BF16 and tuple(bx.shape) == tuple(dx.shape) and bx.is_contiguous():
@@ -167,6 +182,8 @@ def _slab(device, nbytes, tag="main"):
 #: weight gradients of the residual blocks on a second HIP stream: they feed nothing on the backward chain (only the optimizer), and
 #: most of the chain's kernels leave matrix cores / HBM half idle, so the two streams fill each other's gaps
 _WGRAD_STREAM = os.environ.get("SAT_WGRAD_STREAM", "1") != "0"
+#: identity blocks: dx = dgrad + relu_mask(dout) inside the data-gradient launch (dev switch, SAT_DGRAD_JOIN=0 writes the masked gradient out)
+_DGRAD_JOIN = os.environ.get("SAT_DGRAD_JOIN", "1") != "0"
 _WGRAD_STREAMS = int(os.environ.get("SAT_WGRAD_STREAMS", "1"))          # side streams the launches are dealt to in turn
 _side_streams = {}
 
@@ -386,7 +403,11 @@ def _block_bwd(r, dout, grads, need_dx, W=None, dout_tiles=None, prev=None, queu
     writes this block's input gradient can produce.  Returns (dx, tiles for ``prev``'s last BatchNorm or None)."""
     W = W or (lambda p: p)
     blk = r.blk
-    g = torch.empty_like(r.out)                      # gradient of the residual branch (= dout masked by the final ReLU)
+    last_stats = r.s2 if blk.kind == "basic" else r.s3
+    # identity blocks in bf16 storage: the masked gradient of the residual branch is not written out at all - the launch that produces the
+    # block's input gradient reads dout and the ReLU sign bits itself (one pass over the block-wide tensor less)
+    join = _DGRAD_JOIN and blk.downsample is None and need_dx and _is_bf(dout) and last_stats is not None and len(last_stats) > 2 and last_stats[2] is not None and dout.is_contiguous()
+    g = None if join else torch.empty_like(r.out)    # gradient of the residual branch (= dout masked by the final ReLU)
     if blk.kind == "basic":
         dx2, grads[blk.bn2.weight], grads[blk.bn2.bias] = bn_bwd(dout, r.c2, r.out, r.s2, blk.bn2, True, dres=g, tiles=dout_tiles)
         grads[blk.conv2.weight] = conv_wgrad(dx2, r.a1, blk.conv2.weight, 1, 1, param=blk.conv2.weight, queue=queue)
@@ -416,6 +437,10 @@ def _block_bwd(r, dout, grads, need_dx, W=None, dout_tiles=None, prev=None, queu
     pbn = None
     if prev is not None and prev.out is r.x:
         pbn = (prev.c3, prev.s3) if prev.kind == "bottleneck" else (prev.c2, prev.s2)
+    if join:
+        if pbn is not None:
+            return conv_dgrad(dx1, W(first_w), r.x.shape, first_stride, first_pad, bn=pbn, add=(dout, last_stats[2]))
+        return conv_dgrad(dx1, W(first_w), r.x.shape, first_stride, first_pad, add=(dout, last_stats[2])), None
     if pbn is not None:
         return conv_dgrad(dx1, W(first_w), r.x.shape, first_stride, first_pad, out=g, accumulate=True, bn=pbn)
     return conv_dgrad(dx1, W(first_w), r.x.shape, first_stride, first_pad, out=g, accumulate=True), None

@@ -450,6 +450,43 @@ def test_bn_backward_statistics_from_the_dgrad_epilogue_equal_the_statistics_pas
     assert rel(dx_a, dx_b) <= 2e-3, rel(dx_a, dx_b)
 
 
+@pytest.mark.parametrize("kind,cin,planes,nb,hw", [("bottleneck", 256, 64, 8, 32), ("bottleneck", 512, 128, 5, 17), ("basic", 64, 64, 6, 24), ("basic", 128, 128, 3, 40)])
+def test_identity_path_joined_inside_the_data_gradient_launch_is_bit_identical(E, monkeypatch, kind, cin, planes, nb, hw):
+    """bf16 mode, identity blocks: dx = dgrad(conv1) + relu_mask(dout) formed by ``sat_conv2d_dgrad_bf16_fused`` reading dout and the sign bits
+    (no masked copy of dout is written) against the two-step path (BatchNorm backward writes the masked gradient, the data gradient
+    accumulates onto it).  The same values meet in the same fp32 add and one bf16 rounding, so every gradient must be equal bit for bit."""
+    torch.manual_seed(cin * 3 + planes)
+    g = torch.Generator().manual_seed(11 + cin)
+    blocks = [E.Block(kind, cin, planes, 1, 64), E.Block(kind, cin, planes, 1, 64)]
+    for b in blocks:
+        with torch.no_grad():
+            for p in b.parameters():
+                if p.dim() == 1:
+                    p.copy_(torch.rand(p.shape, generator=g) + 0.5)
+        E._channels_last_(b); b.cuda().train()
+    x = torch.randn(nb, hw, hw, cin, generator=g).cuda().to(torch.bfloat16)
+    dy = torch.randn(nb, hw, hw, cin, generator=g).cuda().to(torch.bfloat16)
+    cache = {}
+    Wt = lambda p: cache.setdefault(p, E.cast_bf16(p))              # noqa: E731
+
+    def run(join):
+        monkeypatch.setattr(E, "_DGRAD_JOIN", join)
+        r0 = E._block_fwd(blocks[0], x, True, Wt); r1 = E._block_fwd(blocks[1], r0.out, True, Wt)
+        grads = {}
+        keep = dy.clone()
+        d, tiles = E._block_bwd(r1, keep, grads, True, Wt, dout_tiles=None, prev=r0)
+        assert torch.equal(keep, dy), "the incoming gradient must not be modified"
+        d, _ = E._block_bwd(r0, d, grads, True, Wt, dout_tiles=tiles, prev=None)
+        return d.clone(), {k: v.clone() for k, v in grads.items()}
+
+    dx_a, ga = run(True)
+    dx_b, gb = run(False)
+    assert torch.equal(dx_a, dx_b)
+    names = {p: "%d.%s" % (i, k) for i, b in enumerate(blocks) for k, p in b.named_parameters()}
+    for p in ga:
+        assert torch.equal(ga[p], gb[p]), names[p]
+
+
 @pytest.mark.parametrize("N,H,W,C,K,R,stride,pad", [(4, 16, 16, 64, 64, 3, 1, 1), (3, 9, 9, 64, 256, 1, 1, 0), (2, 20, 20, 8, 64, 7, 2, 3),
                                                     (5, 13, 11, 128, 72, 3, 2, 1), (8, 32, 32, 64, 128, 3, 1, 1),
                                                     (2, 64, 64, 64, 64, 3, 1, 1), (3, 61, 59, 256, 64, 1, 1, 0),       # >= 8192 rows x 64 filters: 128x64 tiles
