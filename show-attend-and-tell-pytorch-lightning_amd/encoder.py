@@ -406,8 +406,11 @@ def _block_bwd(r, dout, grads, need_dx, W=None, dout_tiles=None, prev=None, queu
     last_stats = r.s2 if blk.kind == "basic" else r.s3
     # identity blocks in bf16 storage: the masked gradient of the residual branch is not written out at all - the launch that produces the
     # block's input gradient reads dout and the ReLU sign bits itself (one pass over the block-wide tensor less)
-    join = _DGRAD_JOIN and blk.downsample is None and need_dx and _is_bf(dout) and last_stats is not None and len(last_stats) > 2 and last_stats[2] is not None and dout.is_contiguous()
-    g = None if join else torch.empty_like(r.out)    # gradient of the residual branch (= dout masked by the final ReLU)
+    have_mask = _DGRAD_JOIN and _is_bf(dout) and last_stats is not None and len(last_stats) > 2 and last_stats[2] is not None and dout.is_contiguous()
+    join = have_mask and blk.downsample is None and need_dx
+    # projection blocks: the shortcut's BatchNorm backward masks dout with the same sign bits on the fly (its "ReLU" is the block's)
+    mask_ds = have_mask and blk.downsample is not None
+    g = None if (join or mask_ds) else torch.empty_like(r.out)    # gradient of the residual branch (= dout masked by the final ReLU)
     if blk.kind == "basic":
         dx2, grads[blk.bn2.weight], grads[blk.bn2.bias] = bn_bwd(dout, r.c2, r.out, r.s2, blk.bn2, True, dres=g, tiles=dout_tiles)
         grads[blk.conv2.weight] = conv_wgrad(dx2, r.a1, blk.conv2.weight, 1, 1, param=blk.conv2.weight, queue=queue)
@@ -424,7 +427,10 @@ def _block_bwd(r, dout, grads, need_dx, W=None, dout_tiles=None, prev=None, queu
     dx1, grads[blk.bn1.weight], grads[blk.bn1.bias] = bn_bwd(da1, r.c1, r.a1, r.s1, blk.bn1, True, tiles=t1)
     grads[first_w] = conv_wgrad(dx1, r.x, first_w, first_stride, first_pad, param=first_w, queue=queue)
     if blk.downsample is not None:
-        dxd, grads[blk.downsample[1].weight], grads[blk.downsample[1].bias] = bn_bwd(g, r.cd, None, r.sd, blk.downsample[1], False)
+        if mask_ds:
+            dxd, grads[blk.downsample[1].weight], grads[blk.downsample[1].bias] = bn_bwd(dout, r.cd, None, (r.sd[0], r.sd[1], last_stats[2]), blk.downsample[1], True)
+        else:
+            dxd, grads[blk.downsample[1].weight], grads[blk.downsample[1].bias] = bn_bwd(g, r.cd, None, r.sd, blk.downsample[1], False)
         grads[blk.downsample[0].weight] = conv_wgrad(dxd, r.x, blk.downsample[0].weight, blk.stride, 0, param=blk.downsample[0].weight, queue=queue)
         if not need_dx:
             return None, None

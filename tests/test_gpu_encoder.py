@@ -457,14 +457,16 @@ def test_identity_path_joined_inside_the_data_gradient_launch_is_bit_identical(E
     accumulates onto it).  The same values meet in the same fp32 add and one bf16 rounding, so every gradient must be equal bit for bit."""
     torch.manual_seed(cin * 3 + planes)
     g = torch.Generator().manual_seed(11 + cin)
-    blocks = [E.Block(kind, cin, planes, 1, 64), E.Block(kind, cin, planes, 1, 64)]
+    # a projection block (stride 2 shortcut: its BatchNorm backward masks dout on the fly) in front of an identity block
+    blocks = [E.Block(kind, cin // 2, planes, 2, 64), E.Block(kind, cin, planes, 1, 64)]
     for b in blocks:
         with torch.no_grad():
             for p in b.parameters():
                 if p.dim() == 1:
                     p.copy_(torch.rand(p.shape, generator=g) + 0.5)
         E._channels_last_(b); b.cuda().train()
-    x = torch.randn(nb, hw, hw, cin, generator=g).cuda().to(torch.bfloat16)
+    assert blocks[0].downsample is not None and blocks[1].downsample is None and blocks[0].cout == cin
+    x = torch.randn(nb, 2 * hw, 2 * hw, cin // 2, generator=g).cuda().to(torch.bfloat16)
     dy = torch.randn(nb, hw, hw, cin, generator=g).cuda().to(torch.bfloat16)
     cache = {}
     Wt = lambda p: cache.setdefault(p, E.cast_bf16(p))              # noqa: E731
