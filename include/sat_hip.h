@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SAT_HIP_ABI_VERSION 17
+#define SAT_HIP_ABI_VERSION 18
 
 int sat_abi_version(void);
 /* dev aid: after every kernel launch wait for the device and print the launch's name to stderr (a device fault then points at the
@@ -307,6 +307,13 @@ int sat_conv2d_fwd_bf16_stats(const void* x, const void* w, void* y, const sat_c
 int sat_bn_train_fwd_tiles_bf16(const void* x, int64_t rows, int32_t C, const float* tile_stats, int32_t tile_rows, const float* gamma,
                                 const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* save_mean,
                                 float* save_invstd, const void* residual, int32_t relu, void* y, uint8_t* relu_mask, float* scratch, void* stream);
+/* The same with the residual given RAW: residual_raw is the input of another train-mode BatchNorm (the projection shortcut of a ResNet block,
+ * statistics already in res_mean / res_invstd); y = relu(bn(x) + bn_res(residual_raw)) with the shortcut's normalised value rounded to bf16 as if it had
+ * been stored, but never written.  Bit-identical to sat_bn_train_fwd_tiles_bf16 on the materialised shortcut. */
+int sat_bn_train_fwd_tiles_bf16_resbn(const void* x, int64_t rows, int32_t C, const float* tile_stats, int32_t tile_rows, const float* gamma, const float* beta,
+                                      float eps, float momentum, float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                                      const void* residual_raw, const float* res_mean, const float* res_invstd, const float* res_gamma, const float* res_beta,
+                                      int32_t relu, void* y, uint8_t* relu_mask, float* scratch, void* stream);
 int sat_conv2d_dgrad_bf16(const void* dy, const void* w, void* dx, const sat_conv_geom* g, int32_t accumulate, void* stream);
 /* Data gradient that also leaves the BACKWARD statistics of the BatchNorm in front of this convolution: dx is the gradient of that
  * BatchNorm's (ReLU'd) output, so with its input bn_x (same NHWC shape as dx), the forward's ReLU sign mask (or NULL: no ReLU) and its

@@ -146,6 +146,8 @@ SYMBOLS.update({
     "sat_bn_eval_fwd_t": (C.c_int, [_i32, _vp, _i64, _i32, _vp, _vp, _f, _vp, _vp, _vp, _i32, _vp, _vp]),
     "sat_conv2d_dgrad_stats_bytes": (C.c_size_t, [C.POINTER(ConvGeom)]),
     "sat_conv2d_dgrad_bf16_bnstats": (C.c_int, [_vp, _vp, _vp, C.POINTER(ConvGeom), _i32, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _vp]),
+    "sat_bn_train_fwd_tiles_bf16_resbn": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                                   _i32, _vp, _vp, _vp, _vp]),
     "sat_conv2d_dgrad_bf16_fused": (C.c_int, [_vp, _vp, _vp, C.POINTER(ConvGeom), _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _vp]),
     "sat_bn_train_bwd_tiles_bf16": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "sat_bn_train_bwd_t": (C.c_int, [_i32, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
@@ -245,8 +247,8 @@ def lib():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(handle, name)          # AttributeError if the export is missing
             fn.restype, fn.argtypes = res, args
-        if handle.sat_abi_version() != 17:
-            raise SatHipError("libsat_hip.so ABI version %d != 17 (rebuild: make -C csrc)" % handle.sat_abi_version())
+        if handle.sat_abi_version() != 18:
+            raise SatHipError("libsat_hip.so ABI version %d != 18 (rebuild: make -C csrc)" % handle.sat_abi_version())
         _lib = handle
     return _lib
 

@@ -484,10 +484,13 @@ template <> __device__ __forceinline__ uint4 pack<__bf16, 8>(const float (&v)[8]
     for (int i = 0; i < 8; ++i) o[i] = (__bf16)v[i];
     return *reinterpret_cast<uint4*>(&o);
 }
-template <typename T, bool EVAL>
+// rbn (train mode): the residual is itself the INPUT of a BatchNorm (the projection shortcut) whose mean / invstd / gamma / beta follow in rbn -
+// its normalised value is formed here, rounded to the storage type as if it had been written out, and never touches HBM.
+struct ResBn { const float* mean; const float* invstd; const float* gamma; const float* beta; };
+template <typename T, bool EVAL, bool RBN = false>
 __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
                                 const float* __restrict__ gamma, const float* __restrict__ beta, const T* __restrict__ res, int relu,
-                                T* __restrict__ y, unsigned char* __restrict__ rmask, long totalv, int CV, float var_eps) {
+                                T* __restrict__ y, unsigned char* __restrict__ rmask, long totalv, int CV, float var_eps, ResBn rbn = ResBn{nullptr, nullptr, nullptr, nullptr}) {
     constexpr int E = EPT<T>::n;
     long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= totalv) return;
@@ -495,6 +498,10 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict
     float xv[E], rv[E], o[E];
     unpack<T, E>(reinterpret_cast<const uint4*>(x)[e], xv);
     if (res) unpack<T, E>(reinterpret_cast<const uint4*>(res)[e], rv);
+    if (RBN) {          // (its own instantiation: as a run-time branch it cost the plain kernel 4x - 157 instead of 36 us per launch)
+#pragma unroll
+        for (int i = 0; i < E; ++i) rv[i] = (float)(T)((rv[i] - rbn.mean[c0 + i]) * rbn.invstd[c0 + i] * rbn.gamma[c0 + i] + rbn.beta[c0 + i]);
+    }
     unsigned bits = 0;
 #pragma unroll
     for (int i = 0; i < E; ++i) {
@@ -1081,10 +1088,21 @@ extern "C" size_t sat_bn_scratch_bytes(int64_t rows, int32_t C) {
 }
 
 template <typename T>
+static inline void launch_bn_apply_train(const T* x, const float* mean, const float* invstd, const float* gamma, const float* beta, const T* residual, int relu, T* y,
+                                         uint8_t* relu_mask, long totalv, int CV, ResBn rbn, hipStream_t st) {
+    if (rbn.mean)
+        hipLaunchKernelGGL((bn_apply_kernel<T, false, true>), dim3(cdiv(totalv, 256)), dim3(256), 0, st, x, mean, invstd, gamma, beta, residual, relu, y, relu_mask, totalv, CV, -1.0f, rbn);
+    else
+        hipLaunchKernelGGL((bn_apply_kernel<T, false, false>), dim3(cdiv(totalv, 256)), dim3(256), 0, st, x, mean, invstd, gamma, beta, residual, relu, y, relu_mask, totalv, CV, -1.0f, rbn);
+}
+
+template <typename T>
 static int bn_train_fwd_t(const T* x, int64_t rows, int32_t C, const float* gamma, const float* beta, float eps, float momentum,
                           float* running_mean, float* running_var, float* save_mean, float* save_invstd, const T* residual, int32_t relu,
-                          T* y, uint8_t* relu_mask, float* scratch, hipStream_t st, const float* tile_stats = nullptr, int tile_rows = 0) {
+                          T* y, uint8_t* relu_mask, float* scratch, hipStream_t st, const float* tile_stats = nullptr, int tile_rows = 0,
+                          ResBn rbn = ResBn{nullptr, nullptr, nullptr, nullptr}) {
     if (!x || !gamma || !beta || !save_mean || !save_invstd || !scratch) return fail(SAT_EINVAL, "bn_train_fwd: null pointer");
+    SAT_REQUIRE(!rbn.mean || (residual && rbn.invstd && rbn.gamma && rbn.beta), "bn_train_fwd: the residual's BatchNorm needs the residual and all four vectors");
     SAT_REQUIRE(y || (!residual && !relu_mask), "bn_train_fwd: statistics only (y = NULL) takes no residual / mask");
     SAT_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, "bn_train_fwd: rows=%ld C=%d (C must be a multiple of 4)", (long)rows, C);
     constexpr int E = EPT<T>::n;
@@ -1103,7 +1121,7 @@ static int bn_train_fwd_t(const T* x, int64_t rows, int32_t C, const float* gamm
             if (!y) return SAT_OK;                   // statistics only: the caller normalises inside its own kernel (stem tail)
             long totalv = rows * (C / E);
             ProfScope prof("bn_apply_fwd", 0.0, (double)rows * C * (sizeof(T) * (residual ? 3 : 2) + (relu_mask ? 0.125 : 0.0)), st);
-            hipLaunchKernelGGL((bn_apply_kernel<T, false>), dim3(cdiv(totalv, 256)), dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta, residual, relu, y, relu_mask, totalv, C / E, -1.0f);
+            launch_bn_apply_train<T>(x, save_mean, save_invstd, gamma, beta, residual, relu, y, relu_mask, totalv, C / E, rbn, st);
             return launch_ok("bn_apply");
         }
         if (ntiles <= fuse_upto) {
@@ -1113,7 +1131,7 @@ static int bn_train_fwd_t(const T* x, int64_t rows, int32_t C, const float* gamm
             if (!y) return SAT_OK;                   // statistics only: the caller normalises inside its own kernel (stem tail)
             long totalv = rows * (C / E);
             ProfScope prof("bn_apply_fwd", 0.0, (double)rows * C * (sizeof(T) * (residual ? 3 : 2) + (relu_mask ? 0.125 : 0.0)), st);
-            hipLaunchKernelGGL((bn_apply_kernel<T, false>), dim3(cdiv(totalv, 256)), dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta, residual, relu, y, relu_mask, totalv, C / E, -1.0f);
+            launch_bn_apply_train<T>(x, save_mean, save_invstd, gamma, beta, residual, relu, y, relu_mask, totalv, C / E, rbn, st);
             return launch_ok("bn_apply");
         }
         int np = cdiv(ntiles, 64); if (np > nparts) np = nparts; if (np < 1) np = 1;          // partials fit the scratch sized for nparts
@@ -1129,7 +1147,7 @@ static int bn_train_fwd_t(const T* x, int64_t rows, int32_t C, const float* gamm
             if (!y) return SAT_OK;
             long totalv = rows * (C / E);
             ProfScope prof("bn_apply_fwd", 0.0, (double)rows * C * (sizeof(T) * (residual ? 3 : 2) + (relu_mask ? 0.125 : 0.0)), st);
-            hipLaunchKernelGGL((bn_apply_kernel<T, false>), dim3(cdiv(totalv, 256)), dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta, residual, relu, y, relu_mask, totalv, C / E, -1.0f);
+            launch_bn_apply_train<T>(x, save_mean, save_invstd, gamma, beta, residual, relu, y, relu_mask, totalv, C / E, rbn, st);
             return launch_ok("bn_apply");
         }
         hipLaunchKernelGGL(bn_tile_reduce_kernel, dim3(cdiv(C, 32), np), dim3(256), 0, st, tile_stats, ntiles, C, per, p0, p1);
@@ -1146,7 +1164,7 @@ static int bn_train_fwd_t(const T* x, int64_t rows, int32_t C, const float* gamm
     if (!y) return SAT_OK;
     long totalv = rows * (C / E);
     ProfScope prof("bn_apply_fwd", 0.0, (double)rows * C * (sizeof(T) * (residual ? 3 : 2) + (relu_mask ? 0.125 : 0.0)), st);
-    hipLaunchKernelGGL((bn_apply_kernel<T, false>), dim3(cdiv(totalv, 256)), dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta, residual, relu, y, relu_mask, totalv, C / E, -1.0f);
+    launch_bn_apply_train<T>(x, save_mean, save_invstd, gamma, beta, residual, relu, y, relu_mask, totalv, C / E, rbn, st);
     return launch_ok("bn_apply");
 }
 
@@ -1308,6 +1326,14 @@ int sat_bn_train_fwd_tiles_bf16(const void* x, int64_t rows, int32_t C, const fl
     if (!tile_stats) return fail(SAT_EINVAL, "bn_train_fwd_tiles: null statistics");
     return bn_train_fwd_t<bf>((const bf*)x, rows, C, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, (const bf*)residual, relu,
                               (bf*)y, relu_mask, scratch, (hipStream_t)stream, tile_stats, tile_rows);
+}
+int sat_bn_train_fwd_tiles_bf16_resbn(const void* x, int64_t rows, int32_t C, const float* tile_stats, int32_t tile_rows, const float* gamma, const float* beta,
+                                      float eps, float momentum, float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                                      const void* residual_raw, const float* res_mean, const float* res_invstd, const float* res_gamma, const float* res_beta,
+                                      int32_t relu, void* y, uint8_t* relu_mask, float* scratch, void* stream) {
+    if (!tile_stats || !residual_raw || !res_mean || !res_invstd || !res_gamma || !res_beta) return fail(SAT_EINVAL, "bn_train_fwd_tiles_resbn: null pointer");
+    return bn_train_fwd_t<bf>((const bf*)x, rows, C, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, (const bf*)residual_raw, relu,
+                              (bf*)y, relu_mask, scratch, (hipStream_t)stream, tile_stats, tile_rows, ResBn{res_mean, res_invstd, res_gamma, res_beta});
 }
 int sat_bn_train_fwd(const float* x, int64_t rows, int32_t C, const float* gamma, const float* beta, float eps, float momentum,
                      float* running_mean, float* running_var, float* save_mean, float* save_invstd, const float* residual, int32_t relu,

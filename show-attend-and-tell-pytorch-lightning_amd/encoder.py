@@ -184,6 +184,8 @@ def _slab(device, nbytes, tag="main"):
 _WGRAD_STREAM = os.environ.get("SAT_WGRAD_STREAM", "1") != "0"
 #: identity blocks: dx = dgrad + relu_mask(dout) inside the data-gradient launch (dev switch, SAT_DGRAD_JOIN=0 writes the masked gradient out)
 _DGRAD_JOIN = os.environ.get("SAT_DGRAD_JOIN", "1") != "0"
+#: projection blocks, forward: the shortcut's BatchNorm is applied inside the last BatchNorm's kernel (dev switch, SAT_FWD_RES_BN=0 writes it out)
+_FWD_RES_BN = os.environ.get("SAT_FWD_RES_BN", "1") != "0"
 _WGRAD_STREAMS = int(os.environ.get("SAT_WGRAD_STREAMS", "1"))          # side streams the launches are dealt to in turn
 _side_streams = {}
 
@@ -268,10 +270,29 @@ _tracked = []      # num_batches_tracked buffers touched by the running whole-en
 _defer = [False]
 
 
-def bn_fwd(x, bn, residual=None, relu=True, training=True, want_mask=False, tiles=None):
+def bn_stats(x, bn, tiles):
+    """Training-mode statistics of a BatchNorm from the producing convolution's row tiles, nothing normalised: (mean, invstd); the running
+    statistics move as in nn.BatchNorm2d.  (bf16 storage; the caller normalises inside another kernel, see ``bn_fwd(res_bn=...)``.)"""
+    lib = L.lib()
+    Cc = x.shape[-1]; rows = x.numel() // Cc
+    mean = torch.empty(Cc, dtype=torch.float32, device=x.device); invstd = torch.empty_like(mean)
+    scratch = torch.empty(lib.sat_bn_scratch_bytes(rows, Cc) // 8 + 1, dtype=torch.float64, device=x.device)
+    mom = 0.1 if bn.momentum is None else float(bn.momentum)
+    L.check(lib.sat_bn_train_fwd_tiles_bf16(L.ptr(x), rows, Cc, L.ptr(tiles[0]), int(tiles[1]), L.ptr(bn.weight), L.ptr(bn.bias), float(bn.eps),
+                                            mom, L.ptr(bn.running_mean), L.ptr(bn.running_var), L.ptr(mean), L.ptr(invstd), None, 0, None, None,
+                                            L.ptr(scratch), L.stream_ptr()), "sat_bn_train_fwd_tiles (statistics)")
+    if _defer[0]:
+        _tracked.append(bn.num_batches_tracked)
+    else:
+        bn.num_batches_tracked += 1
+    return mean, invstd
+
+
+def bn_fwd(x, bn, residual=None, relu=True, training=True, want_mask=False, tiles=None, res_bn=None):
     """BatchNorm (+ residual) (+ ReLU) of a (..., C) NHWC tensor.  Returns (y, stats); in training mode stats =
     (mean, invstd[, relu_mask]) -- with ``want_mask`` the sign mask of the output (1 bit per element) that ``bn_bwd``
-    reads instead of y."""
+    reads instead of y.  ``res_bn`` = ((mean, invstd), module): ``residual`` is the RAW input of that train-mode BatchNorm (the projection
+    shortcut), normalised on the fly (``sat_bn_train_fwd_tiles_bf16_resbn``)."""
     lib = L.lib()
     Cc = x.shape[-1]; rows = x.numel() // Cc
     y = torch.empty_like(x)
@@ -281,7 +302,14 @@ def bn_fwd(x, bn, residual=None, relu=True, training=True, want_mask=False, tile
         mean = torch.empty(Cc, dtype=torch.float32, device=x.device); invstd = torch.empty_like(mean)
         scratch = torch.empty(lib.sat_bn_scratch_bytes(rows, Cc) // 8 + 1, dtype=torch.float64, device=x.device)
         mom = 0.1 if bn.momentum is None else float(bn.momentum)
-        if tiles is not None and dt == 1:          # statistics already reduced per row tile by the producing convolution
+        if res_bn is not None:
+            assert tiles is not None and dt == 1 and residual is not None
+            (rmean, rinv), rmod = res_bn
+            L.check(lib.sat_bn_train_fwd_tiles_bf16_resbn(L.ptr(x), rows, Cc, L.ptr(tiles[0]), int(tiles[1]), L.ptr(bn.weight), L.ptr(bn.bias), float(bn.eps),
+                                                          mom, L.ptr(bn.running_mean), L.ptr(bn.running_var), L.ptr(mean), L.ptr(invstd), L.ptr(residual),
+                                                          L.ptr(rmean), L.ptr(rinv), L.ptr(rmod.weight), L.ptr(rmod.bias), int(relu), L.ptr(y), L.ptr(mask),
+                                                          L.ptr(scratch), L.stream_ptr()), "sat_bn_train_fwd_tiles_bf16_resbn")
+        elif tiles is not None and dt == 1:          # statistics already reduced per row tile by the producing convolution
             L.check(lib.sat_bn_train_fwd_tiles_bf16(L.ptr(x), rows, Cc, L.ptr(tiles[0]), int(tiles[1]), L.ptr(bn.weight), L.ptr(bn.bias), float(bn.eps),
                                                     mom, L.ptr(bn.running_mean), L.ptr(bn.running_var), L.ptr(mean), L.ptr(invstd), L.ptr(residual),
                                                     int(relu), L.ptr(y), L.ptr(mask), L.ptr(scratch), L.stream_ptr()), "sat_bn_train_fwd_tiles")
@@ -380,20 +408,30 @@ def _block_fwd(blk, x, training, W=None):
     r.cd = r.sd = None
     # training: the convolution's epilogue leaves the BatchNorm statistics of its output (bf16 storage), see conv_fwd_stats
     conv = conv_fwd_stats if training else (lambda *a: (conv_fwd(*a), None))
-    if blk.downsample is not None:
-        r.cd, tl = conv(x, W(blk.downsample[0].weight), blk.stride, 0)
-        r.idn, r.sd = bn_fwd(r.cd, blk.downsample[1], None, False, training, tiles=tl)
-    else:
-        r.idn = x
     if blk.kind == "basic":
         r.c1, tl = conv(x, W(blk.conv1.weight), blk.stride, 1); r.a1, r.s1 = bn_fwd(r.c1, blk.bn1, None, True, training, want_mask=True, tiles=tl)
-        r.c2, tl = conv(r.a1, W(blk.conv2.weight), 1, 1)
-        r.out, r.s2 = bn_fwd(r.c2, blk.bn2, r.idn, True, training, want_mask=True, tiles=tl)
+        last, tl = conv(r.a1, W(blk.conv2.weight), 1, 1); r.c2 = last
     else:
         r.c1, tl = conv(x, W(blk.conv1.weight), 1, 0); r.a1, r.s1 = bn_fwd(r.c1, blk.bn1, None, True, training, want_mask=True, tiles=tl)
         r.c2, tl = conv(r.a1, W(blk.conv2.weight), blk.stride, 1); r.a2, r.s2 = bn_fwd(r.c2, blk.bn2, None, True, training, want_mask=True, tiles=tl)
-        r.c3, tl = conv(r.a2, W(blk.conv3.weight), 1, 0)
-        r.out, r.s3 = bn_fwd(r.c3, blk.bn3, r.idn, True, training, want_mask=True, tiles=tl)
+        last, tl = conv(r.a2, W(blk.conv3.weight), 1, 0); r.c3 = last
+    res_bn = None
+    if blk.downsample is not None:
+        r.cd, tld = conv(x, W(blk.downsample[0].weight), blk.stride, 0)
+        if _FWD_RES_BN and training and tl is not None and tld is not None and _is_bf(r.cd):
+            # projection shortcut: only its statistics are taken here; the last BatchNorm's kernel normalises r.cd on the fly
+            r.sd = bn_stats(r.cd, blk.downsample[1], tld)
+            r.idn, res_bn = r.cd, (r.sd, blk.downsample[1])
+        else:
+            r.idn, r.sd = bn_fwd(r.cd, blk.downsample[1], None, False, training, tiles=tld)
+    else:
+        r.idn = x
+    last_bn = blk.bn2 if blk.kind == "basic" else blk.bn3
+    r.out, st = bn_fwd(last, last_bn, r.idn, True, training, want_mask=True, tiles=tl, res_bn=res_bn)
+    if blk.kind == "basic":
+        r.s2 = st
+    else:
+        r.s3 = st
     return r
 
 

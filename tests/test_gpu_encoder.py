@@ -489,6 +489,44 @@ def test_identity_path_joined_inside_the_data_gradient_launch_is_bit_identical(E
         assert torch.equal(ga[p], gb[p]), names[p]
 
 
+@pytest.mark.parametrize("kind,cin,planes,stride,nb,hw", [("bottleneck", 64, 64, 1, 6, 24), ("bottleneck", 256, 128, 2, 4, 34), ("basic", 64, 128, 2, 5, 26)])
+def test_projection_shortcut_normalised_inside_the_last_batchnorm_kernel_is_bit_identical(E, monkeypatch, kind, cin, planes, stride, nb, hw):
+    """bf16 mode, projection blocks: relu(bn_last(c) + bn_shortcut(cd)) with the shortcut's BatchNorm applied inside the last BatchNorm's kernel
+    (``sat_bn_train_fwd_tiles_bf16_resbn``, the normalised shortcut rounded to bf16 as if stored) against the path that writes the shortcut out:
+    outputs, saved statistics, running statistics and every gradient equal bit for bit."""
+    import copy
+    torch.manual_seed(cin + 7 * planes)
+    g = torch.Generator().manual_seed(3 + cin)
+    proto = E.Block(kind, cin, planes, stride, 64)
+    with torch.no_grad():
+        for p in proto.parameters():
+            if p.dim() == 1:
+                p.copy_(torch.rand(p.shape, generator=g) + 0.5)
+    assert proto.downsample is not None
+    x = torch.randn(nb, hw, hw, cin, generator=g).cuda().to(torch.bfloat16)
+
+    def run(fused):
+        monkeypatch.setattr(E, "_FWD_RES_BN", fused)
+        blk = copy.deepcopy(proto); E._channels_last_(blk); blk.cuda().train()
+        cache = {}
+        Wt = lambda p: cache.setdefault(p, E.cast_bf16(p))              # noqa: E731
+        r = E._block_fwd(blk, x, True, Wt)
+        dy = torch.randn(r.out.shape, generator=torch.Generator().manual_seed(5)).cuda().to(torch.bfloat16)
+        grads = {}
+        d, _ = E._block_bwd(r, dy, grads, True, Wt)
+        names = {p: k for k, p in blk.named_parameters()}
+        bufs = {k: v.clone() for k, v in blk.named_buffers()}
+        return r.out.clone(), d.clone(), {names[p]: v.clone() for p, v in grads.items()}, bufs
+
+    out_a, d_a, g_a, b_a = run(True)
+    out_b, d_b, g_b, b_b = run(False)
+    assert torch.equal(out_a, out_b) and torch.equal(d_a, d_b)
+    for k in g_b:
+        assert torch.equal(g_a[k], g_b[k]), k
+    for k in b_b:
+        assert torch.equal(b_a[k], b_b[k]), k
+
+
 @pytest.mark.parametrize("N,H,W,C,K,R,stride,pad", [(4, 16, 16, 64, 64, 3, 1, 1), (3, 9, 9, 64, 256, 1, 1, 0), (2, 20, 20, 8, 64, 7, 2, 3),
                                                     (5, 13, 11, 128, 72, 3, 2, 1), (8, 32, 32, 64, 128, 3, 1, 1),
                                                     (2, 64, 64, 64, 64, 3, 1, 1), (3, 61, 59, 256, 64, 1, 1, 0),       # >= 8192 rows x 64 filters: 128x64 tiles
