@@ -487,74 +487,138 @@ template <> __device__ __forceinline__ uint4 pack<__bf16, 8>(const float (&v)[8]
 // rbn (train mode): the residual is itself the INPUT of a BatchNorm (the projection shortcut) whose mean / invstd / gamma / beta follow in rbn -
 // its normalised value is formed here, rounded to the storage type as if it had been written out, and never touches HBM.
 struct ResBn { const float* mean; const float* invstd; const float* gamma; const float* beta; };
-template <typename T, bool EVAL, bool RBN = false>
+template <typename T, bool EVAL, bool RBN = false, int VPT = 1>
 __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
                                 const float* __restrict__ gamma, const float* __restrict__ beta, const T* __restrict__ res, int relu,
-                                T* __restrict__ y, unsigned char* __restrict__ rmask, long totalv, int CV, float var_eps, ResBn rbn = ResBn{nullptr, nullptr, nullptr, nullptr}) {
+                                T* __restrict__ y, unsigned char* __restrict__ rmask, long totalv, int CV, float var_eps, ResBn rbn = ResBn{nullptr, nullptr, nullptr, nullptr},
+                                long part = 0) {
     constexpr int E = EPT<T>::n;
-    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= totalv) return;
+    if (VPT == 1) part = totalv;
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= part) return;
     const int c0 = (totalv <= 0xffffffffL ? (int)((unsigned)e % (unsigned)CV) : (int)(e % CV)) * E;      // a 64-bit modulo costs ~100 instructions per lane
-    float xv[E], rv[E], o[E];
-    unpack<T, E>(reinterpret_cast<const uint4*>(x)[e], xv);
-    if (res) unpack<T, E>(reinterpret_cast<const uint4*>(res)[e], rv);
-    if (RBN) {          // (its own instantiation: as a run-time branch it cost the plain kernel 4x - 157 instead of 36 us per launch)
+    // VPT vectors per thread, `part` vectors apart (a multiple of CV: same channels), all loads issued before the first use
+    uint4 xr[VPT], rr[VPT];
 #pragma unroll
-        for (int i = 0; i < E; ++i) rv[i] = (float)(T)((rv[i] - rbn.mean[c0 + i]) * rbn.invstd[c0 + i] * rbn.gamma[c0 + i] + rbn.beta[c0 + i]);
+    for (int k = 0; k < VPT; ++k) {
+        const long idx = e + k * part;
+        if (idx < totalv) { xr[k] = reinterpret_cast<const uint4*>(x)[idx]; if (res) rr[k] = reinterpret_cast<const uint4*>(res)[idx]; }
     }
-    unsigned bits = 0;
+    float isd[E], gm[E], mu[E], bt[E];
 #pragma unroll
     for (int i = 0; i < E; ++i) {
         float is = invstd[c0 + i];
         if (EVAL) is = 1.f / sqrtf(is + var_eps);      // eval mode only: the training pass gets invstd from the finalize kernel
-        float v = (xv[i] - mean[c0 + i]) * is * gamma[c0 + i] + beta[c0 + i];
-        if (res) v += rv[i];
-        bits |= (v > 0.f ? 1u : 0u) << i;
-        o[i] = relu ? (v < 0.f ? 0.f : v) : v;            // like torch's ReLU a NaN stays a NaN (fmaxf would turn it into 0 and hide it)
+        isd[i] = is; gm[i] = gamma[c0 + i]; mu[i] = mean[c0 + i]; bt[i] = beta[c0 + i];
     }
-    if (rmask) {
-        if (E == 8) rmask[e] = (unsigned char)bits;
-        else {               // fp32: two lanes make a byte (totalv is even: the mask needs C % 8 == 0)
-            const unsigned other = __shfl_xor(bits, 1, 64);
-            if (!(threadIdx.x & 1)) rmask[e >> 1] = (unsigned char)(bits | (other << 4));
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+        const long idx = e + k * part;
+        if (idx >= totalv) continue;
+        float xv[E], rv[E], o[E];
+        unpack<T, E>(xr[k], xv);
+        if (res) unpack<T, E>(rr[k], rv);
+        if (RBN) {          // (its own instantiation: as a run-time branch it cost the plain kernel 4x - 157 instead of 36 us per launch)
+#pragma unroll
+            for (int i = 0; i < E; ++i) rv[i] = (float)(T)((rv[i] - rbn.mean[c0 + i]) * rbn.invstd[c0 + i] * rbn.gamma[c0 + i] + rbn.beta[c0 + i]);
         }
+        unsigned bits = 0;
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            float v = (xv[i] - mu[i]) * isd[i] * gm[i] + bt[i];          // this association everywhere (the stem-tail kernel must match bit for bit)
+            if (res) v += rv[i];
+            bits |= (v > 0.f ? 1u : 0u) << i;
+            o[i] = relu ? (v < 0.f ? 0.f : v) : v;            // like torch's ReLU a NaN stays a NaN (fmaxf would turn it into 0 and hide it)
+        }
+        if (rmask) {
+            if (E == 8) rmask[idx] = (unsigned char)bits;
+            else {               // fp32: two lanes make a byte (totalv and part are even: the mask needs C % 8 == 0)
+                const unsigned other = __shfl_xor(bits, 1, 64);
+                if (!(threadIdx.x & 1)) rmask[idx >> 1] = (unsigned char)(bits | (other << 4));
+            }
+        }
+        reinterpret_cast<uint4*>(y)[idx] = pack<T, E>(o);
     }
-    reinterpret_cast<uint4*>(y)[e] = pack<T, E>(o);
 }
 
 // dx = gamma * invstd * (g - dbeta/M - xhat * dgamma/M);  dres (optional) receives g (the masked upstream gradient)
-template <typename T>
+// VPT vectors per thread, `part` vectors apart (a multiple of CV: the same channels, so the per-channel factors are formed once), every load
+// issued before the first use.
+template <typename T, int VPT>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
                                     const unsigned char* __restrict__ rmask, const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ gamma, const float* __restrict__ dbeta, const float* __restrict__ dgamma, int relu,
-                                    float inv_rows, T* __restrict__ dx, T* __restrict__ dres, int dres_accumulate, long totalv, int CV) {
+                                    float inv_rows, T* __restrict__ dx, T* __restrict__ dres, int dres_accumulate, long totalv, int CV, long part) {
     constexpr int E = EPT<T>::n;
-    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= totalv) return;
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= part) return;
     const int c0 = (totalv <= 0xffffffffL ? (int)((unsigned)e % (unsigned)CV) : (int)(e % CV)) * E;      // a 64-bit modulo costs ~100 instructions per lane
-    float xv[E], g[E], yv[E], o[E];
-    unpack<T, E>(reinterpret_cast<const uint4*>(x)[e], xv);
-    unpack<T, E>(reinterpret_cast<const uint4*>(dy)[e], g);
-    if (relu) {
-        if (rmask) mask_to_floats<E>(rmask, e, yv);
-        else unpack<T, E>(reinterpret_cast<const uint4*>(y)[e], yv);
+    uint4 xr[VPT], gr[VPT], yr[VPT], rr[VPT]; unsigned mb[VPT];
 #pragma unroll
-        for (int i = 0; i < E; ++i) g[i] = yv[i] > 0.f ? g[i] : 0.f;
+    for (int k = 0; k < VPT; ++k) {
+        const long idx = e + k * part;
+        if (idx < totalv) {
+            xr[k] = reinterpret_cast<const uint4*>(x)[idx]; gr[k] = reinterpret_cast<const uint4*>(dy)[idx];
+            if (relu) {
+                if (rmask) mb[k] = (E == 8) ? rmask[idx] : (unsigned)(rmask[idx >> 1] >> ((idx & 1) * 4));
+                else yr[k] = reinterpret_cast<const uint4*>(y)[idx];
+            }
+            if (dres && dres_accumulate) rr[k] = reinterpret_cast<const uint4*>(dres)[idx];
+        }
     }
+    float fa[E], fb[E], fc[E], mu[E];
 #pragma unroll
     for (int i = 0; i < E; ++i) {
         const float is = invstd[c0 + i];
-        o[i] = gamma[c0 + i] * is * (g[i] - dbeta[c0 + i] * inv_rows - (xv[i] - mean[c0 + i]) * is * dgamma[c0 + i] * inv_rows);
+        fa[i] = gamma[c0 + i] * is; fb[i] = dbeta[c0 + i] * inv_rows; fc[i] = is * dgamma[c0 + i] * inv_rows; mu[i] = mean[c0 + i];
     }
-    reinterpret_cast<uint4*>(dx)[e] = pack<T, E>(o);
-    if (dres) {
-        if (dres_accumulate) {
-            float r[E];
-            unpack<T, E>(reinterpret_cast<const uint4*>(dres)[e], r);
 #pragma unroll
-            for (int i = 0; i < E; ++i) g[i] += r[i];
+    for (int k = 0; k < VPT; ++k) {
+        const long idx = e + k * part;
+        if (idx >= totalv) continue;
+        float xv[E], g[E], o[E];
+        unpack<T, E>(xr[k], xv); unpack<T, E>(gr[k], g);
+        if (relu) {
+            if (rmask) {
+#pragma unroll
+                for (int i = 0; i < E; ++i) g[i] = ((mb[k] >> i) & 1u) ? g[i] : 0.f;
+            } else {
+                float yv[E]; unpack<T, E>(yr[k], yv);
+#pragma unroll
+                for (int i = 0; i < E; ++i) g[i] = yv[i] > 0.f ? g[i] : 0.f;
+            }
         }
-        reinterpret_cast<uint4*>(dres)[e] = pack<T, E>(g);
+#pragma unroll
+        for (int i = 0; i < E; ++i) o[i] = fa[i] * (g[i] - fb[i] - (xv[i] - mu[i]) * fc[i]);
+        reinterpret_cast<uint4*>(dx)[idx] = pack<T, E>(o);
+        if (dres) {
+            if (dres_accumulate) {
+                float r[E];
+                unpack<T, E>(rr[k], r);
+#pragma unroll
+                for (int i = 0; i < E; ++i) g[i] += r[i];
+            }
+            reinterpret_cast<uint4*>(dres)[idx] = pack<T, E>(g);
+        }
+    }
+}
+template <typename T>
+static inline void launch_bn_bwd_apply(const T* x, const T* dy, const T* y, const uint8_t* rmask, const float* mean, const float* invstd, const float* gamma,
+                                       const float* dbeta, const float* dgamma, int relu, float inv_rows, T* dx, T* dres, int dres_accumulate, long rows, int CV,
+                                       hipStream_t st) {
+    const long totalv = rows * CV;
+    const int vpt = dev_switch(SW_BN_VPT);
+    if (vpt >= 4 && rows >= 16384) {
+        const long part = ((rows + 3) / 4) * CV;
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 4>), dim3(cdiv(part, 256)), dim3(256), 0, st, x, dy, y, rmask, mean, invstd, gamma, dbeta, dgamma, relu, inv_rows, dx, dres,
+                           dres_accumulate, totalv, CV, part);
+    } else if (vpt >= 2 && rows >= 4096) {
+        const long part = ((rows + 1) / 2) * CV;
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 2>), dim3(cdiv(part, 256)), dim3(256), 0, st, x, dy, y, rmask, mean, invstd, gamma, dbeta, dgamma, relu, inv_rows, dx, dres,
+                           dres_accumulate, totalv, CV, part);
+    } else {
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1>), dim3(cdiv(totalv, 256)), dim3(256), 0, st, x, dy, y, rmask, mean, invstd, gamma, dbeta, dgamma, relu, inv_rows, dx, dres,
+                           dres_accumulate, totalv, CV, totalv);
     }
 }
 
@@ -1090,10 +1154,18 @@ extern "C" size_t sat_bn_scratch_bytes(int64_t rows, int32_t C) {
 template <typename T>
 static inline void launch_bn_apply_train(const T* x, const float* mean, const float* invstd, const float* gamma, const float* beta, const T* residual, int relu, T* y,
                                          uint8_t* relu_mask, long totalv, int CV, ResBn rbn, hipStream_t st) {
+    const long rows = totalv / CV;
+    const int vpt = dev_switch(SW_BN_VPT);
     if (rbn.mean)
-        hipLaunchKernelGGL((bn_apply_kernel<T, false, true>), dim3(cdiv(totalv, 256)), dim3(256), 0, st, x, mean, invstd, gamma, beta, residual, relu, y, relu_mask, totalv, CV, -1.0f, rbn);
-    else
-        hipLaunchKernelGGL((bn_apply_kernel<T, false, false>), dim3(cdiv(totalv, 256)), dim3(256), 0, st, x, mean, invstd, gamma, beta, residual, relu, y, relu_mask, totalv, CV, -1.0f, rbn);
+        hipLaunchKernelGGL((bn_apply_kernel<T, false, true>), dim3(cdiv(totalv, 256)), dim3(256), 0, st, x, mean, invstd, gamma, beta, residual, relu, y, relu_mask, totalv, CV, -1.0f, rbn, totalv);
+    else if (vpt >= 4 && rows >= 16384) {
+        const long part = ((rows + 3) / 4) * CV;
+        hipLaunchKernelGGL((bn_apply_kernel<T, false, false, 4>), dim3(cdiv(part, 256)), dim3(256), 0, st, x, mean, invstd, gamma, beta, residual, relu, y, relu_mask, totalv, CV, -1.0f, rbn, part);
+    } else if (vpt >= 2 && rows >= 4096) {
+        const long part = ((rows + 1) / 2) * CV;
+        hipLaunchKernelGGL((bn_apply_kernel<T, false, false, 2>), dim3(cdiv(part, 256)), dim3(256), 0, st, x, mean, invstd, gamma, beta, residual, relu, y, relu_mask, totalv, CV, -1.0f, rbn, part);
+    } else
+        hipLaunchKernelGGL((bn_apply_kernel<T, false, false>), dim3(cdiv(totalv, 256)), dim3(256), 0, st, x, mean, invstd, gamma, beta, residual, relu, y, relu_mask, totalv, CV, -1.0f, rbn, totalv);
 }
 
 template <typename T>
@@ -1228,8 +1300,7 @@ static int bn_train_bwd_t(const T* dy, const T* x, const T* y, int64_t rows, int
     }
     long totalv = rows * (C / E);
     ProfScope prof("bn_apply_bwd", 0.0, (double)rows * C * (sizeof(T) * (3 + (dres ? (dres_accumulate ? 2 : 1) : 0)) + (relu ? (relu_mask ? 0.125 : (double)sizeof(T)) : 0.0)), st);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(cdiv(totalv, 256)), dim3(256), 0, st, x, dy, y, relu_mask, save_mean, save_invstd, gamma, dbeta, dgamma, relu,
-                       1.0f / (float)rows, dx, dres, dres_accumulate, totalv, C / E);
+    launch_bn_bwd_apply<T>(x, dy, y, relu_mask, save_mean, save_invstd, gamma, dbeta, dgamma, relu, 1.0f / (float)rows, dx, dres, dres_accumulate, (long)rows, C / E, st);
     return launch_ok("bn_bwd_apply");
 }
 
