@@ -511,6 +511,11 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict
         if (EVAL) is = 1.f / sqrtf(is + var_eps);      // eval mode only: the training pass gets invstd from the finalize kernel
         isd[i] = is; gm[i] = gamma[c0 + i]; mu[i] = mean[c0 + i]; bt[i] = beta[c0 + i];
     }
+    float rmu[RBN ? E : 1], ris[RBN ? E : 1], rgm[RBN ? E : 1], rbt[RBN ? E : 1];
+    if (RBN) {          // (its own instantiation: as a run-time branch it cost the plain kernel 4x - 157 instead of 36 us per launch)
+#pragma unroll
+        for (int i = 0; i < E; ++i) { rmu[i] = rbn.mean[c0 + i]; ris[i] = rbn.invstd[c0 + i]; rgm[i] = rbn.gamma[c0 + i]; rbt[i] = rbn.beta[c0 + i]; }
+    }
 #pragma unroll
     for (int k = 0; k < VPT; ++k) {
         const long idx = e + k * part;
@@ -518,9 +523,9 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict
         float xv[E], rv[E], o[E];
         unpack<T, E>(xr[k], xv);
         if (res) unpack<T, E>(rr[k], rv);
-        if (RBN) {          // (its own instantiation: as a run-time branch it cost the plain kernel 4x - 157 instead of 36 us per launch)
+        if (RBN) {
 #pragma unroll
-            for (int i = 0; i < E; ++i) rv[i] = (float)(T)((rv[i] - rbn.mean[c0 + i]) * rbn.invstd[c0 + i] * rbn.gamma[c0 + i] + rbn.beta[c0 + i]);
+            for (int i = 0; i < E; ++i) rv[i] = (float)(T)((rv[i] - rmu[i]) * ris[i] * rgm[i] + rbt[i]);
         }
         unsigned bits = 0;
 #pragma unroll
@@ -1156,7 +1161,10 @@ static inline void launch_bn_apply_train(const T* x, const float* mean, const fl
                                          uint8_t* relu_mask, long totalv, int CV, ResBn rbn, hipStream_t st) {
     const long rows = totalv / CV;
     const int vpt = dev_switch(SW_BN_VPT);
-    if (rbn.mean)
+    if (rbn.mean && vpt >= 2 && rows >= 4096) {
+        const long part = ((rows + 1) / 2) * CV;
+        hipLaunchKernelGGL((bn_apply_kernel<T, false, true, 2>), dim3(cdiv(part, 256)), dim3(256), 0, st, x, mean, invstd, gamma, beta, residual, relu, y, relu_mask, totalv, CV, -1.0f, rbn, part);
+    } else if (rbn.mean)
         hipLaunchKernelGGL((bn_apply_kernel<T, false, true>), dim3(cdiv(totalv, 256)), dim3(256), 0, st, x, mean, invstd, gamma, beta, residual, relu, y, relu_mask, totalv, CV, -1.0f, rbn, totalv);
     else if (vpt >= 4 && rows >= 16384) {
         const long part = ((rows + 3) / 4) * CV;
