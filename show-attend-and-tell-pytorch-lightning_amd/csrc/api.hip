@@ -12,7 +12,8 @@ int& dev_switch(int which) {
     static int v[SW_COUNT] = {getenv("SAT_BN_TICKET") ? atoi(getenv("SAT_BN_TICKET")) : 0, getenv("SAT_NO_WGRAD3X3") ? !atoi(getenv("SAT_NO_WGRAD3X3")) : 1,
                               getenv("SAT_REDUCE_Z16") ? atoi(getenv("SAT_REDUCE_Z16")) : 1, getenv("SAT_WIDE_TILES") ? atoi(getenv("SAT_WIDE_TILES")) : 0,
                               getenv("SAT_BN_ONEPASS") ? atoi(getenv("SAT_BN_ONEPASS")) : 1,
-                              getenv("SAT_BN_VPT") ? atoi(getenv("SAT_BN_VPT")) : 2};
+                              getenv("SAT_BN_VPT") ? atoi(getenv("SAT_BN_VPT")) : 2,
+                              getenv("SAT_ACC_PREFETCH") ? atoi(getenv("SAT_ACC_PREFETCH")) : 0};
     return v[which];
 }
 int& trace_launches() { static int on = getenv("SAT_TRACE_LAUNCH") ? 1 : 0; return on; }
@@ -34,6 +35,7 @@ int sat_debug_option(const char* name, int32_t value) {
     if (!strcmp(name, "bn_ticket")) { dev_switch(SW_BN_TICKET) = value; return SAT_OK; }
     if (!strcmp(name, "wgrad3x3")) { dev_switch(SW_WGRAD3X3) = value; return SAT_OK; }
     if (!strcmp(name, "reduce_z16")) { dev_switch(SW_REDUCE_Z16) = value; return SAT_OK; }
+    if (!strcmp(name, "acc_prefetch")) { dev_switch(SW_ACC_PREFETCH) = value; return SAT_OK; }
     if (!strcmp(name, "bn_vpt")) { dev_switch(SW_BN_VPT) = value; return SAT_OK; }
     if (!strcmp(name, "bn_onepass")) { dev_switch(SW_BN_ONEPASS) = value; return SAT_OK; }
     if (!strcmp(name, "wide_tiles")) { dev_switch(SW_WIDE_TILES) = value; return SAT_OK; }

@@ -397,6 +397,7 @@ static int launch_gemm_bf16_tile(const GemmArgs& g, int tile_mode, hipStream_t s
         k.bn_x = reinterpret_cast<const __bf16*>(g.bn_x); k.bn_mask = g.bn_mask; k.bn_mean = g.bn_mean; k.bn_invstd = g.bn_invstd;
     }
 
+    k.acc_prefetch = dev_switch(SW_ACC_PREFETCH);
     if (g.add_src) {
         SAT_REQUIRE(g.c_bf16 && k.wide_store && k.nsplit == 1 && g.accumulate && al16(g.add_src) && (!g.add_mask || g.ldc % 8 == 0),
                     "gemm_bf16: add_src needs an accumulating bf16 launch on the 16-byte store path (M=%d N=%d ldc=%ld)", g.M, g.N, g.ldc);

@@ -36,6 +36,7 @@ struct BArgs {
     // accumulate from ANOTHER tensor of C's layout (wide bf16 store only): C = result + add_src, add_src gated per element by the bits of add_mask
     // when given - the identity path of a residual block joins its data gradient here without ever being written out masked
     const __bf16* add_src = nullptr; const unsigned char* add_mask = nullptr;
+    int acc_prefetch = 1;      // dev switch: accumulating bf16 launches take the instantiation that fetches the old values before the write loop
 };
 
 template <typename T> struct VecN { static constexpr int n = 16 / sizeof(T); };
@@ -143,7 +144,7 @@ struct BnAcc {
 // Accumulator tile -> C.  acc[i][j] is the 32x32 MFMA block (i, j) of this wave's (BM/2 x BN/2) quadrant at (wm, wn);
 // C/D layout of v_mfma_f32_32x32x16_bf16: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
 // `smem` is the kernel's operand staging area (free once the k loop is over), `smem_elems` its size in bf16.
-template <int BM, int BN, typename TC, int SMEM_ELEMS>
+template <int BM, int BN, typename TC, int SMEM_ELEMS, bool APF = false>
 __device__ __forceinline__ void store_tile(const BArgs& a, f32x16 (&acc)[BM / 64][BN / 64], __bf16* smem, int bm, int bn, int bz, int wm, int wn,
                                            int tid, int lane, BnAcc<BM, BN, NT>& bacc, bool prefetched /* statistics operands fetched by the caller already */) {
     constexpr int TM = BM / 64, TN = BN / 64;
@@ -206,8 +207,24 @@ __device__ __forceinline__ void store_tile(const BArgs& a, f32x16 (&acc)[BM / 64
                     if (odd) { pk[0] = (__bf16)got; pk[1] = (__bf16)v1; } else { pk[0] = (__bf16)v0; pk[1] = (__bf16)got; }
                     *reinterpret_cast<bf16x2*>(cs + (lr0 + (odd ? 1 : 0)) * LDC + (lc & ~1)) = pk;
                 }
-        __syncthreads();
         constexpr int VPR = BN / 8;
+        // APF (accumulating launches, their own instantiation): the old values of this thread's segments, all in flight before the write loop -
+        // inside it every load waits behind the previous iteration's store to the same array (the compiler must assume they alias).  The
+        // registers cost the third workgroup per CU, which is why the non-accumulating launches keep the plain instantiation.
+        constexpr int NJO = APF ? BM * VPR / NT : 1;
+        bf16x8 oldv[NJO]; unsigned mbv[NJO];
+        if constexpr (APF) {
+            const __bf16* osrc = a.add_src ? a.add_src : reinterpret_cast<const __bf16*>(a.C);
+#pragma unroll
+            for (int j = 0; j < NJO; ++j) {
+                const int v = tid + j * NT, row = bm + v / VPR, col = bn + (v % VPR) * 8;
+                const bool ok = row < a.M && col < a.N;
+                const long off = ok ? (a.g.cls ? class_row(a, row) : (long)row) * a.ldc + col : 0;
+                oldv[j] = *reinterpret_cast<const bf16x8*>(osrc + off);
+                mbv[j] = a.add_mask ? (unsigned)a.add_mask[off >> 3] : 0xFFu;
+            }
+        }
+        __syncthreads();
 #pragma unroll
         for (int j = 0; j < BM * VPR / NT; ++j) {
             int v = tid + j * NT, lr = v / VPR, lc = (v % VPR) * 8;
@@ -218,8 +235,12 @@ __device__ __forceinline__ void store_tile(const BArgs& a, f32x16 (&acc)[BM / 64
                 __bf16* dst = reinterpret_cast<__bf16*>(a.C) + orow * a.ldc + col;
                 if (a.accumulate) {
                     const long off = orow * a.ldc + col;
-                    bf16x8 old = *reinterpret_cast<const bf16x8*>((a.add_src ? a.add_src : reinterpret_cast<const __bf16*>(a.C)) + off);
-                    const unsigned mb = a.add_mask ? (unsigned)a.add_mask[off >> 3] : 0xFFu;
+                    bf16x8 old; unsigned mb;
+                    if constexpr (APF) { old = oldv[j]; mb = mbv[j]; }
+                    else {
+                        old = *reinterpret_cast<const bf16x8*>((a.add_src ? a.add_src : reinterpret_cast<const __bf16*>(a.C)) + off);
+                        mb = a.add_mask ? (unsigned)a.add_mask[off >> 3] : 0xFFu;
+                    }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] = (__bf16)((float)o[e] + (((mb >> e) & 1u) ? (float)old[e] : 0.f));
                 }

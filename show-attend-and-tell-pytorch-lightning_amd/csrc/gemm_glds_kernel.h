@@ -89,7 +89,7 @@ struct PixEnt { int off; unsigned mask; };   // wgrad: byte offset of the input 
 // WR x WC waves per workgroup; wave (wr, wc) owns the (BM / WR) x (BN / WC) block of the tile.  2 x 2 waves on 128x128 (and 128x64,
 // 64x64) is the original form; 4 x 2 waves on 256x128 and 256x256 tiles (one workgroup per CU) halve the L2 -> LDS traffic per
 // product and, on 256x256, read 6 LDS fragments per 8 MFMAs instead of 4 per 4.
-template <int BM, int BN, int WR, int WC, int AM, int BMo, typename TC>
+template <int BM, int BN, int WR, int WC, int AM, int BMo, typename TC, bool APF = false>
 __global__ __launch_bounds__(64 * WR * WC) void gemm_glds_kernel(BArgs a) {
     constexpr int KB = 64;
     constexpr int NW = WR * WC;
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_glds_kernel(BArgs a) {
             for (int j = 0; j < TN; ++j) keep_alive(acc[i][j]);
         return;
     }
-    if constexpr (WR == 2 && WC == 2) store_tile<BM, BN, TC, 2 * STAGE>(a, acc, smem, bm, bn, bz, wm, wn, tid, lane, bnacc, sizeof(TC) == 2);
+    if constexpr (WR == 2 && WC == 2) store_tile<BM, BN, TC, 2 * STAGE, APF>(a, acc, smem, bm, bn, bz, wm, wn, tid, lane, bnacc, sizeof(TC) == 2);
     else store_tile_w<BM, BN, WR, WC, TC>(a, acc, smem, bm, bn, bz, wm, wn, wrow, tid, lane, bnacc, sizeof(TC) == 2);      // the launch allocates at least the epilogue's staging size
 }
 
@@ -436,6 +436,27 @@ static int rung(const BArgs& k, hipStream_t st) {
         SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BM, BN, WR, WC, AM, BMo, TC>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)LDS_DYN_MAX));
         attr_set = true;
+    }
+    // accumulating bf16 launches of the data-gradient forms (identity joins, projection sums): the instantiation whose epilogue has the old values in flight
+    // MEASURED (tools/ab_step.py, C2 step): 22.52 ms with it, 22.20 ms without - the registers of the old values (214 VGPRs) take the third workgroup per CU
+    // from these launches and that costs more than the serialised loads; with the prefetch inside the ONE instantiation every launch lost the third
+    // workgroup (25.3 ms).  Compiled out unless SAT_GLDS_APF is defined.
+#ifndef SAT_GLDS_APF
+#define SAT_GLDS_APF 0
+#endif
+    constexpr bool HAS_APF = SAT_GLDS_APF && sizeof(TC) == 2 && WR == 2 && WC == 2 && BM == 128 && BM * (BN / 8) / 256 <= 8 &&
+                             ((AM == A_ROW && BMo == B_KMAJOR) || AM == A_CONV_DGRAD);
+    if constexpr (HAS_APF) {
+        if (k.accumulate && k.acc_prefetch && k.wide_store && k.nsplit == 1) {
+            static bool attr_apf = false;
+            if (!attr_apf) {
+                SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BM, BN, WR, WC, AM, BMo, TC, true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_DYN_MAX));
+                attr_apf = true;
+            }
+            hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WR, WC, AM, BMo, TC, true>), grid, dim3(64 * WR * WC), lds, st, k);
+            return launch_ok("gemm_glds_kernel (accumulate)");
+        }
     }
     hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WR, WC, AM, BMo, TC>), grid, dim3(64 * WR * WC), lds, st, k);
     SAT_TRY(launch_ok("gemm_glds_kernel"));
