@@ -240,7 +240,10 @@ def main():
     img, caps, lengths = synthetic_batch(B, R, T, hp["vocab_size"], 1234 + rank, args.ragged)
     img, caps = img.to(dev), caps.to(dev)
 
+    steps_run = [0]
+
     def step():
+        steps_run[0] += 1
         opt.zero_grad(set_to_none=True)
         out = model.training_step((img, caps, lengths), 0)
         out["loss"].backward()
@@ -395,7 +398,7 @@ def main():
                 roof["step_hbm_gb"] = round(gb, 2)
                 roof["step_hbm_frac"] = round(gb / (ms * 1e-3) / PEAK_HBM_GBS, 4)
         line = {"metric": "captions/sec (train step) at B=128, 256px, seq_len=22", "value": round(caps_per_s, 1), "unit": "captions/s",
-                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_steps_run": warm_done, "ms_per_step": round(ms, 3), "higher_is_better": True,
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_steps_run": warm_done, "train_steps_in_process": steps_run[0], "ms_per_step": round(ms, 3), "higher_is_better": True,
                 "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
                 "config": {"workload": "%s: %s encoder_size=%s encoder_dim=%d vocab=%d T=%d, %d images/GPU x R=%d captions, "
                                        "trainable encoder, Adam, %s lengths, decoder_tf=%s" % (args.config.upper(), CONFIGS[args.config][0],

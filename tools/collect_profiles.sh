@@ -13,8 +13,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o run -- p
 cp "$out/trace/run_kernel_stats.csv" "$out/kernel_stats.csv"; rm -rf "$out/trace"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_fetch" -o run -- python3 $B > "$out/bench_fetch.json" 2> "$out/fetch.log" || exit 3
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/pmc_write" -o run -- python3 $B > "$out/bench_write.json" 2> "$out/write.log" || exit 4
-sf=$(python3 -c "import json,sys; d=json.loads([l for l in open('$out/bench_fetch.json') if l.startswith('{')][-1]); print(d.get('warmup_steps_run', d['warmup']) + 2 + d['steps'])")
-sw=$(python3 -c "import json,sys; d=json.loads([l for l in open('$out/bench_write.json') if l.startswith('{')][-1]); print(d.get('warmup_steps_run', d['warmup']) + 2 + d['steps'])")
+sf=$(python3 -c "import json,sys; d=json.loads([l for l in open('$out/bench_fetch.json') if l.startswith('{')][-1]); print(d['train_steps_in_process'])")
+sw=$(python3 -c "import json,sys; d=json.loads([l for l in open('$out/bench_write.json') if l.startswith('{')][-1]); print(d['train_steps_in_process'])")
 cd "$root" && python3 tools/pmc_aggregate.py "$out/pmc_fetch" "$out/pmc_write" "$out/pmc_hbm.json" $sf $sw > "$out/pmc_aggregate.log" 2>&1 || exit 5
 rm -rf "$out/pmc_fetch" "$out/pmc_write"
 tail -2 "$out/pmc_aggregate.log"; tail -c 600 "$out/bench_plain.json"

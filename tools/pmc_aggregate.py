@@ -4,8 +4,8 @@ request for wide coalesced streaming reads, so the read side is doubled.
 
     python tools/pmc_aggregate.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r02_bf16_bench_c2_pmc_hbm.json [steps_fetch steps_write]
 
-``steps_*`` = train steps the profiled command ran in each pass (warm-up + 2 profile + timed: the bench line's
-``warmup_steps_run`` + 2 + ``steps``; the warm-up is time-based, so the two passes differ).  Written as a ``__meta__`` row so that
+``steps_*`` = train steps the profiled command ran in each pass (the bench line's ``train_steps_in_process``: warm-up + profile + timed
+steps; the warm-up is time-based, so the two passes differ).  Written as a ``__meta__`` row so that
 bench.py can state HBM bytes per step.
 """
 import collections, csv, glob, json, re, sys
