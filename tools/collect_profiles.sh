@@ -4,7 +4,7 @@
 # (rocprofv3 needs the program itself after "--", and --pmc runs alone with --kernel-trace: see README "profiling")
 set -o pipefail
 cfg=${1:-c2}; shift
-root=$(pwd); out=$root/gpurun_out/prof_$cfg; rm -rf "$out"; mkdir -p "$out"
+root=$(pwd); out=$root/gpurun_out/prof_$cfg${TAG:+_$TAG}; rm -rf "$out"; mkdir -p "$out"
 export TMPDIR=/tmp
 B="$root/bench.py --config $cfg --steps 20 --warmup 5 --no-cpu-baseline --no-extras $*"
 cd /tmp
