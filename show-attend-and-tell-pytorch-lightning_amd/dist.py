@@ -69,6 +69,7 @@ class GradSync:
         self._handles = []
         self.buckets = []
         self._sig = None
+        self._early = set()              # diagnostics: indices of the buckets launched from inside the encoder backward this step
         self._build()
 
     # ------------------------------------------------------------------ construction
@@ -160,6 +161,7 @@ class GradSync:
                     ok = False
                     break
             if ok:
+                self._early.add(self.buckets.index(b))
                 self._launch(b)
 
     def _launch(self, b):
@@ -195,6 +197,7 @@ class GradSync:
             for p in b.params:
                 if p.grad is None:                               # unused this step: the mean of the ranks' zeros / gradients
                     p.grad = b.view(p)
+        self._early = set()
 
 
 def default_buckets(model):
