@@ -14,7 +14,8 @@ decisions agree and what remains is accumulation-order noise:
            statistics from the rounded convolution output, in fp32; stem tail = bn1 -> relu -> maxpool, pooled map -> bf16;
            1x1 projection: bf16 x bf16 -> fp32 annotations + fp32 bias, the incoming gradient is cast to bf16 for its GEMMs;
   decoder  every Linear / LSTM product rounds both operands to bf16 (fp32 accumulate) in forward and in both backward GEMMs;
-           pointwise kernels (attention scores / softmax / context, cell, losses) are fp32.
+           the attention context (and its backward, dalpha) reads a bf16 copy of the annotations; everything else pointwise
+           (scores / softmax, cell, losses) is fp32.
 
 Only tests import this file."""
 import contextlib
@@ -143,14 +144,28 @@ class _F:
         return _LinearBF16.apply(x, w, b)
 
 
+def _soft_attention_bf16(sd, ann, h):
+    """``O.soft_attention`` (model.py:94-109) with the annotations of the CONTEXT product rounded to bf16: the HIP path keeps a bf16 copy of the
+    annotations for the two kernels that stream them every time step (context forward, dalpha backward); scores, softmax, sums are fp32 and the
+    gradient that reaches the annotations through the context (alpha x dz) is not rounded."""
+    N, D, H, W = ann.shape
+    a = ann.reshape(N, D, H * W).permute(0, 2, 1)
+    u = O.F.linear(a, sd["attention.encoder_att.weight"])
+    q = O.F.linear(h, sd["attention.decoder_att.weight"]).unsqueeze(1)
+    s = O.F.linear(torch.tanh(u + q), sd["attention.f_att.weight"]) * a.shape[1] ** -0.5
+    alpha = F.softmax(s, dim=1)
+    z = (rf(a) * alpha).sum(dim=1)
+    return z, alpha.permute(0, 2, 1).reshape(N, H, W)
+
+
 @contextlib.contextmanager
 def decoder_bf16_products():
-    old = O.F
-    O.F = _F()
+    old, old_att = O.F, O.soft_attention
+    O.F = _F(); O.soft_attention = _soft_attention_bf16
     try:
         yield
     finally:
-        O.F = old
+        O.F = old; O.soft_attention = old_att
 
 
 def step_loss(oracle, img, caps, lengths, epsilon=1.0, draw=None):

@@ -12,7 +12,8 @@ int decoder_fwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
 int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sat_decoder_batch& b, const float* dlogits,
                 const float* alphas, const float* dalphas, const sat_decoder_params& g, float* dann, char* ws, size_t ws_bytes, hipStream_t st);
 int launch_attention_fwd(hipStream_t st, const float* ann, const float* U, const float* hc, int hc_ld, const float* wf,
-                         const int* lengths, int step, float* alphas, int T1, float* Z, float* XZ, int B, int R, int L, int D, int A, float* sc = nullptr, void* xzb = nullptr);
+                         const int* lengths, int step, float* alphas, int T1, float* Z, float* XZ, int B, int R, int L, int D, int A, float* sc = nullptr, void* xzb = nullptr,
+                         const void* annb = nullptr);
 size_t decoder_infer_workspace_bytes(const sat_decoder_dims& d, int Kmax);
 int decoder_infer_begin(const sat_decoder_dims& d, const sat_decoder_params& p, const float* ann, int K, int Kmax, float* h, float* c,
                         char* ws, size_t ws_bytes, hipStream_t st);

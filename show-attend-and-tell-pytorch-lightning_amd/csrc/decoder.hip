@@ -17,6 +17,7 @@ struct Ws {
     float *Udrop, *mean_rows, *f_rows, *init_rows, *df_rows;     // only carved when dropout > 0
     float *GU, *DGU, *bup;                                       // stacked LSTM layers (layers > 1): gates, gate grads, bias sums
     __bf16 *Wb_out, *Ub;                                         // bf16 mode: bf16 copies of output.output.weight and of the packed deep-output rows
+    __bf16 *annb;                                                // bf16 mode: annotations as the attention context / dalpha kernels stream them
     __bf16 *Hb, *XZb, *Wcat_b, *Wz_b, *DHCb;                            // bf16 mode, one LSTM layer: operands of the per-step GEMMs (state, gated context, weights)
     int* Tok; int* flags;
     int *emb_count, *emb_offset, *emb_cursor, *emb_list;         // embedding gradient: per-row token segments
@@ -63,6 +64,8 @@ Ws layout(const sat_decoder_dims& d, char* base) {
         w.Wb_out = (__bf16*)take((size_t)d.V * d.m, 2); w.Ub = (__bf16*)take((size_t)(d.P > 0 ? d.P : 1) * d.m, 2);
     }
     w.Hb = w.XZb = w.Wcat_b = w.Wz_b = w.DHCb = nullptr;
+    // bf16 mode: a bf16 copy of the annotations for the two kernels that stream them every time step (attention context / dalpha)
+    w.annb = (d.precision && d.D % 4 == 0) ? (__bf16*)take((size_t)d.B * d.L * d.D, 2) : nullptr;
     if (d.precision && d.layers == 1 && d.n % 64 == 0 && d.D % 64 == 0 && d.A % 4 == 0 && d.m % 4 == 0) {
         w.Hb = (__bf16*)take((size_t)(T1 + 1) * N * d.n, 2); w.XZb = (__bf16*)take((size_t)N * d.D, 2);
         w.Wcat_b = (__bf16*)take((size_t)HCW * d.n, 2); w.Wz_b = (__bf16*)take((size_t)4 * d.n * d.D, 2);
@@ -165,42 +168,53 @@ static int live_steps(const sat_decoder_dims& d, const sat_decoder_batch& b) {
 static size_t att_fwd_lds(int L, int A, int vw) { return (size_t)(ATT_RMAX * L + ATT_RMAX * A + A + ATT_RMAX * ATT_THREADS * vw) * 4; }
 static size_t att_bwd_lds(int L, int A, int D) { return (size_t)(2 * ATT_RMAX * L + ATT_RMAX * A + A + ATT_RMAX * D + ATTB_WAVES * ATT_RMAX * A + ATTB_WAVES * A) * 4; }
 
+static bool ann_bf16_enabled() { static const bool off = getenv("SAT_ANN_BF16") && !atoi(getenv("SAT_ANN_BF16")); return !off; }      // dev switch
 static bool attention_split_enabled() {
     static const int no_split = getenv("SAT_ATT_FUSED") ? atoi(getenv("SAT_ATT_FUSED")) : 0;
     return !no_split;
 }
-template <int RN>
-static int attention_fwd_split(hipStream_t st, const float* ann, const float* U, const float* hc, int hc_ld, const float* wf, const int* lengths, int step,
+template <int RN, typename TA>
+static int attention_fwd_split(hipStream_t st, const TA* ann, const float* U, const float* hc, int hc_ld, const float* wf, const int* lengths, int step,
                                float* alphas, int T1, float* Z, float* XZ, int B, int R, int L, int D, int A, float* sc, __bf16* xzb) {
     const size_t lds_s = (size_t)(RN * A + A) * 4, lds_c = (size_t)((RN * L + 3) & ~3) * 4 + (size_t)16 * RN * 16 * 16;
     SAT_REQUIRE(lds_s <= 160 * 1024 && lds_c <= 160 * 1024, "attention_fwd: L=%d A=%d do not fit the LDS", L, A);
     SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_scores_kernel<RN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
-    SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_context_kernel<RN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
+    SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_context_kernel<RN, TA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
     hipLaunchKernelGGL(attention_scores_kernel<RN>, dim3(B, cdiv(L, ATTS_WAVES)), dim3(ATTS_WAVES * 64), lds_s, st, U, hc, hc_ld, wf, sc, R, L, A);
     SAT_TRY(launch_ok("attention_scores"));
-    hipLaunchKernelGGL(attention_context_kernel<RN>, dim3(B, cdiv(D, ATTC_DCH)), dim3(256), lds_c, st, ann, sc, hc, hc_ld, lengths, step, alphas, T1, Z, XZ, R, L, D, A, xzb);
+    hipLaunchKernelGGL((attention_context_kernel<RN, TA>), dim3(B, cdiv(D, ATTC_DCH)), dim3(256), lds_c, st, ann, sc, hc, hc_ld, lengths, step, alphas, T1, Z, XZ, R, L, D, A, xzb);
     return launch_ok("attention_context");
 }
 
 int launch_attention_fwd(hipStream_t st, const float* ann, const float* U, const float* hc, int hc_ld, const float* wf,
-                                const int* lengths, int step, float* alphas, int T1, float* Z, float* XZ, int B, int R, int L, int D, int A, float* sc, void* xzb_v) {
+                                const int* lengths, int step, float* alphas, int T1, float* Z, float* XZ, int B, int R, int L, int D, int A, float* sc, void* xzb_v,
+                                const void* annb_v) {
     __bf16* xzb = reinterpret_cast<__bf16*>(xzb_v);
+    const __bf16* annb = reinterpret_cast<const __bf16*>(annb_v);          // bf16 copy of ann for the context stream (split kernels only), or NULL
     static const int no_split = getenv("SAT_ATT_FUSED") ? atoi(getenv("SAT_ATT_FUSED")) : 0;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     if (sc && !no_split && D % 4 == 0 && A % 4 == 0 && hc_ld % 4 == 0 && al16(ann) && al16(hc) && al16(Z) && al16(XZ)) {
         // scores and context as two chip-wide launches (scratch: raw scores (B*R, L))
         switch (R < ATT_RMAX ? R : ATT_RMAX) {
-            case 1: return attention_fwd_split<1>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc, xzb);
-            case 2: return attention_fwd_split<2>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc, xzb);
-            case 3: return attention_fwd_split<3>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc, xzb);
-            case 4: return attention_fwd_split<4>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc, xzb);
-            case 5: return attention_fwd_split<5>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc, xzb);
-            case 6: return attention_fwd_split<6>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc, xzb);
-            case 7: return attention_fwd_split<7>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc, xzb);
-            default: return attention_fwd_split<8>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc, xzb);
+            case 1: return annb ? attention_fwd_split<1, __bf16>(st, annb, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc, xzb)
+                                : attention_fwd_split<1, float>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc, xzb);
+            case 2: return annb ? attention_fwd_split<2, __bf16>(st, annb, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc, xzb)
+                                : attention_fwd_split<2, float>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc, xzb);
+            case 3: return annb ? attention_fwd_split<3, __bf16>(st, annb, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc, xzb)
+                                : attention_fwd_split<3, float>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc, xzb);
+            case 4: return annb ? attention_fwd_split<4, __bf16>(st, annb, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc, xzb)
+                                : attention_fwd_split<4, float>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc, xzb);
+            case 5: return annb ? attention_fwd_split<5, __bf16>(st, annb, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc, xzb)
+                                : attention_fwd_split<5, float>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc, xzb);
+            case 6: return annb ? attention_fwd_split<6, __bf16>(st, annb, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc, xzb)
+                                : attention_fwd_split<6, float>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc, xzb);
+            case 7: return annb ? attention_fwd_split<7, __bf16>(st, annb, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc, xzb)
+                                : attention_fwd_split<7, float>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc, xzb);
+            default: return annb ? attention_fwd_split<8, __bf16>(st, annb, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc, xzb)
+                                 : attention_fwd_split<8, float>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, T1, Z, XZ, B, R, L, D, A, sc, xzb);
         }
     }
-    SAT_REQUIRE(!xzb, "attention_fwd: the bf16 copy of the gated context needs the split kernels (aligned shapes)");
+    SAT_REQUIRE(!xzb && !annb, "attention_fwd: the bf16 copies need the split kernels (aligned shapes)");
     const bool vec = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(ann) & 15) == 0);
     const int vw = vec ? 4 : 1;
     int dchunk = vec ? 256 : 64;
@@ -223,15 +237,15 @@ int launch_attention_fwd(hipStream_t st, const float* ann, const float* U, const
     return launch_ok("attention_fwd");
 }
 
-template <int RN>
-static int attention_bwd_split_t(hipStream_t st, const float* ann, const float* U, const float* hc, int hc_ld, const float* wf, const int* lengths, int step,
+template <int RN, typename TA>
+static int attention_bwd_split_t(hipStream_t st, const TA* ann, const float* U, const float* hc, int hc_ld, const float* wf, const int* lengths, int step,
                                  const float* alphas, const float* dalphas, int T1, const float* Zs, const float* dZ_out, const float* dXZ, float* DZ, float* dhc,
                                  int dhc_ld, float* dU, float* dwf_part, float* da, int B, int R, int L, int D, int A, __bf16* dhcb) {
     const size_t lds_a = (size_t)RN * D * 4, lds_t = (size_t)(RN * L + RN * ATTB_KCH + 32 * (RN + 1) * ATTB_KCH) * 4;
     SAT_REQUIRE(lds_a <= 160 * 1024 && lds_t <= 160 * 1024, "attention_bwd: L=%d D=%d do not fit the LDS", L, D);
-    SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_dalpha_kernel<RN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
+    SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_dalpha_kernel<RN, TA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
     SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_tanh_kernel<RN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
-    hipLaunchKernelGGL(attention_bwd_dalpha_kernel<RN>, dim3(B, cdiv(L, 16)), dim3(1024), lds_a, st, ann, hc, hc_ld, lengths, step, dalphas, T1, Zs, dZ_out, dXZ, DZ, dhc,
+    hipLaunchKernelGGL((attention_bwd_dalpha_kernel<RN, TA>), dim3(B, cdiv(L, 16)), dim3(1024), lds_a, st, ann, hc, hc_ld, lengths, step, dalphas, T1, Zs, dZ_out, dXZ, DZ, dhc,
                        dhc_ld, da, R, L, D, A, dhcb);
     SAT_TRY(launch_ok("attention_bwd_dalpha"));
     hipLaunchKernelGGL(attention_bwd_tanh_kernel<RN>, dim3(B, cdiv(A, ATTB_KCH)), dim3(1024), lds_t, st, U, hc, hc_ld, wf, lengths, step, alphas, T1, da, dhc, dhc_ld, dU,
@@ -240,9 +254,10 @@ static int attention_bwd_split_t(hipStream_t st, const float* ann, const float* 
 }
 static int attention_bwd_split(int RN, hipStream_t st, const float* ann, const float* U, const float* hc, int hc_ld, const float* wf, const int* lengths, int step,
                                const float* alphas, const float* dalphas, int T1, const float* Zs, const float* dZ_out, const float* dXZ, float* DZ, float* dhc,
-                               int dhc_ld, float* dU, float* dwf_part, float* da, int B, int R, int L, int D, int A, __bf16* dhcb) {
-#define SAT_ATTB(RNV) case RNV: return attention_bwd_split_t<RNV>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, dalphas, T1, Zs, dZ_out, dXZ, DZ, dhc, dhc_ld, dU, dwf_part, da, B, R, L, D, A, dhcb);
-    switch (RN) { SAT_ATTB(1) SAT_ATTB(2) SAT_ATTB(3) SAT_ATTB(4) SAT_ATTB(5) SAT_ATTB(6) SAT_ATTB(7) default: return attention_bwd_split_t<8>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, dalphas, T1, Zs, dZ_out, dXZ, DZ, dhc, dhc_ld, dU, dwf_part, da, B, R, L, D, A, dhcb); }
+                               int dhc_ld, float* dU, float* dwf_part, float* da, int B, int R, int L, int D, int A, __bf16* dhcb, const __bf16* annb = nullptr) {
+#define SAT_ATTB(RNV) case RNV: return annb ? attention_bwd_split_t<RNV, __bf16>(st, annb, U, hc, hc_ld, wf, lengths, step, alphas, dalphas, T1, Zs, dZ_out, dXZ, DZ, dhc, dhc_ld, dU, dwf_part, da, B, R, L, D, A, dhcb) \
+                                            : attention_bwd_split_t<RNV, float>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, dalphas, T1, Zs, dZ_out, dXZ, DZ, dhc, dhc_ld, dU, dwf_part, da, B, R, L, D, A, dhcb);
+    switch (RN) { SAT_ATTB(1) SAT_ATTB(2) SAT_ATTB(3) SAT_ATTB(4) SAT_ATTB(5) SAT_ATTB(6) SAT_ATTB(7) default: SAT_ATTB(8) }
 #undef SAT_ATTB
 }
 
@@ -330,6 +345,8 @@ int decoder_fwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
 
     // bf16 mode, one layer: the per-step GEMMs read bf16 copies (state written by the cell kernel, gated context by the attention
     // kernel, weights cast here once) through the direct-to-LDS kernel instead of rounding fp32 operands in registers every step
+    const __bf16* annb = (w.annb && attention_split_enabled() && ann_bf16_enabled()) ? w.annb : nullptr;
+    if (annb) SAT_TRY(cast_bf16(st, b.ann, w.annb, (long)d.B * d.L * D));
     if (use_b) {
         hipLaunchKernelGGL(cast_block_bf16_kernel, dim3(cdiv((long)4 * n * (D / 4), 256)), dim3(256), 0, st, p.w_ih + m, (long)(m + D), w.Wz_b, 4 * n, D);
         SAT_TRY(launch_ok("cast W_ih[:, m:]"));
@@ -390,7 +407,7 @@ int decoder_fwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
             SAT_TRY(gemm(st, A_ROW, B_ROW, Hs(t, 0), n, w.Wcat + (long)(A + D) * n, n, hc + A + D, HCW, N, 4 * n, n, 0, EPI_BIAS, w.bcat + A + D));
         }
         SAT_TRY(launch_attention_fwd(st, b.ann, w.U, hc, HCW, p.att_f, b.lengths, t, alphas, T1, w.Z + (long)t * N * D, w.XZ + (long)t * N * D,
-                                     d.B, d.R, d.L, D, A, w.SC, use_b ? w.XZb : nullptr));
+                                     d.B, d.R, d.L, D, A, w.SC, use_b ? w.XZb : nullptr, annb));
         // gates += (beta*z) * W_ih[:, m:]^T
         if (use_b) SAT_TRY(gemm_bb_nt(st, w.XZb, D, w.Wz_b, D, hc + A + D, HCW, N, 4 * n, D, EPI_NONE, nullptr, 1));
         else SAT_TRY(gemm(st, A_ROW, B_ROW, w.XZ + (long)t * N * D, D, p.w_ih + m, m + D, hc + A + D, HCW, N, 4 * n, D, 1));
@@ -463,6 +480,7 @@ int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
     SAT_REQUIRE(lds_b <= 160 * 1024, "attention_bwd: L=%d A=%d D=%d need %zu B of LDS (> 160 KiB)", d.L, A, D, lds_b);
     static const int att_fused = getenv("SAT_ATT_FUSED") ? atoi(getenv("SAT_ATT_FUSED")) : 0;
     const bool use_b = w.Hb != nullptr && !att_fused;           // bf16 operand copies (the forward cast the weights into Wcat_b / Wz_b)
+    const __bf16* annb = (w.annb && !att_fused && ann_bf16_enabled()) ? w.annb : nullptr;      // the forward left the bf16 annotations there
     typedef void (*attb_fn)(const float*, const float*, const float*, int, const float*, const int*, int, const float*, const float*, int, const float*,
                             const float*, const float*, float*, float*, int, float*, float*, int, int, int, int);
     attb_fn attb = nullptr;
@@ -493,7 +511,7 @@ int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
         if (!att_fused) {
             SAT_TRY(attention_bwd_split(d.R < ATT_RMAX ? d.R : ATT_RMAX, st, b.ann, w.U, hc, HCW, p.att_f, b.lengths, t, alphas, dalphas, T1, w.Z + (long)t * N * D,
                                         w.dZout + (long)t * N * D, w.dXZ, w.DZ + (long)t * N * D, dhc, HCW, w.dU, w.dwf_part, w.DA, d.B, d.R, d.L, D, A,
-                                        use_b ? w.DHCb : nullptr));
+                                        use_b ? w.DHCb : nullptr, annb));
         } else
         hipLaunchKernelGGL(attb, dim3(d.B), dim3(ATTB_THREADS), lds_b, st, b.ann, w.U, hc, HCW, p.att_f, b.lengths, t, alphas,
                            dalphas, T1, w.Z + (long)t * N * D, w.dZout + (long)t * N * D, w.dXZ, w.DZ + (long)t * N * D, dhc, HCW, w.dU, w.dwf_part,
