@@ -178,17 +178,18 @@ def test_stem_tail_one_pass_equals_bn_relu_maxpool(E, dtype, shape):
         assert float(diff.max()) <= 0.02 * float(dx0.float().abs().max()) + 1e-6, "dx differs beyond a bf16 rounding of the statistics: %g" % float(diff.max())
 
 
-@pytest.mark.parametrize("out", [7, 14, 5])
-def test_resize_fwd_bwd(E, out):
+@pytest.mark.parametrize("C", [12, 10])            # 16-byte and 4-byte forms of the pooling kernel
+@pytest.mark.parametrize("out", [7, 14, 5, 3, 1])
+def test_resize_fwd_bwd(E, out, C):
     import sat_amd  # noqa
     from sat_amd import _lib as L
     g = torch.Generator().manual_seed(out)
-    x = torch.randn(2, 12, 8, 8, generator=g, requires_grad=True)
+    x = torch.randn(2, C, 8, 8, generator=g, requires_grad=True)
     mod = torch.nn.AdaptiveAvgPool2d((out, out)) if out < 8 else torch.nn.Upsample((out, out), mode="bilinear", align_corners=False)
     y = mod(x); dy = torch.randn(y.shape, generator=g); y.backward(dy)
-    xd = nhwc(x.detach()).cuda(); yd = torch.empty(2, out, out, 12, device="cuda"); dx = torch.empty_like(xd)
-    L.check(L.lib().sat_resize_fwd(L.ptr(xd), L.ptr(yd), 2, 8, 8, 12, out, out, L.stream_ptr()), "resize fwd")
-    L.check(L.lib().sat_resize_bwd(L.ptr(nhwc(dy).cuda()), L.ptr(dx), 2, 8, 8, 12, out, out, L.stream_ptr()), "resize bwd")
+    xd = nhwc(x.detach()).cuda(); yd = torch.empty(2, out, out, C, device="cuda"); dx = torch.empty_like(xd)
+    L.check(L.lib().sat_resize_fwd(L.ptr(xd), L.ptr(yd), 2, 8, 8, C, out, out, L.stream_ptr()), "resize fwd")
+    L.check(L.lib().sat_resize_bwd(L.ptr(nhwc(dy).cuda()), L.ptr(dx), 2, 8, 8, C, out, out, L.stream_ptr()), "resize bwd")
     close(nchw(yd), y, 1e-6, "resize fwd"); close(nchw(dx), x.grad, 1e-6, "resize bwd")
 
 
