@@ -187,6 +187,7 @@ _DGRAD_JOIN = os.environ.get("SAT_DGRAD_JOIN", "1") != "0"
 #: projection blocks, forward: the shortcut's BatchNorm is applied inside the last BatchNorm's kernel (dev switch, SAT_FWD_RES_BN=0 writes it out)
 _FWD_RES_BN = os.environ.get("SAT_FWD_RES_BN", "1") != "0"
 _WGRAD_STREAMS = int(os.environ.get("SAT_WGRAD_STREAMS", "1"))          # side streams the launches are dealt to in turn
+_WGRAD_SIDE_ONLY = int(os.environ.get("SAT_WGRAD_SIDE_ONLY", "0"))      # dev: which filters go to the side stream (0 = all)
 _side_streams = {}
 
 
@@ -245,6 +246,8 @@ def conv_wgrad(dy, x, w, stride, pad, stride_w=0, param=None, queue=None):
     lib = L.lib()
     nbytes = max(lib.sat_conv2d_wgrad_slab_bytes(C.byref(g)), 128 << 20)
     side = queue is not None and queue.enabled
+    if side and _WGRAD_SIDE_ONLY:          # dev: 1 = only the 3x3 filters, 2 = only the 1x1 filters go to the side stream
+        side = (R == 3) if _WGRAD_SIDE_ONLY == 1 else (R == 1)
     slab = _slab(x.device, nbytes, "side%d" % queue.slot() if side else "main")
     fn = lib.sat_conv2d_wgrad_bf16 if _is_bf(x) else lib.sat_conv2d_wgrad
     out = L.grad_buffer(param) if param is not None else None                 # (K,C,R,S), KRSC memory when the parameter is

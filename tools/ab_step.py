@@ -17,18 +17,31 @@ model.__dict__["_sat_global_step"] = 2
 opt = model.configure_optimizers()
 img, caps, lengths = bench.synthetic_batch(B, R, T, hp["vocab_size"], 1234, False)
 img, caps = img.cuda(), caps.cuda()
-DEFAULTS = {"bn_ticket": 0, "bn_onepass": 1, "bn_vpt": 2, "acc_prefetch": 0, "wgrad3x3": 1, "reduce_z16": 1, "wide_tiles": 0, "py:bn_bwd_epilogue": 1, "py:wgrad_stream": 1, "py:wgrad_streams": 1, "py:dgrad_join": 1, "py:fwd_res_bn": 1}
+DEFAULTS = {"bn_ticket": 0, "bn_onepass": 1, "bn_vpt": 2, "acc_prefetch": 0, "wgrad3x3": 1, "reduce_z16": 1, "wide_tiles": 0, "py:bn_bwd_epilogue": 1, "py:wgrad_stream": 1, "py:wgrad_streams": 1, "py:dgrad_join": 1, "py:fwd_res_bn": 1, "py:hi_prio": 0, "py:wgrad_side_only": 0}
 
 
 def apply(settings):
     for k, v in {**DEFAULTS, **settings}.items():
-        if k.startswith("py:"):
-            setattr(E, "_" + k[3:].upper(), int(v) if k.endswith("streams") else bool(v))
+        if k == "py:hi_prio":
+            _hi[0] = bool(v)
+        elif k.startswith("py:"):
+            setattr(E, "_" + k[3:].upper(), int(v) if (k.endswith("streams") or k.endswith("side_only")) else bool(v))
         else:
             L.check(L.lib().sat_debug_option(k.encode(), int(v)), k)
 
 
+HI = torch.cuda.Stream(priority=-1)      # py:hi_prio=1: the whole step on a high-priority stream (the side stream keeps the default priority)
+_hi = [False]
+
+
 def step():
+    if _hi[0]:
+        HI.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(HI):
+            opt.zero_grad(set_to_none=True)
+            out = model.training_step((img, caps, lengths), 0); out["loss"].backward(); opt.step()
+        torch.cuda.current_stream().wait_stream(HI)
+        return
     opt.zero_grad(set_to_none=True)
     out = model.training_step((img, caps, lengths), 0); out["loss"].backward(); opt.step()
 
