@@ -189,6 +189,7 @@ _FWD_RES_BN = os.environ.get("SAT_FWD_RES_BN", "1") != "0"
 _WGRAD_STREAMS = int(os.environ.get("SAT_WGRAD_STREAMS", "1"))          # side streams the launches are dealt to in turn
 _WGRAD_SIDE_ONLY = int(os.environ.get("SAT_WGRAD_SIDE_ONLY", "0"))      # dev: which filters go to the side stream (0 = all)
 _side_streams = {}
+_JOIN_LAG = None          # dev: a list collects (main-arrival, side-done) event pairs of every join
 
 
 class _SideQueue:
@@ -231,7 +232,11 @@ class _SideQueue:
             return
         for i, side in enumerate(self.sides):
             if self.dirty[i]:
-                ev = torch.cuda.Event(); ev.record(side)
+                timing = _JOIN_LAG is not None
+                ev = torch.cuda.Event(enable_timing=timing); ev.record(side)
+                if timing:          # dev (tools/join_lag.py): how long after the main stream arrived here the side stream finished
+                    em = torch.cuda.Event(enable_timing=True); em.record(self.main)
+                    _JOIN_LAG.append((em, ev))
                 self.main.wait_event(ev)
                 self.dirty[i] = False
 
