@@ -3,12 +3,19 @@
 ``libsat_hip.so``.  Mirrors the decoder half of ``SAT.train_batch``
 (reference model.py:487-557) and the loss lines model.py:592-597.
 """
+import collections
 import ctypes as C
 
 import numpy as np
 import torch
 
 from . import _lib as L
+
+
+def _upload(t, dev):
+    if dev.type != "cuda":
+        return t.to(dev)
+    return t.pin_memory().to(dev, non_blocking=True)
 
 
 class PackPlan:
@@ -46,9 +53,30 @@ class PackPlan:
         self.offsets_host = np.ascontiguousarray(offsets)
         self.lengths_cpu = lens
         dev = torch.device(device)
-        self.prow = torch.from_numpy(prow).to(dev)
-        self.src_row = torch.from_numpy(self.src_row_np).to(dev)
-        self.lengths = lens.to(torch.int32).to(dev)
+        # pinned staging + asynchronous copies: a copy out of pageable memory blocks the host until the stream has drained, i.e. one
+        # host/GPU synchronisation per train step (the host then issues the rest of the step into an empty queue)
+        self.prow = _upload(torch.from_numpy(prow), dev)
+        self.src_row = _upload(torch.from_numpy(self.src_row_np), dev)
+        self.lengths = _upload(lens.to(torch.int32), dev)
+        unsorted = torch.empty_like(order); unsorted[order] = torch.arange(self.N)
+        self.unsorted_indices = unsorted                     # PackedSequence's index pair (model.py:553-554), host and device
+        self.sorted_indices_dev, self.unsorted_indices_dev = _upload(order, dev), _upload(unsorted, dev)
+
+    _cache = collections.OrderedDict()
+
+    @classmethod
+    def cached(cls, lengths, T, device):
+        """Plans are read-only: batches with the same lengths (bucketed sampling repeats them often) share one."""
+        lens = torch.as_tensor(lengths, dtype=torch.int64, device="cpu").reshape(-1)
+        key = (int(T), str(torch.device(device)), lens.numpy().tobytes())
+        plan = cls._cache.get(key)
+        if plan is None:
+            plan = cls._cache[key] = cls(lens, T, device)
+            if len(cls._cache) > 32:
+                cls._cache.popitem(last=False)
+        else:
+            cls._cache.move_to_end(key)
+        return plan
 
     def pack(self, x_ntx):
         """(N, T-1, ...) padded -> packed rows (P, ...), same order as the library writes."""

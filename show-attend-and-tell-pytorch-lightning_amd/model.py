@@ -387,7 +387,7 @@ class SATDecoder(nn.Module):
 
         ann_bld (B, L, D) on the GPU; caps (B, R, T) int64; lengths (B, R) int64 (host or device)."""
         B, R, T = caps.shape
-        plan = Dk.PackPlan(lengths.reshape(-1).cpu(), T, ann_bld.device)
+        plan = Dk.PackPlan.cached(lengths.reshape(-1).cpu(), T, ann_bld.device)
         teacher = plan.teacher_flags(float(epsilon), draw)
         caps2 = caps.reshape(B * R, T)
         caps_i32 = caps2.to(device=ann_bld.device, dtype=torch.int32).contiguous()
@@ -489,11 +489,8 @@ class SAT(SATDecoder, _Base):
         ann_bld, _ = self.encode(img)
         res = self.train_decode(ann_bld, encoded_captions, lengths, float(epsilon), draw, with_loss=False)
         plan = res["plan"]
-        unsorted = torch.empty_like(plan.sorted_indices)
-        unsorted[plan.sorted_indices] = torch.arange(plan.N)
-        dev = ann_bld.device
-        lp = PackedSequence(res["logits_packed"], plan.batch_sizes, plan.sorted_indices.to(dev), unsorted.to(dev))
-        tp = PackedSequence(res["targets_packed"], plan.batch_sizes, plan.sorted_indices.to(dev), unsorted.to(dev))
+        lp = PackedSequence(res["logits_packed"], plan.batch_sizes, plan.sorted_indices_dev, plan.unsorted_indices_dev)
+        tp = PackedSequence(res["targets_packed"], plan.batch_sizes, plan.sorted_indices_dev, plan.unsorted_indices_dev)
         self._last = res
         return lp, tp, res["alphas"]
 
