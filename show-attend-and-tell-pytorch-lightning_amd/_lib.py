@@ -292,5 +292,12 @@ def ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr():
+    """the current stream of the current device as a raw handle.  (``torch.cuda.current_stream().cuda_stream`` builds a Stream object through
+    several Python layers: 8 us a call, ~330 calls per C2 train step = a quarter of the host time of a step.)"""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -91,7 +91,7 @@ class FusedOptimizer(torch.optim.Optimizer):
             slot[1].synchronize()                      # the upload that last read this pinned table has executed
         host = slot[0]
         table = (L.OptTensor * len(entries)).from_buffer(host.numpy())
-        steps = set()
+        steps = []          # the per-parameter step counters (torch's state layout), advanced together below
         for i, (p, group) in enumerate(entries):
             dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))      # KRSC filters
             if p.dtype != torch.float32 or not dense:
@@ -103,8 +103,7 @@ class FusedOptimizer(torch.optim.Optimizer):
                     st["momentum_buffer"] = torch.zeros_like(p) if group["momentum"] != 0 else None
                 else:
                     st["exp_avg"] = torch.zeros_like(p); st["exp_avg_sq"] = torch.zeros_like(p)
-            st["step"] += 1
-            steps.add(float(st["step"]))
+            steps.append(st["step"])
             grad = p.grad if _same_layout(p.grad, p) else torch.empty_like(p).copy_(p.grad)     # element i of g <-> element i of p
             m = st.get("momentum_buffer") if self.kind == "sgd" else st["exp_avg"]
             v = None if self.kind == "sgd" else st["exp_avg_sq"]
@@ -116,9 +115,11 @@ class FusedOptimizer(torch.optim.Optimizer):
             if t.shadow_bf16:
                 p._sat_shadow_version = p._version
             entries[i] = (p, group, grad)              # keep a re-laid-out gradient alive until the launch
-        if len(steps) != 1:
-            raise ValueError("FusedOptimizer: parameters are at different step counts %s" % sorted(steps))
-        step = steps.pop()
+        torch._foreach_add_(steps, 1)                  # one call instead of a tensor add + a float() per parameter (0.8 ms of host time at C2)
+        sv = torch.stack(steps)
+        step = float(sv[0])
+        if float(sv.min()) != float(sv.max()):
+            raise ValueError("FusedOptimizer: parameters are at different step counts %s" % sorted(set(sv.tolist())))
         raw = host.numpy().tobytes()
         if raw != self._uploaded:                      # pointers / lr / weight decay changed since the table on the device was written
             self._dev.copy_(host, non_blocking=True)

@@ -5,7 +5,7 @@ import torch
 import bench
 import sat_amd  # noqa
 from sat_amd import model as M
-hp, T, B, R = bench.hparams("c2")
+hp, T, B, R = bench.hparams(os.environ.get("CFG", "c2"))
 torch.manual_seed(42)
 model = M.SAT(**hp).cuda().train(); model.set_precision("bf16")
 model.__dict__["_sat_global_step"] = 2
@@ -24,8 +24,10 @@ for rep in range(3):
     print("issue %.2f ms/step on the host; %.2f ms/step until the GPU is done" % ((t1 - t0) / 4 * 1e3, (t2 - t0) / 4 * 1e3))
 if os.environ.get("PROFILE"):
     import cProfile, pstats
+    torch.autograd.set_multithreading_enabled(False)          # the backward's Python runs on this thread: the profiler sees it
+    for _ in range(2): step()
     pr = cProfile.Profile(); pr.enable()
     for _ in range(4): step()
     pr.disable(); torch.cuda.synchronize()
-    st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(12)
-    st.print_callers("method 'to' of")
+    st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(45)
+
