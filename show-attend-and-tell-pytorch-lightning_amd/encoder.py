@@ -206,6 +206,8 @@ class _SideQueue:
         while len(_side_streams.setdefault(key, [])) < n:
             _side_streams[key].append(torch.cuda.Stream(device))
         self.sides = _side_streams[key][:n]
+        self.side_ptrs = [C.c_void_p(sd.cuda_stream) for sd in self.sides]
+        self.ev = torch.cuda.Event()
         self.turn = 0
         self.dirty = [False] * n
 
@@ -214,13 +216,13 @@ class _SideQueue:
         return self.turn % len(self.sides)
 
     def launch(self, fn, *inputs):
+        """fn(stream) enqueues on the raw stream handle it is given (it must not allocate: its outputs are created by the caller)"""
         if not self.enabled:
-            return fn()
+            return fn(L.stream_ptr())
         i = self.slot(); side = self.sides[i]; self.turn += 1
-        ev = torch.cuda.Event(); ev.record(self.main)
-        side.wait_event(ev)
-        with torch.cuda.stream(side):
-            out = fn()
+        self.ev.record(self.main)              # one event serves every launch: a stream wait captures the record that precedes it
+        side.wait_event(self.ev)
+        out = fn(self.side_ptrs[i])            # no current-stream switch: the handle goes straight to the library (the switch was 10 us a launch)
         for t in inputs:                       # the caching allocator must not hand these blocks out again before the side stream is done
             if t is not None:
                 t.record_stream(side)
@@ -241,6 +243,9 @@ class _SideQueue:
                 self.dirty[i] = False
 
 
+_wgrad_slab_bytes = {}
+
+
 def conv_wgrad(dy, x, w, stride, pad, stride_w=0, param=None, queue=None):
     """fp32 gradient of the (K,C,R,S) filter, whatever the activation storage.  ``param``: the filter parameter itself, when the
     gradient may be written to its data-parallel bucket slice (``_lib.grad_buffer``).  ``queue``: a ``_SideQueue`` - the launch then goes
@@ -249,7 +254,10 @@ def conv_wgrad(dy, x, w, stride, pad, stride_w=0, param=None, queue=None):
     K, _, R, S = w.shape
     g = _geom(N, H, W, Cc, K, R, S, stride, pad, stride_w)
     lib = L.lib()
-    nbytes = max(lib.sat_conv2d_wgrad_slab_bytes(C.byref(g)), 128 << 20)
+    gkey = (N, H, W, Cc, K, R, S, stride, pad, stride_w)
+    nbytes = _wgrad_slab_bytes.get(gkey)
+    if nbytes is None:
+        nbytes = _wgrad_slab_bytes[gkey] = max(lib.sat_conv2d_wgrad_slab_bytes(C.byref(g)), 128 << 20)
     side = queue is not None and queue.enabled
     if side and _WGRAD_SIDE_ONLY:          # dev: 1 = only the 3x3 filters, 2 = only the 1x1 filters go to the side stream
         side = (R == 3) if _WGRAD_SIDE_ONLY == 1 else (R == 1)
@@ -259,13 +267,13 @@ def conv_wgrad(dy, x, w, stride, pad, stride_w=0, param=None, queue=None):
     direct = out is not None and tuple(out.shape) == (K, Cc, R, S) and out.permute(0, 2, 3, 1).is_contiguous()
     dst = out if direct else torch.empty(K, R, S, Cc, dtype=torch.float32, device=x.device)       # KRSC
 
-    def run():
-        L.check(fn(L.ptr(dy), L.ptr(x), L.ptr(dst), C.byref(g), L.ptr(slab), slab.numel(), L.stream_ptr()), "sat_conv2d_wgrad")
+    def run(stream):
+        L.check(fn(L.ptr(dy), L.ptr(x), L.ptr(dst), C.byref(g), L.ptr(slab), slab.numel(), stream), "sat_conv2d_wgrad")
 
     if side:
         queue.launch(run, dy, x, dst)
     else:
-        run()
+        run(L.stream_ptr())
     return out if direct else dst.permute(0, 3, 1, 2)                         # (K,C,R,S) view, channels_last memory
 
 
