@@ -146,3 +146,18 @@ def test_pretrained_without_a_local_file_says_so(tmp_path, monkeypatch):
     args.pretrained = os.path.join(str(tmp_path), "nope.pth")
     with pytest.raises(FileNotFoundError):
         E.get_encoder(args)
+
+
+def test_packing_plans_are_cached_by_caption_lengths_and_match_pack_padded_sequence():
+    """model.py:553-554: the plan's index pair / batch sizes are what ``pack_padded_sequence(enforce_sorted=False)`` builds; plans are shared
+    between batches with the same lengths (read-only) and rebuilt for different ones."""
+    from sat_amd import decoder as Dk
+    lens = torch.tensor([3, 5, 1, 5, 0, 2])
+    a = Dk.PackPlan.cached(lens, 7, "cpu"); b = Dk.PackPlan.cached(lens.clone(), 7, "cpu"); c = Dk.PackPlan.cached(lens + 1, 7, "cpu")
+    assert a is b and a is not c
+    x = torch.arange(6 * 6, dtype=torch.float32).reshape(6, 6)
+    keep = lens > 0                                        # pack_padded_sequence refuses zero lengths; the plan gives such rows no slot
+    ref = torch.nn.utils.rnn.pack_padded_sequence(x[keep], lens[keep], batch_first=True, enforce_sorted=False)
+    assert a.batch_sizes.tolist() == ref.batch_sizes.tolist()
+    assert torch.equal(a.pack(x.unsqueeze(-1)).squeeze(-1), ref.data)
+    assert torch.equal(a.sorted_indices_dev, a.sorted_indices) and torch.equal(a.unsorted_indices_dev[a.sorted_indices], torch.arange(6))
