@@ -289,7 +289,9 @@ def grad_buffer(param):
 
 
 def ptr(t):
-    return None if t is None else C.c_void_p(t.data_ptr())
+    """raw device address for a ``c_void_p`` argument / struct field (a plain int: ctypes converts it; wrapping it in ``c_void_p`` here cost
+    0.2 us x ~2100 arguments per train step)"""
+    return None if t is None else t.data_ptr()
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
