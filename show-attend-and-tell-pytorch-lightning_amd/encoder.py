@@ -76,8 +76,26 @@ def _channels_last_(module):
 
 
 # ----------------------------------------------------------------------------- raw layer calls
+_geoms = {}
+_stats_n = {}
+
+
+def _stats_elems(g, fwd):
+    """floats of the tile-statistics array of a convolution launch (forward / data gradient), asked of the library once per geometry"""
+    key = (id(g), fwd)
+    n = _stats_n.get(key)
+    if n is None:
+        lib = L.lib()
+        n = _stats_n[key] = (lib.sat_conv2d_fwd_stats_bytes(C.byref(g)) if fwd else lib.sat_conv2d_dgrad_stats_bytes(C.byref(g))) // 4
+    return n
+
+
 def _geom(N, H, W, Cc, K, R, S, stride, pad, stride_w=0):
-    return L.ConvGeom(N=N, H=H, W=W, C=Cc, K=K, R=R, S=S, stride=stride, pad=pad, stride_w=int(stride_w or 0))
+    key = (N, H, W, Cc, K, R, S, stride, pad, stride_w)
+    g = _geoms.get(key)
+    if g is None:          # the library only reads it: one struct per geometry, not one per call
+        g = _geoms[key] = L.ConvGeom(N=N, H=H, W=W, C=Cc, K=K, R=R, S=S, stride=stride, pad=pad, stride_w=int(stride_w or 0))
+    return g
 
 
 def _krsc(w):
@@ -132,7 +150,7 @@ def conv_fwd_stats(x, w, stride, pad, stride_w=0):
     P, Q = _out_hw(H, W, R, S, stride, pad, stride_w)
     y = torch.empty(N, P, Q, K, dtype=x.dtype, device=x.device)
     g = _geom(N, H, W, Cc, K, R, S, stride, pad, stride_w)
-    stats = torch.empty(lib.sat_conv2d_fwd_stats_bytes(C.byref(g)) // 4, dtype=torch.float32, device=x.device)
+    stats = torch.empty(_stats_elems(g, True), dtype=torch.float32, device=x.device)
     rows = C.c_int32(0)
     L.check(lib.sat_conv2d_fwd_bf16_stats(L.ptr(x), L.ptr(_krsc(w)), L.ptr(y), C.byref(g), L.ptr(stats), C.byref(rows), L.stream_ptr()),
             "sat_conv2d_fwd_bf16_stats")
@@ -162,7 +180,7 @@ def conv_dgrad(dy, w, x_shape, stride, pad, out=None, accumulate=False, bn=None,
         bx = st = None
         if bn is not None and _BN_BWD_EPILOGUE and bn[0] is not None and bn[0].dtype == BF16 and tuple(bn[0].shape) == tuple(dx.shape) and bn[0].is_contiguous():
             bx, st = bn
-            stats = torch.empty(lib.sat_conv2d_dgrad_stats_bytes(C.byref(g)) // 4, dtype=torch.float32, device=dy.device)
+            stats = torch.empty(_stats_elems(g, False), dtype=torch.float32, device=dy.device)
         L.check(lib.sat_conv2d_dgrad_bf16_fused(L.ptr(dy), L.ptr(_krsc(w)), L.ptr(dx), C.byref(g), L.ptr(src), L.ptr(mask), L.ptr(bx),
                                                 L.ptr(st[2] if st is not None and len(st) > 2 else None), L.ptr(st[0] if st is not None else None),
                                                 L.ptr(st[1] if st is not None else None), L.ptr(stats), C.byref(rows), L.stream_ptr()), "sat_conv2d_dgrad_bf16_fused")
@@ -171,7 +189,7 @@ def conv_dgrad(dy, w, x_shape, stride, pad, out=None, accumulate=False, bn=None,
     if bn is not None:
         bx, st = bn
         if _BN_BWD_EPILOGUE and _is_bf(dy) and stride == 1 and bx is not None and bx.dtype == BF16 and tuple(bx.shape) == tuple(dx.shape) and bx.is_contiguous():
-            stats = torch.empty(lib.sat_conv2d_dgrad_stats_bytes(C.byref(g)) // 4, dtype=torch.float32, device=dy.device)
+            stats = torch.empty(_stats_elems(g, False), dtype=torch.float32, device=dy.device)
             rows = C.c_int32(0)
             L.check(lib.sat_conv2d_dgrad_bf16_bnstats(L.ptr(dy), L.ptr(_krsc(w)), L.ptr(dx), C.byref(g), int(accumulate), L.ptr(bx), L.ptr(st[2] if len(st) > 2 else None),
                                                       L.ptr(st[0]), L.ptr(st[1]), L.ptr(stats), C.byref(rows), L.stream_ptr()), "sat_conv2d_dgrad_bf16_bnstats")
