@@ -36,6 +36,10 @@ class FusedOptimizer(torch.optim.Optimizer):
         self._sig = None
         self.last_grad_norm = None                     # device scalar after a step with norm clipping
 
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._fast_key = None                          # the state tensors were replaced: rebuild the pointer table on the next step
+
     def set_clipping(self, algorithm, value):
         """train.py:93-96: ``--grad_clip value|norm`` with ``--clip_value`` (0 = off)."""
         if algorithm not in (None, "value", "norm"):
@@ -84,6 +88,18 @@ class FusedOptimizer(torch.optim.Optimizer):
         for g in self.param_groups:
             if tuple(g["betas"]) != (beta1, beta2) or g["eps"] != g0["eps"] or g["momentum"] != g0["momentum"] or g["nesterov"] != g0["nesterov"]:
                 raise ValueError("FusedOptimizer: betas / eps / momentum / nesterov must be the same in every group (lr and weight_decay may differ)")
+        # Fast path: the same tensors, gradient addresses, learning rates and weight decays as the step before - the table on the device is
+        # current, nothing to rebuild or upload (the per-parameter loop below is ~1.2 ms of host time at C2, 2.5 ms for resnet101, and C1 / C3
+        # are host-bound).  Gradients living in persistent buckets (dist.GradSync) or reallocated at the same addresses hit it every step.
+        fast_key = (tuple([p.grad.data_ptr() for p, _ in entries]), tuple([(g["lr"], g["weight_decay"]) for g in self.param_groups]),
+                    tuple([p.data_ptr() for p, _ in entries]))
+        if fast_key == getattr(self, "_fast_key", None) and self._fast_ok:
+            self.fast_path_steps = getattr(self, "fast_path_steps", 0) + 1
+            torch._foreach_add_(self._fast_steps, 1)
+            step = float(self._fast_steps[0])
+            for q in self._fast_shadowed:
+                q._sat_shadow_version = q._version
+            return self._launch(lib, g0, beta1, beta2, step, self._chunks, loss)
         chunks = self._tables(entries, dev)
         self._ring_pos = (self._ring_pos + 1) % len(self._ring)
         slot = self._ring[self._ring_pos]
@@ -127,6 +143,13 @@ class FusedOptimizer(torch.optim.Optimizer):
             ev.record(torch.cuda.current_stream(dev))
             slot[1] = ev
             self._uploaded = raw
+        # the fast path may take over when every gradient was used where it lies (no re-laid-out copy whose address would be stale)
+        self._fast_key, self._fast_steps = fast_key, steps
+        self._fast_ok = all(e[2] is e[0].grad for e in entries)
+        self._fast_shadowed = [e[0] for e in entries if getattr(e[0], "_sat_bf16_shadow", None) is not None]
+        return self._launch(lib, g0, beta1, beta2, step, chunks, loss)
+
+    def _launch(self, lib, g0, beta1, beta2, step, chunks, loss):
         coef = None
         if self.grad_clip == "norm":
             L.check(lib.sat_grad_clip_coef(L.ptr(self._dev), L.ptr(chunks), self._n_chunks, self.clip_value, L.ptr(self._scratch),

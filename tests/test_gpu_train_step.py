@@ -146,6 +146,38 @@ def test_pretrained_trunk_from_a_local_checkpoint_trains_only_what_the_reference
             assert rel(p.grad, og[k]) < 1e-3, (k, rel(p.grad, og[k]))
 
 
+def test_one_process_gradsync_keeps_gradients_in_place_and_the_optimizer_fast_path_changes_nothing():
+    """One process: GradSync keeps every gradient in its persistent bucket slice (no collective), so gradient addresses repeat and
+    FusedOptimizer reuses the pointer table already on the device.  Four steps with it against four steps without: every parameter,
+    Adam state and BatchNorm buffer bit-identical; the fast path ran on steps 2..4."""
+    from sat_amd.dist import GradSync
+    runs = []
+    for use_sync in (False, True):
+        model, _, hp = make(dict(decoder_tf="always"))
+        model.set_precision("bf16")
+        opt = model.configure_optimizers()
+        sync = GradSync(model) if use_sync else None
+        img, caps, lengths = batch(hp)
+        img, caps = img.cuda(), caps.cuda()
+        for _ in range(4):
+            opt.zero_grad(set_to_none=True)
+            model.training_step((img, caps, lengths), 0)["loss"].backward()
+            if sync is not None:
+                sync.finish()
+            opt.step()
+        torch.cuda.synchronize()
+        if use_sync:
+            assert getattr(opt, "fast_path_steps", 0) == 3, getattr(opt, "fast_path_steps", 0)
+            assert all(p.grad is None or sync._of[id(p)].owns(p) for p in model.parameters())
+            sync.remove()
+        runs.append(({k: v.detach().clone() for k, v in model.state_dict().items()},
+                     [st["exp_avg"].clone() for st in opt.state.values() if "exp_avg" in st]))
+    (sd_a, m_a), (sd_b, m_b) = runs
+    for k in sd_a:
+        assert torch.equal(sd_a[k], sd_b[k]), k
+    assert len(m_a) == len(m_b) and all(torch.equal(x, y) for x, y in zip(m_a, m_b))
+
+
 BF16_CASES = {
     # name: (hparams, images, residual damping)
     "small": (dict(decoder_tf="always", encoder_dim=32, embed_dim=32, attention_dim=16, decoder_dim=64, vocab_size=128, input_size=128, encoder_size=None), 16, 0.25),
