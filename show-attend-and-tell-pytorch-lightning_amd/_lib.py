@@ -1,5 +1,6 @@
 """ctypes binding of libsat_hip.so (include/sat_hip.h).  Fails loudly: no fallback."""
 import ctypes as C
+import weakref
 import os
 
 import torch
@@ -278,13 +279,23 @@ def unregister_grad_sink(param):
     _grad_sinks.pop(id(param), None)
 
 
+_handed_out = {}          # id(param) -> weak reference to the slice view handed out and not yet adopted as param.grad
+
+
 def grad_buffer(param):
     """Where a backward kernel writes ``param``'s gradient: the registered bucket slice when the parameter holds no
     gradient yet (autograd then adopts the slice as ``param.grad``), else new memory with the parameter's layout
-    (autograd adds it to the existing gradient)."""
+    (autograd adds it to the existing gradient).  The slice goes out ONCE per backward pass: a second backward node of the same
+    parameter (the encoder or decoder Function applied twice before one ``backward()``) would otherwise overwrite the first node's
+    gradient in the shared slice and autograd would add the slice to itself.  "Still out" = the view handed out is alive and the
+    parameter has not adopted it (``AccumulateGrad`` runs only after every use of the parameter)."""
     make = _grad_sinks.get(id(param))
     if make is not None and param.grad is None:
-        return make()
+        ref = _handed_out.get(id(param))
+        if ref is None or ref() is None:
+            v = make()
+            _handed_out[id(param)] = weakref.ref(v)
+            return v
     return torch.empty_like(param)
 
 

@@ -66,7 +66,7 @@ class GradSync:
         self._custom = buckets
         self.bucket_dtype = bucket_dtype
         self.enabled = True
-        self._handles = []
+        self._hook_handles = {}          # id(parameter) -> its post-accumulate hook
         self.buckets = []
         self._sig = None
         self._early = set()              # diagnostics: indices of the buckets launched from inside the encoder backward this step
@@ -79,8 +79,23 @@ class GradSync:
             plist = self.__dict__["_plist"] = list(self.model.parameters())
         return tuple([p.requires_grad for p in plist])
 
+    def _layout_stale(self):
+        """True when the set of trainable parameters differs from the one the buckets were laid out for.  The cached parameter list is
+        checked against the model first (``model.to()`` / ``_apply`` may replace Parameter objects: the first and the last one are looked at)."""
+        plist = self.__dict__.get("_plist")
+        if plist:
+            it = self.model.parameters()
+            first = next(it, None)
+            if first is not plist[0]:
+                self.__dict__.pop("_plist", None)
+        return self._signature() != self._sig
+
     def _build(self):
-        self.remove()
+        """(Re)lay out the buckets.  A bucket whose parameter list is unchanged is KEPT as it is - buffer, slices, and an all-reduce that may be
+        in flight on it (``finish()`` re-lays the buckets out in the middle of a step when ``encoder_finetune_after`` unfreezes the encoder:
+        the decoder bucket launched by this step's hooks must neither be cloned out of nor reduced a second time).  Returns the ids of the
+        parameters whose (changed) bucket had already been reduced this step: their gradients hold the mean."""
+        self.__dict__.pop("_plist", None)
         groups = self._custom if self._custom is not None else default_buckets(self.model)
         seen, clean = set(), []
         for grp in groups:                                       # tied weights appear once
@@ -93,27 +108,59 @@ class GradSync:
         self._sig = self._signature()
         # one process: the same persistent buffers without the collective - gradient addresses then stay put from step to step, which lets
         # FusedOptimizer skip rebuilding / uploading its pointer table (optim.py) and saves ~180 gradient allocations per step
-        self.buckets = [_Bucket(g) for g in clean]
+        old = {tuple(id(p) for p in b.params): b for b in self.buckets}
+        kept, fresh, done = [], [], set()
+        for g in clean:
+            b = old.pop(tuple(id(p) for p in g), None)
+            if b is None:
+                b = _Bucket(g); fresh.append(b)
+            kept.append(b)
+        for b in old.values():          # buckets whose parameter list changed: finish what is in flight on them, then move the gradients out
+            if b.launched:
+                self._complete(b)
+                done.update(id(p) for p in b.params)
+            self._retire(b)
+        self.buckets = kept
         self._of = {}
         for b in self.buckets:
             for p in b.params:
                 self._of[id(p)] = b
+        for b in fresh:
+            for p in b.params:
                 if self.world > 1:      # (one process: nothing to launch early; finish() adopts whatever did not land in its slice)
-                    self._handles.append(p.register_post_accumulate_grad_hook(self._hook))
+                    self._hook_handles[id(p)] = p.register_post_accumulate_grad_hook(self._hook)
                 L.register_grad_sink(p, (lambda b=b, p=p: b.view(p)))
         enc = getattr(self.model, "encoder", None)
         if enc is not None and hasattr(enc, "precision"):          # HipEncoder: stage-by-stage notification
             enc.grad_ready = self.encoder_stage_ready if self.world > 1 else None
+        return done
+
+    def _retire(self, b):
+        """a bucket that goes away: hooks and gradient sinks off, gradients that live in its buffer moved out (nothing may be in flight on it)"""
+        for p in b.params:
+            h = self._hook_handles.pop(id(p), None)
+            if h is not None:
+                h.remove()
+            L.unregister_grad_sink(p)
+            if b.owns(p):
+                p.grad = p.grad.clone()                      # the flat buffer is about to go away
+
+    def _complete(self, b):
+        """wait for the bucket's all-reduce and leave the mean in its buffer"""
+        if b.work is not None:
+            b.work.wait()
+            if b.wire is not None:
+                b.flat.copy_(b.wire)
+                b.wire = None
+            b.flat.div_(self.world)
+        b.work, b.launched, b.pending = None, False, 0
 
     def remove(self):
-        for h in self._handles:
-            h.remove()
-        self._handles = []
+        """detach from the model: collectives in flight are completed first, gradients are moved out of the flat buffers"""
         for b in self.buckets:
-            for p in b.params:
-                L.unregister_grad_sink(p)
-                if b.owns(p):
-                    p.grad = p.grad.clone()                      # the flat buffer is about to go away
+            if b.launched:
+                self._complete(b)
+            self._retire(b)
         self.buckets = []
 
     # ------------------------------------------------------------------ per step
@@ -184,27 +231,37 @@ class GradSync:
     def finish(self):
         """Wait for every bucket; afterwards every ``p.grad`` holds the mean over ranks.  Call after backward, before
         ``optimizer.step()`` (with accumulation: after the LAST micro-batch's backward)."""
-        if self._signature() != self._sig:
-            # requires_grad changed since the buckets were laid out (encoder_finetune_after, model.py:584-586): lay them out
-            # again and reduce this step's gradients from where autograd left them
-            self._build()
+        done = set()
+        if self._layout_stale():
+            # requires_grad changed since the buckets were laid out (encoder_finetune_after, model.py:584-586): lay the CHANGED buckets out
+            # again and reduce this step's gradients from where autograd left them.  Unchanged buckets keep their buffer and whatever
+            # all-reduce this step's hooks started on them; a changed bucket that had been launched is completed before its gradients move.
+            done = self._build()
         for b in self.buckets:
             if not b.launched:
+                if self.world == 1:
+                    # one process: no collective.  A gradient produced elsewhere moves into its slice (addresses then repeat from step to
+                    # step); a parameter WITHOUT a gradient keeps ``grad is None`` - the optimizer skips it, as torch and the reference do
+                    for p in b.params:
+                        if p.grad is not None:
+                            self._adopt(b, p)
+                    b.pending = 0
+                    continue
+                ids = [id(p) for p in b.params]
                 for p in b.params:                               # parameters the hooks did not see this step
                     self._adopt(b, p)
                 b.pending = 0
+                if ids and all(i in done for i in ids):          # every gradient in it already holds the mean (its old bucket was reduced)
+                    continue
+                if any(i in done for i in ids):                  # mixed: the reduced ones are equal on every rank; sum / world returns them
+                    pass
                 self._launch(b)
         for b in self.buckets:
-            if b.work is not None:
-                b.work.wait()
-                if b.wire is not None:
-                    b.flat.copy_(b.wire)
-                    b.wire = None
-                b.flat.div_(self.world)
-            b.work, b.launched, b.pending = None, False, 0
-            for p in b.params:
-                if p.grad is None:                               # unused this step: the mean of the ranks' zeros / gradients
-                    p.grad = b.view(p)
+            self._complete(b)
+            if self.world > 1:
+                for p in b.params:
+                    if p.grad is None:                           # unused this step: the mean of the ranks' zeros / gradients
+                        p.grad = b.view(p)
         self._early = set()
 
 

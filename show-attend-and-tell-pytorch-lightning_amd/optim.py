@@ -91,9 +91,25 @@ class FusedOptimizer(torch.optim.Optimizer):
         # Fast path: the same tensors, gradient addresses, learning rates and weight decays as the step before - the table on the device is
         # current, nothing to rebuild or upload (the per-parameter loop below is ~1.2 ms of host time at C2, 2.5 ms for resnet101, and C1 / C3
         # are host-bound).  Gradients living in persistent buckets (dist.GradSync) or reallocated at the same addresses hit it every step.
+        # Everything the table on the device points at is part of the key: the bf16 filter copies (remade by encoder.py whenever a parameter
+        # changed behind the optimizer's back - load_state_dict, broadcast, clamping - or created later by set_precision) and the state
+        # tensors (replaced by anything but this class's load_state_dict) would otherwise be written through stale addresses.
+        state = self.state
+        mv_key = []
+        for p, _ in entries:
+            st = state.get(p)
+            if not st:
+                mv_key = None
+                break
+            if self.kind == "sgd":
+                m = st.get("momentum_buffer"); mv_key.append(0 if m is None else m.data_ptr())
+            else:
+                mv_key.append(st["exp_avg"].data_ptr()); mv_key.append(st["exp_avg_sq"].data_ptr())
+        shadows = [getattr(p, "_sat_bf16_shadow", None) for p, _ in entries]
         fast_key = (tuple([p.grad.data_ptr() for p, _ in entries]), tuple([(g["lr"], g["weight_decay"]) for g in self.param_groups]),
-                    tuple([p.data_ptr() for p, _ in entries]))
-        if fast_key == getattr(self, "_fast_key", None) and self._fast_ok:
+                    tuple([p.data_ptr() for p, _ in entries]), tuple([0 if s is None else s.data_ptr() for s in shadows]),
+                    None if mv_key is None else tuple(mv_key))
+        if mv_key is not None and fast_key == getattr(self, "_fast_key", None) and self._fast_ok:
             self.fast_path_steps = getattr(self, "fast_path_steps", 0) + 1
             torch._foreach_add_(self._fast_steps, 1)
             step = float(self._fast_steps[0])
@@ -144,9 +160,18 @@ class FusedOptimizer(torch.optim.Optimizer):
             slot[1] = ev
             self._uploaded = raw
         # the fast path may take over when every gradient was used where it lies (no re-laid-out copy whose address would be stale)
+        if mv_key is None:          # first step: the state tensors were created above
+            mv = []
+            for p, _, _ in entries:
+                st = state[p]
+                if self.kind == "sgd":
+                    m = st.get("momentum_buffer"); mv.append(0 if m is None else m.data_ptr())
+                else:
+                    mv.append(st["exp_avg"].data_ptr()); mv.append(st["exp_avg_sq"].data_ptr())
+            fast_key = fast_key[:4] + (tuple(mv),)
         self._fast_key, self._fast_steps = fast_key, steps
         self._fast_ok = all(e[2] is e[0].grad for e in entries)
-        self._fast_shadowed = [e[0] for e in entries if getattr(e[0], "_sat_bf16_shadow", None) is not None]
+        self._fast_shadowed = [e[0] for i, e in enumerate(entries) if table[i].shadow_bf16]      # only the copies the kernel really rewrites
         return self._launch(lib, g0, beta1, beta2, step, chunks, loss)
 
     def _launch(self, lib, g0, beta1, beta2, step, chunks, loss):

@@ -121,9 +121,15 @@ def _worker(rank, world, port, out):
     for p in model.encoder.parameters():
         p.requires_grad = True
     model.zero_grad(set_to_none=True)
+    dec_bucket = sync.buckets[0]
     model(idx[sl], x[sl]).backward()
+    # the decoder bucket's all-reduce was started by this step's hooks on the OLD layout.  Let it complete before finish() re-lays the
+    # buckets out (the case that used to reduce the decoder gradients twice: world x mean) ...
+    assert dec_bucket.launched and dec_bucket.work is not None
+    dec_bucket.work.wait()
     sync.finish()
     assert len(sync.buckets) == 5
+    assert sync.buckets[0] is dec_bucket                 # ... the unchanged bucket is kept, with its buffer and its collective
     res["unfrozen"] = {k: p.grad.clone() for k, p in model.named_parameters()}
     model.zero_grad(set_to_none=True)                    # and the step after runs through the hooks again
     model(idx[sl], x[sl]).backward()
@@ -156,3 +162,48 @@ def test_two_rank_gradient_mean_matches_single_process(tmp_path):
                 assert torch.allclose(g0[k], p.grad, atol=2e-3 * p.grad.abs().max().item() + 1e-6, rtol=1e-2), (case, k)
             else:
                 assert torch.allclose(g0[k], p.grad, atol=1e-7, rtol=1e-5), (case, k)
+
+
+def test_one_process_gradsync_leaves_unused_parameters_without_a_gradient():
+    """world size 1: finish() must not invent zero gradients (Adam would decay its moments and apply weight decay on them); torch and the
+    reference skip parameters whose grad is None."""
+    sys.path.insert(0, ROOT)
+    import sat_amd  # noqa: F401
+    from sat_amd.dist import GradSync
+    torch.manual_seed(3)
+    model = Toy()
+    idx, x = _data()
+    unused = torch.nn.Parameter(torch.zeros(3))
+    model.unused = unused
+    sync2 = GradSync(model)
+    model.zero_grad(set_to_none=True)
+    model(idx, x).backward()
+    sync2.finish()
+    assert unused.grad is None
+    for k, p in model.named_parameters():
+        if p is not unused:
+            assert p.grad is not None, k
+            assert sync2._of[id(p)].owns(p), k          # produced gradients live in their slices (addresses repeat from step to step)
+    sync2.remove()
+
+
+def test_a_gradient_slice_is_handed_out_once_per_backward():
+    """two backward nodes of one parameter inside ONE backward pass: the second must not be given the same bucket slice (it would overwrite
+    the first node's gradient and autograd would add the slice to itself: 2 x g(b) instead of g(a) + g(b))"""
+    sys.path.insert(0, ROOT)
+    import sat_amd  # noqa: F401
+    from sat_amd.dist import GradSync
+    torch.manual_seed(4)
+    model = Toy()
+    idx, x = _data()
+    ref = Toy(); ref.load_state_dict(model.state_dict())
+    (ref(idx[:4], x[:4]) + ref(idx[4:], x[4:])).backward()
+    sync = GradSync(model)
+    for _ in range(2):
+        model.zero_grad(set_to_none=True)
+        (model(idx[:4], x[:4]) + model(idx[4:], x[4:])).backward()
+        sync.finish()
+        assert torch.allclose(model.sink.grad, ref.sink.grad, atol=1e-7, rtol=1e-6)
+        for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+            assert torch.allclose(p.grad, q.grad, atol=1e-7, rtol=1e-6), k
+    sync.remove()

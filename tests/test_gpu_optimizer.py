@@ -109,3 +109,55 @@ def test_pointer_table_survives_a_host_that_runs_ahead():
     for i, (p, q) in enumerate(zip(ref, dev)):
         err = float((q.detach().cpu() - p.detach()).abs().max())
         assert err <= 5e-6 * max(1.0, float(p.detach().abs().max())), (i, err)
+
+
+def test_fast_path_follows_replaced_bf16_copies_and_state_tensors():
+    """Constant learning rate and persistent gradient buffers put FusedOptimizer on its fast path (device table reused).  The table also holds
+    the addresses of the bf16 filter copies the encoder reads and of the moment tensors: a copy remade behind the optimizer's back (the
+    encoder does that when ``p._version`` moved), a copy that appears later (set_precision fp32 -> bf16 mid-run) and a replaced moment tensor
+    must all take the slow path once, not be written through the stale address."""
+    import sat_amd  # noqa: F401
+    from sat_amd.optim import FusedOptimizer
+    g = torch.Generator().manual_seed(5)
+    ref = [torch.randn(64, 8, 3, 3, generator=g).requires_grad_(), torch.randn(300, generator=g).requires_grad_()]
+    dev = [p.detach().clone().cuda().requires_grad_() for p in ref]
+    topt = torch.optim.Adam(ref, lr=1e-2)
+    fopt = FusedOptimizer(dev, kind="adam", lr=1e-2)
+    bufs = [torch.empty_like(q) for q in dev]
+    keep = []
+
+    def step(i):
+        for p, q, b in zip(ref, dev, bufs):
+            gr = torch.randn(p.shape, generator=g)
+            p.grad = gr.clone(); b.copy_(gr.cuda()); q.grad = b
+        topt.step(); fopt.step()
+
+    def shadow_ok():
+        sh = dev[0]._sat_bf16_shadow
+        assert torch.equal(sh, dev[0].detach().to(torch.bfloat16)), "the bf16 copy the encoder reads is not the rounded master weight"
+
+    step(0); step(1)
+    n_fast = getattr(fopt, "fast_path_steps", 0)
+    assert n_fast >= 1                                   # the second step already reused the table
+    # (b) a copy that did not exist when the table was built
+    dev[0]._sat_bf16_shadow = dev[0].detach().to(torch.bfloat16); dev[0]._sat_shadow_version = dev[0]._version
+    step(2); shadow_ok()
+    step(3); shadow_ok()
+    # (a) the copy remade after an in-place change of the weight (what encoder.py does when p._version moved); the old copy stays allocated
+    # here so that the new one has a different address, and is poisoned: a stale table would update the poisoned one
+    with torch.no_grad():
+        dev[0].mul_(0.5); ref[0].mul_(0.5)
+    keep.append(dev[0]._sat_bf16_shadow); keep[-1].fill_(float("nan"))
+    dev[0]._sat_bf16_shadow = dev[0].detach().to(torch.bfloat16); dev[0]._sat_shadow_version = dev[0]._version
+    step(4); shadow_ok()
+    assert torch.isnan(keep[-1].float()).all()           # nobody wrote through the old address
+    # a moment tensor replaced from outside
+    st = fopt.state[dev[1]]
+    old = st["exp_avg"]; st["exp_avg"] = old.clone(); keep.append(old); old.fill_(float("nan"))
+    step(5); step(6)
+    torch.cuda.synchronize()
+    assert torch.isnan(old).all()
+    for i, (p, q) in enumerate(zip(ref, dev)):
+        err = float((q.detach().cpu() - p.detach()).abs().max())
+        assert err <= 5e-6 * max(1.0, float(p.detach().abs().max())), (i, err)
+    assert fopt.fast_path_steps > n_fast                 # and the fast path is taken again once things repeat
