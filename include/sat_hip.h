@@ -13,9 +13,13 @@
  *     layout, conv weights are KRSC (torch channels_last memory), activations NHWC;
  *   - no allocation, no synchronisation, no ownership transfer: the caller provides
  *     outputs and a workspace (size from the *_workspace_bytes query) and a hipStream_t
- *     (passed as void*); calls are re-entrant per stream.  Stream capture (hipGraph): sat_beam_search_batched /
- *     _sampled enqueue kernels only and are tested under capture + replay; the other entry points also enqueue
- *     hipMemsetAsync / hipMemcpyAsync nodes (and read HOST arrays while enqueueing) and are NOT tested under capture;
+ *     (passed as void*); calls are re-entrant per stream.  Stream capture (hipGraph): every entry point enqueues KERNEL
+ *     launches only (clears and device-to-device copies are kernels too, csrc/devmem.hip), nothing reads host memory at
+ *     execution time and nothing synchronises, so a captured stream is a chain of kernel nodes.  `_host` arrays
+ *     (step_offsets_host, teacher_host) are read while ENQUEUEING: they shape the launch sequence, so a captured train step
+ *     is valid for that packing plan and those teacher-forcing flags (sat_amd/graph.py keys its graphs by them).  Tested under
+ *     capture + replay: sat_beam_search_batched / _sampled (tests/test_gpu_inference.py) and the whole train step - encoder,
+ *     sat_decoder_train_fwd / _bwd, the losses, sat_optimizer_step_dev - bit-equal to the eager step (tests/test_gpu_graph.py);
  *   - return 0 on success, non-zero otherwise with text in sat_last_error()
  *     (thread-local).  Nothing throws, nothing exits.
  */
@@ -28,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SAT_HIP_ABI_VERSION 18
+#define SAT_HIP_ABI_VERSION 19
 
 int sat_abi_version(void);
 /* dev aid: after every kernel launch wait for the device and print the launch's name to stderr (a device fault then points at the
@@ -433,6 +437,10 @@ int sat_grad_clip_coef(const sat_opt_tensor* tensors, const sat_opt_chunk* chunk
 /* p, m, v updated in place from g * clip_coef[0] (clip_coef NULL = 1) */
 int sat_optimizer_step(const sat_opt_tensor* tensors, const sat_opt_chunk* chunks, int32_t n_chunks, const sat_opt_hyper* hyper,
                        const float* clip_coef, void* stream);
+/* the same launch with the hyper-parameters in DEVICE memory (one sat_opt_hyper): a captured / replayed launch (hipGraph) then follows the
+ * step count (bias corrections) and the clipping settings that the host writes there before every replay (sat_amd/graph.py)            */
+int sat_optimizer_step_dev(const sat_opt_tensor* tensors, const sat_opt_chunk* chunks, int32_t n_chunks, const sat_opt_hyper* hyper_dev,
+                           const float* clip_coef, void* stream);
 
 /* ---- input pipeline on device ------------------------------------------------------------------------
  * Replaces, per batch, the per-sample PIL / torchvision chain of train.py:208-233: T.RandomResizedCrop | T.Resize +

@@ -187,7 +187,8 @@ SYMBOLS.update({
 })
 SYMBOLS.update({"sat_optimizer_chunk_elems": (C.c_int32, []),
                 "sat_grad_clip_coef": (C.c_int, [_vp, _vp, _i32, _f, _vp, _vp, _vp]),
-                "sat_optimizer_step": (C.c_int, [_vp, _vp, _i32, C.POINTER(OptHyper), _vp, _vp])})
+                "sat_optimizer_step": (C.c_int, [_vp, _vp, _i32, C.POINTER(OptHyper), _vp, _vp]),
+                "sat_optimizer_step_dev": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp])})
 SYMBOLS.update({"sat_stem_tail_fwd_t": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
                 "sat_stem_tail_bwd_t": (C.c_int, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])})
 _u64 = C.c_uint64
@@ -248,8 +249,8 @@ def lib():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(handle, name)          # AttributeError if the export is missing
             fn.restype, fn.argtypes = res, args
-        if handle.sat_abi_version() != 18:
-            raise SatHipError("libsat_hip.so ABI version %d != 18 (rebuild: make -C csrc)" % handle.sat_abi_version())
+        if handle.sat_abi_version() != 19:
+            raise SatHipError("libsat_hip.so ABI version %d != 19 (rebuild: make -C csrc)" % handle.sat_abi_version())
         _lib = handle
     return _lib
 

@@ -9,7 +9,7 @@
 namespace sat {
 static thread_local char g_err[512] = {0};
 int& dev_switch(int which) {
-    static int v[SW_COUNT] = {getenv("SAT_BN_TICKET") ? atoi(getenv("SAT_BN_TICKET")) : 0, getenv("SAT_NO_WGRAD3X3") ? !atoi(getenv("SAT_NO_WGRAD3X3")) : 1,
+    static int v[SW_COUNT] = {0 /* (ticket-based BatchNorm reduce: removed in round 3, measured slower) */, getenv("SAT_NO_WGRAD3X3") ? !atoi(getenv("SAT_NO_WGRAD3X3")) : 1,
                               getenv("SAT_REDUCE_Z16") ? atoi(getenv("SAT_REDUCE_Z16")) : 1, getenv("SAT_WIDE_TILES") ? atoi(getenv("SAT_WIDE_TILES")) : 0,
                               getenv("SAT_BN_ONEPASS") ? atoi(getenv("SAT_BN_ONEPASS")) : 1,
                               getenv("SAT_BN_VPT") ? atoi(getenv("SAT_BN_VPT")) : 2,
@@ -32,7 +32,6 @@ int sat_abi_version(void) { return SAT_HIP_ABI_VERSION; }
 int sat_debug_trace_launches(int32_t on) { sat::trace_launches() = on ? 1 : 0; return SAT_OK; }
 int sat_debug_option(const char* name, int32_t value) {
     if (!name) return fail(SAT_EINVAL, "debug_option: null name");
-    if (!strcmp(name, "bn_ticket")) { dev_switch(SW_BN_TICKET) = value; return SAT_OK; }
     if (!strcmp(name, "wgrad3x3")) { dev_switch(SW_WGRAD3X3) = value; return SAT_OK; }
     if (!strcmp(name, "reduce_z16")) { dev_switch(SW_REDUCE_Z16) = value; return SAT_OK; }
     if (!strcmp(name, "acc_prefetch")) { dev_switch(SW_ACC_PREFETCH) = value; return SAT_OK; }

@@ -44,6 +44,10 @@ inline int launch_ok(const char* what) {
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// devmem.hip: clears / device-to-device copies as kernel launches (the train path enqueues kernels only: capturable, see the file header)
+int dev_fill_bytes(hipStream_t st, void* ptr, int byte, size_t nbytes);
+int dev_copy_bytes(hipStream_t st, void* dst, const void* src, size_t nbytes);
+
 // ---- device helpers ----------------------------------------------------
 __device__ __forceinline__ float fast_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
 // tanh through one exp: |err| ~1e-7 absolute, saturates correctly for large |x|

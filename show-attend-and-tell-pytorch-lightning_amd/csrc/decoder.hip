@@ -148,7 +148,7 @@ static int gemm_bb_nn(hipStream_t st, const __bf16* A, long lda, const __bf16* B
 
 static int colsum(hipStream_t st, const Ws& w, const float* x, long ld, int rows, int cols, float* out, int accumulate = 0, float scale = 1.f) {
     if (cols <= 0) return SAT_OK;
-    if (rows <= 0) { if (!accumulate) SAT_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)cols * 4, st)); return SAT_OK; }
+    if (rows <= 0) { if (!accumulate) SAT_TRY(dev_fill_bytes(st, out, 0, (size_t)cols * 4)); return SAT_OK; }
     int nparts = cdiv(rows, 256);
     if (cols % 4 == 0 && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
         hipLaunchKernelGGL(colsum_part4_kernel, dim3(cdiv(cols / 4, 128), nparts), dim3(128), 0, st, x, ld, rows, cols / 4, 256, w.colpart);
@@ -333,8 +333,8 @@ int decoder_fwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
         SAT_TRY(gemm(st, A_ROW, B_ROW, w.mean_rows, D, p.init_f_w, D, w.f_rows, m, N, m, D, 0, EPI_BIAS, p.init_f_b));
         SAT_TRY(gemm(st, A_ROW, B_ROW, w.f_rows, m, p.init_i_w, m, w.init_rows, 2 * n * NL, N, 2 * n * NL, m, 0, EPI_BIAS, p.init_i_b));
         for (int l = 0; l < NL; ++l) {
-            SAT_CHECK_HIP(hipMemcpyAsync(Hs(0, l), w.init_rows + (long)l * N * n, (size_t)N * n * 4, hipMemcpyDeviceToDevice, st));
-            SAT_CHECK_HIP(hipMemcpyAsync(Cs(0, l), w.init_rows + (long)(NL + l) * N * n, (size_t)N * n * 4, hipMemcpyDeviceToDevice, st));
+            SAT_TRY(dev_copy_bytes(st, Hs(0, l), w.init_rows + (long)l * N * n, (size_t)N * n * 4));
+            SAT_TRY(dev_copy_bytes(st, Cs(0, l), w.init_rows + (long)(NL + l) * N * n, (size_t)N * n * 4));
         }
     } else {
         SAT_TRY(gemm(st, A_ROW, B_ROW, w.mean, D, p.init_f_w, D, w.f, m, d.B, m, D, 0, EPI_BIAS, p.init_f_b));
@@ -353,10 +353,10 @@ int decoder_fwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
         SAT_TRY(cast_bf16(st, Hs(0, 0), w.Hb, (long)N * n));
     }
     // alphas of steps that never run stay zero (model.py:506)
-    if (ts < T1) SAT_CHECK_HIP(hipMemsetAsync(alphas, 0, (size_t)N * T1 * d.L * 4, st));
+    if (ts < T1) SAT_TRY(dev_fill_bytes(st, alphas, 0, (size_t)N * T1 * d.L * 4));
 
     // tokens + embeddings + the embedding half of the LSTM input GEMM for every teacher-forced step, in one batch
-    SAT_CHECK_HIP(hipMemsetAsync(w.Tok, 0xFF, (size_t)T1 * N * 4, st));       // -1: no token
+    SAT_TRY(dev_fill_bytes(st, w.Tok, 0xFF, (size_t)T1 * N * 4));       // -1: no token
     for (int t = 0; t < ts;) {          // one launch per run of teacher-forced steps (the whole caption when epsilon = 1)
         if (!b.teacher_host[t]) { ++t; continue; }
         int t1 = t + 1;
@@ -372,7 +372,7 @@ int decoder_fwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
         hipLaunchKernelGGL(embedding_renorm_kernel, dim3(d.V), dim3(64), 0, st, p.embedding, w.flags, m, d.embed_max_norm);
         return launch_ok("embedding_renorm");
     };
-    if (d.embed_max_norm > 0.f) SAT_CHECK_HIP(hipMemsetAsync(w.flags, 0, (size_t)d.V * 4, st));
+    if (d.embed_max_norm > 0.f) SAT_TRY(dev_fill_bytes(st, w.flags, 0, (size_t)d.V * 4));
     if (ts > 0) {
         SAT_TRY(renorm(w.Tok, ts * N));
         hipLaunchKernelGGL(gather_rows_kernel, dim3(ts * N), dim3(64), 0, st, p.embedding, w.Tok, w.Y, ts * N, m, d.embedding_dropout, (unsigned long long)d.dropout_seed, 0L);
@@ -444,8 +444,8 @@ int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
     auto dCcs = [&](int l) { return w.dCc + (long)l * N * n; };
     float* const slab = w.slab; const long se = w.slab_elems;
 
-    SAT_CHECK_HIP(hipMemsetAsync(w.zero_begin, 0, (size_t)(w.zero_end - w.zero_begin), st));       // dHout, dZout, dHc, dCc, dU, dwf_part
-    if (NL > 1 && KR < T1 * N) SAT_CHECK_HIP(hipMemsetAsync(w.DGU, 0, (size_t)(NL - 1) * T1 * N * 4 * n * 4, st));
+    SAT_TRY(dev_fill_bytes(st, w.zero_begin, 0, (size_t)(w.zero_end - w.zero_begin)));       // dHout, dZout, dHc, dCc, dU, dwf_part
+    if (NL > 1 && KR < T1 * N) SAT_TRY(dev_fill_bytes(st, w.DGU, 0, (size_t)(NL - 1) * T1 * N * 4 * n * 4));
 
     // ---- output layer, all packed rows at once (DeepOutput backward)
     if (P > 0) {
@@ -462,8 +462,8 @@ int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
         if (d.deep_output)
             SAT_TRY(gemm(st, A_ROW, B_KMAJOR, w.dA, m, p.out_context, D, w.dZout, D, P, D, m, 0, EPI_NONE, nullptr, nullptr, b.src_row));
     } else {
-        SAT_CHECK_HIP(hipMemsetAsync(g.out_w, 0, (size_t)V * m * 4, st));
-        if (g.out_b) SAT_CHECK_HIP(hipMemsetAsync(g.out_b, 0, (size_t)V * 4, st));
+        SAT_TRY(dev_fill_bytes(st, g.out_w, 0, (size_t)V * m * 4));
+        if (g.out_b) SAT_TRY(dev_fill_bytes(st, g.out_b, 0, (size_t)V * 4));
     }
     // dA in time-major padded rows (zeros for finished captions): operand of the weight-grad GEMMs and of dY
     hipLaunchKernelGGL(scatter_rows_kernel, dim3(T1 * N), dim3(64), 0, st, w.dA, b.prow, w.dY, T1 * N, m);
@@ -473,7 +473,7 @@ int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
     if (d.deep_output)
         SAT_TRY(gemm(st, A_KMAJOR, B_KMAJOR, w.dY, m, w.Z, D, g.out_context, D, m, D, KR, 0, EPI_NONE, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, slab, se));
     else
-        SAT_CHECK_HIP(hipMemsetAsync(w.dY, 0, (size_t)T1 * N * m * 4, st));     // shallow output does not see the embedding
+        SAT_TRY(dev_fill_bytes(st, w.dY, 0, (size_t)T1 * N * m * 4));     // shallow output does not see the embedding
 
     // ---- back through time
     const size_t lds_b = att_bwd_lds(d.L, A, D);
@@ -542,11 +542,11 @@ int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
         SAT_TRY(wgrad(dgu, 4 * n, Hs(1, l - 1), n, g.up_w_ih[l - 1], n, 4 * n, n));
         SAT_TRY(wgrad(dgu, 4 * n, Hs(0, l), n, g.up_w_hh[l - 1], n, 4 * n, n));
         SAT_TRY(colsum(st, w, dgu, 4 * n, KR, 4 * n, g.up_b_ih[l - 1]));
-        SAT_CHECK_HIP(hipMemcpyAsync(g.up_b_hh[l - 1], g.up_b_ih[l - 1], (size_t)4 * n * 4, hipMemcpyDeviceToDevice, st));
+        SAT_TRY(dev_copy_bytes(st, g.up_b_hh[l - 1], g.up_b_ih[l - 1], (size_t)4 * n * 4));
     }
     SAT_TRY(colsum(st, w, w.DHC + A, HCW, KR, D, g.beta_b));
     SAT_TRY(colsum(st, w, dG, HCW, KR, 4 * n, g.b_ih));
-    SAT_CHECK_HIP(hipMemcpyAsync(g.b_hh, g.b_ih, (size_t)4 * n * 4, hipMemcpyDeviceToDevice, st));
+    SAT_TRY(dev_copy_bytes(st, g.b_hh, g.b_ih, (size_t)4 * n * 4));
     SAT_TRY(wgrad(dG, HCW, w.Y, m, g.w_ih, m + D, 4 * n, m));
     SAT_TRY(wgrad(dG, HCW, w.XZ, D, g.w_ih + m, m + D, 4 * n, D));
     // embedding: dY = dA (deep output) + dG * W_ih[:, :m], scattered into the table (padding row skipped)
@@ -557,13 +557,13 @@ int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
         SAT_TRY(launch_ok("embedding dropout bwd"));
     }
     if (KR > 0) {
-        SAT_CHECK_HIP(hipMemsetAsync(w.emb_count, 0, (size_t)V * 4, st));
+        SAT_TRY(dev_fill_bytes(st, w.emb_count, 0, (size_t)V * 4));
         hipLaunchKernelGGL(embedding_count_kernel, dim3(cdiv(KR, 256)), dim3(256), 0, st, w.Tok, KR, V, d.padding_idx, w.emb_count);
         hipLaunchKernelGGL(embedding_scan_kernel, dim3(1), dim3(1024), 0, st, w.emb_count, V, w.emb_offset, w.emb_cursor);
         hipLaunchKernelGGL(embedding_place_kernel, dim3(cdiv(KR, 256)), dim3(256), 0, st, w.Tok, KR, V, d.padding_idx, w.emb_offset, w.emb_cursor, w.emb_list);
         hipLaunchKernelGGL(embedding_sum_kernel, dim3(V), dim3(256), 0, st, w.dY, w.Tok, w.emb_offset, w.emb_list, g.embedding, KR, m, d.padding_idx);
         SAT_TRY(launch_ok("embedding gradient"));
-    } else SAT_CHECK_HIP(hipMemsetAsync(g.embedding, 0, (size_t)V * m * 4, st));
+    } else SAT_TRY(dev_fill_bytes(st, g.embedding, 0, (size_t)V * m * 4));
     // attention parameters and the annotation gradient
     SAT_TRY(colsum(st, w, w.dwf_part, A, d.B, A, g.att_f));
     SAT_TRY(gemm(st, A_KMAJOR, B_KMAJOR, w.dU, A, b.ann, D, g.att_enc, D, A, D, d.B * d.L, 0, EPI_NONE, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, slab, se));
@@ -587,8 +587,8 @@ int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
     // InitLSTM backward (the raw reshape is a reinterpretation: gradients of the repeated rows add up per image)
     if (d.dropout > 0.f) {                 // per-caption-row path (see decoder_fwd)
         const int n2 = 2 * n * NL;
-        SAT_CHECK_HIP(hipMemcpyAsync(w.init_rows, w.dHc, (size_t)NL * N * n * 4, hipMemcpyDeviceToDevice, st));
-        SAT_CHECK_HIP(hipMemcpyAsync(w.init_rows + (long)NL * N * n, w.dCc, (size_t)NL * N * n * 4, hipMemcpyDeviceToDevice, st));
+        SAT_TRY(dev_copy_bytes(st, w.init_rows, w.dHc, (size_t)NL * N * n * 4));
+        SAT_TRY(dev_copy_bytes(st, w.init_rows + (long)NL * N * n, w.dCc, (size_t)NL * N * n * 4));
         SAT_TRY(gemm(st, A_KMAJOR, B_KMAJOR, w.init_rows, n2, w.f_rows, m, g.init_i_w, m, n2, m, N));
         SAT_TRY(colsum(st, w, w.init_rows, n2, N, n2, g.init_i_b));
         SAT_TRY(gemm(st, A_ROW, B_KMAJOR, w.init_rows, n2, p.init_i_w, m, w.df_rows, m, N, m, n2));
@@ -645,11 +645,11 @@ int decoder_infer_begin(const sat_decoder_dims& d, const sat_decoder_params& p, 
     SAT_REQUIRE(ws_bytes >= w.total && K >= 1 && K <= Kmax, "decoder_infer_begin: workspace %zu < %zu or bad beam count %d/%d", ws_bytes, w.total, K, Kmax);
     t_bf16_mfma = d.precision ? 1 : 0;
     const int n = d.n, A = d.A, D = d.D, m = d.m;
-    SAT_CHECK_HIP(hipMemcpyAsync(w.Wcat, p.att_dec, (size_t)A * n * 4, hipMemcpyDeviceToDevice, st));
-    SAT_CHECK_HIP(hipMemcpyAsync(w.Wcat + (long)A * n, p.beta_w, (size_t)D * n * 4, hipMemcpyDeviceToDevice, st));
-    SAT_CHECK_HIP(hipMemcpyAsync(w.Wcat + (long)(A + D) * n, p.w_hh, (size_t)4 * n * n * 4, hipMemcpyDeviceToDevice, st));
-    SAT_CHECK_HIP(hipMemsetAsync(w.bcat, 0, (size_t)A * 4, st));
-    SAT_CHECK_HIP(hipMemcpyAsync(w.bcat + A, p.beta_b, (size_t)D * 4, hipMemcpyDeviceToDevice, st));
+    SAT_TRY(dev_copy_bytes(st, w.Wcat, p.att_dec, (size_t)A * n * 4));
+    SAT_TRY(dev_copy_bytes(st, w.Wcat + (long)A * n, p.beta_w, (size_t)D * n * 4));
+    SAT_TRY(dev_copy_bytes(st, w.Wcat + (long)(A + D) * n, p.w_hh, (size_t)4 * n * n * 4));
+    SAT_TRY(dev_fill_bytes(st, w.bcat, 0, (size_t)A * 4));
+    SAT_TRY(dev_copy_bytes(st, w.bcat + A, p.beta_b, (size_t)D * 4));
     hipLaunchKernelGGL(add_kernel, dim3(cdiv(4 * n, 256)), dim3(256), 0, st, w.bcat + A + D, p.b_ih, p.b_hh, (long)4 * n);
     SAT_TRY(launch_ok("bias add"));
     for (int l = 1; l < d.layers; ++l) {
@@ -925,7 +925,7 @@ int lstm_cell_bwd(const float* x, int in, const float* h_prev, const float* c_pr
                   float* dgates, float* scratch, int N, int n, hipStream_t st) {
     t_bf16_mfma = 0;
     // the cell kernel adds its `carry` inputs and leaves dc_prev in the cell carry: start them from the incoming cell gradient / zero
-    if (dc_new) SAT_CHECK_HIP(hipMemcpyAsync(dc_prev, dc_new, (size_t)N * n * 4, hipMemcpyDeviceToDevice, st));
+    if (dc_new) SAT_TRY(dev_copy_bytes(st, dc_prev, dc_new, (size_t)N * n * 4));
     else SAT_TRY(fill_f(st, dc_prev, (long)N * n, 0.f));
     SAT_TRY(fill_f(st, dh_prev, (long)N * n, 0.f));
     hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(cdiv((long)N * n, 256)), dim3(256), 0, st, gates, 4 * n, c_prev, c_new, dh_new, dh_prev, dc_prev, dgates, 4 * n,
@@ -937,7 +937,7 @@ int lstm_cell_bwd(const float* x, int in, const float* h_prev, const float* c_pr
     SAT_TRY(gemm(st, A_KMAJOR, B_KMAJOR, dgates, 4 * n, h_prev, n, dw_hh, n, 4 * n, n, N));
     Ws w; w.colpart = scratch;
     SAT_TRY(colsum(st, w, dgates, 4 * n, N, 4 * n, db_ih));
-    SAT_CHECK_HIP(hipMemcpyAsync(db_hh, db_ih, (size_t)4 * n * 4, hipMemcpyDeviceToDevice, st));
+    SAT_TRY(dev_copy_bytes(st, db_hh, db_ih, (size_t)4 * n * 4));
     return SAT_OK;
 }
 

@@ -274,70 +274,6 @@ __global__ __launch_bounds__(256) void bn_tile_reduce_kernel(const float* __rest
     }
 }
 
-// The same reduction with the finalize step folded in: every block publishes its partial (write-through stores, drained), draws a ticket per
-// channel group, and the block that draws the last ticket of its group reads all partials back (L1-bypassing loads) and finishes - in
-// a FIXED order that does not depend on which block came last, so results stay bit-reproducible.  Saves the separate finalize launch
-// (5 - 9 us of dependent-launch latency each, ~80 of them per C2 step).  `cnt`: one zeroed int per channel group; the last block re-arms it.
-// OFF by default (SAT_BN_TICKET=1 / sat_debug_option("bn_ticket", 1)): measured inside the C2 step it costs +0.14 ms (tools/ab_step.py:
-// 24.22 vs 24.08 ms) - the write-through stores, the ticket and the last block's serial tail outweigh the launch they save.
-//   mode 0 (forward) : mean / invstd (+ running statistics)   mode 1 (backward): dbeta = sum g, dgamma = sum g * xhat
-__global__ __launch_bounds__(256) void bn_tile_reduce_finish_kernel(const float* __restrict__ tiles, int ntiles, int C, int tiles_per, double* __restrict__ part0,
-                                                                    double* __restrict__ part1, int* __restrict__ cnt, int mode, long rows, float eps, float momentum,
-                                                                    float* __restrict__ out0, float* __restrict__ out1, float* __restrict__ running_mean,
-                                                                    float* __restrict__ running_var) {
-    __shared__ double sh[2][8][32];
-    __shared__ int s_last;
-    const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
-    const int t0 = blockIdx.y * tiles_per, t1 = min(ntiles, t0 + tiles_per);
-    double s = 0.0, q = 0.0;
-    if (c < C)
-        for (int t = t0 + pl; t < t1; t += 8) { const float2 v = reinterpret_cast<const float2*>(tiles)[(long)t * C + c]; s += (double)v.x; q += (double)v.y; }
-    sh[0][pl][cl] = s; sh[1][pl][cl] = q;
-    __syncthreads();
-    if (pl == 0 && c < C) {
-        double ss = 0.0, qq = 0.0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { ss += sh[0][k][cl]; qq += sh[1][k][cl]; }
-        // published write-through (agent-scope relaxed stores = sc1): no release fence, which on this chip writes back the whole L2
-        // (the first version with __threadfence() cost more than the launch it saved)
-        __hip_atomic_store(reinterpret_cast<unsigned long long*>(&part0[(long)blockIdx.y * C + c]), (unsigned long long)__double_as_longlong(ss), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(reinterpret_cast<unsigned long long*>(&part1[(long)blockIdx.y * C + c]), (unsigned long long)__double_as_longlong(qq), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores before the block's ticket
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = (__hip_atomic_fetch_add(&cnt[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.y - 1);
-    __syncthreads();
-    if (!s_last) return;
-    if (threadIdx.x == 0) __hip_atomic_store(&cnt[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);         // re-armed for the next launch on this scratch
-    const int np = gridDim.y;
-    s = 0.0; q = 0.0;
-    if (c < C)
-        for (int p = pl; p < np; p += 8) {           // agent-scope loads (sc1) bypass this CU's L1: every one of them
-            s += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&part0[(long)p * C + c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            q += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&part1[(long)p * C + c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        }
-    __syncthreads();
-    sh[0][pl][cl] = s; sh[1][pl][cl] = q;
-    __syncthreads();
-    if (pl != 0 || c >= C) return;
-    double ss = 0.0, qq = 0.0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { ss += sh[0][k][cl]; qq += sh[1][k][cl]; }
-    if (mode == 1) { out0[c] = (float)ss; out1[c] = (float)qq; return; }      // dbeta, dgamma
-    const double n = (double)rows;
-    double var = (qq - ss * ss / n) / n; if (var < 0.0) var = 0.0;
-    const double mu = ss / n;
-    out0[c] = (float)mu;
-    out1[c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (running_mean) {
-        const double unb = rows > 1 ? var * n / (n - 1.0) : var;
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
-    }
-}
-
 // Finalise: one 64-lane wave per channel sums the partials (lane-strided, then a fixed xor tree).
 // forward : mean / biased variance -> invstd, running stats (momentum, unbiased variance) as nn.BatchNorm2d
 __device__ __forceinline__ double wave_sum_d(double v) {
@@ -1233,19 +1169,6 @@ static int bn_train_fwd_t(const T* x, int64_t rows, int32_t C, const float* gamm
         int np = cdiv(ntiles, 64); if (np > nparts) np = nparts; if (np < 1) np = 1;          // partials fit the scratch sized for nparts
         const int per = cdiv(ntiles, np); np = cdiv(ntiles, per);
         p1 = p0 + (long)np * C;
-        const int fin = dev_switch(SW_BN_TICKET);
-        if (fin) {          // reduce + finalize in one launch (the last block of a channel group finishes)
-            int* cnt = reinterpret_cast<int*>(p0 + (long)nparts * C * 2 + 8);
-            SAT_CHECK_HIP(hipMemsetAsync(cnt, 0, (size_t)cdiv(C, 32) * sizeof(int), st));
-            hipLaunchKernelGGL(bn_tile_reduce_finish_kernel, dim3(cdiv(C, 32), np), dim3(256), 0, st, tile_stats, ntiles, C, per, p0, p1, cnt, 0, (long)rows, eps, momentum,
-                               save_mean, save_invstd, running_mean, running_var);
-            SAT_TRY(launch_ok("bn_tile_reduce_finish"));
-            if (!y) return SAT_OK;
-            long totalv = rows * (C / E);
-            ProfScope prof("bn_apply_fwd", 0.0, (double)rows * C * (sizeof(T) * (residual ? 3 : 2) + (relu_mask ? 0.125 : 0.0)), st);
-            launch_bn_apply_train<T>(x, save_mean, save_invstd, gamma, beta, residual, relu, y, relu_mask, totalv, C / E, rbn, st);
-            return launch_ok("bn_apply");
-        }
         hipLaunchKernelGGL(bn_tile_reduce_kernel, dim3(cdiv(C, 32), np), dim3(256), 0, st, tile_stats, ntiles, C, per, p0, p1);
         SAT_TRY(launch_ok("bn_tile_reduce"));
         nparts = np; shift_src = nullptr;
@@ -1295,17 +1218,9 @@ static int bn_train_bwd_t(const T* dy, const T* x, const T* y, int64_t rows, int
         int np = cdiv(ntiles, 64); if (np > nparts) np = nparts; if (np < 1) np = 1;
         const int per = cdiv(ntiles, np); np = cdiv(ntiles, per);
         p1 = p0 + (long)np * C;
-        const int fin = dev_switch(SW_BN_TICKET);
         if (dev_switch(SW_BN_ONEPASS) && bn_tile_finish_ok(ntiles)) {
             launch_bn_tile_finish(tile_stats, ntiles, C, 1, (long)rows, 0.f, 0.f, dbeta, dgamma, nullptr, nullptr, st);
             SAT_TRY(launch_ok("bn_tile_finish (backward)"));
-            tiles_done = true;
-        } else if (fin) {
-            int* cnt = reinterpret_cast<int*>(p0 + (long)nparts * C * 2 + 8);
-            SAT_CHECK_HIP(hipMemsetAsync(cnt, 0, (size_t)cdiv(C, 32) * sizeof(int), st));
-            hipLaunchKernelGGL(bn_tile_reduce_finish_kernel, dim3(cdiv(C, 32), np), dim3(256), 0, st, tile_stats, ntiles, C, per, p0, p1, cnt, 1, (long)rows, 0.f, 0.f,
-                               dbeta, dgamma, (float*)nullptr, (float*)nullptr);
-            SAT_TRY(launch_ok("bn_tile_reduce_finish (backward)"));
             tiles_done = true;
         } else {
             hipLaunchKernelGGL(bn_tile_reduce_kernel, dim3(cdiv(C, 32), np), dim3(256), 0, st, tile_stats, ntiles, C, per, p0, p1);

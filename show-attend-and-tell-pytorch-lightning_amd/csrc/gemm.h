@@ -68,7 +68,7 @@ int launch_gemm_bf16(const GemmArgs& a, hipStream_t stream);
 int gemm_bf16_eligible(const GemmArgs& a);
 // dev switches (environment variable = initial value; sat_debug_option(name, value) changes them at run time so that variants can be
 // timed alternately inside ONE process): index into dev_switch()
-enum { SW_BN_TICKET = 0, SW_WGRAD3X3 = 1, SW_REDUCE_Z16 = 2, SW_WIDE_TILES = 3, SW_BN_ONEPASS = 4, SW_BN_VPT = 5, SW_ACC_PREFETCH = 6, SW_COUNT = 7 };
+enum { SW_UNUSED0 = 0, SW_WGRAD3X3 = 1, SW_REDUCE_Z16 = 2, SW_WIDE_TILES = 3, SW_BN_ONEPASS = 4, SW_BN_VPT = 5, SW_ACC_PREFETCH = 6, SW_COUNT = 7 };
 int& dev_switch(int which);
 
 // wgrad3x3.hip: weight gradient of a 3x3 / stride 1 / pad 1 convolution with all nine taps per workgroup (bf16 activations, fp32 result)

@@ -9,16 +9,22 @@ namespace sat {
 template <int AM, int BMo, typename TC> int glds_run_64(const BArgs& k, hipStream_t st);
 template <int AM, int BMo, typename TC> int glds_run_128(const BArgs& k, hipStream_t st);
 template <int AM, int BMo, typename TC> int glds_run_128x64(const BArgs& k, hipStream_t st);
+#ifdef SAT_DEV_TILES      // `make DEV=1`: the 8-wave 256-row forms (measured slower inside the step) are kept out of the shipped library
 template <int AM, int BMo, typename TC> int glds_run_256x128(const BArgs& k, hipStream_t st);
 template <int AM, int BMo, typename TC> int glds_run_256(const BArgs& k, hipStream_t st);
+#endif
 
 // tile forms: 0 = 64x64, 1 = 128x128, 2 = 128x64 (4 waves); 3 = 256x128, 4 = 256x256 (8 waves, one workgroup per CU)
 enum { TILE_64 = 0, TILE_128 = 1, TILE_128x64 = 2, TILE_256x128 = 3, TILE_256 = 4 };
 template <int AM, int BMo, typename TC>
 static int rung_tiles(const BArgs& k, int tile, hipStream_t st, int* bm_used) {
     switch (tile) {
+#ifdef SAT_DEV_TILES
         case TILE_256: if (bm_used) *bm_used = 256; return glds_run_256<AM, BMo, TC>(k, st);
         case TILE_256x128: if (bm_used) *bm_used = 256; return glds_run_256x128<AM, BMo, TC>(k, st);
+#else
+        case TILE_256: case TILE_256x128: return -1;          // not in this build: the caller falls back to the 128 / 64 forms
+#endif
         case TILE_128: if (bm_used) *bm_used = 128; return glds_run_128<AM, BMo, TC>(k, st);
         case TILE_128x64: if (bm_used) *bm_used = 128; return glds_run_128x64<AM, BMo, TC>(k, st);
         default: if (bm_used) *bm_used = 64; return glds_run_64<AM, BMo, TC>(k, st);

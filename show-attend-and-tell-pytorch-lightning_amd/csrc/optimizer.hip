@@ -60,7 +60,8 @@ __device__ __forceinline__ void opt_update(const sat_opt_hyper& h, float lr, flo
 }
 
 __global__ __launch_bounds__(256) void optimizer_step_kernel(const sat_opt_tensor* __restrict__ tensors, const sat_opt_chunk* __restrict__ chunks,
-                                                             sat_opt_hyper h, const float* __restrict__ clip_coef) {
+                                                             sat_opt_hyper h, const sat_opt_hyper* __restrict__ h_dev, const float* __restrict__ clip_coef) {
+    if (h_dev) h = *h_dev;          // hyper-parameters read from device memory (sat_optimizer_step_dev: the launch is replayed from a graph, the step count moves on)
     const sat_opt_chunk c = chunks[blockIdx.x];
     const sat_opt_tensor t = tensors[c.tensor];
     const long end = (c.start + OPT_CHUNK < t.n) ? c.start + OPT_CHUNK : t.n;
@@ -128,8 +129,17 @@ int sat_optimizer_step(const sat_opt_tensor* tensors, const sat_opt_chunk* chunk
     if (n_chunks <= 0) return SAT_OK;
     SAT_REQUIRE(hyper->kind == SAT_OPT_SGD || hyper->kind == SAT_OPT_ADAM || hyper->kind == SAT_OPT_ADAMW, "optimizer_step: kind %d", hyper->kind);
     SAT_REQUIRE(hyper->kind == SAT_OPT_SGD || (hyper->bias_correction1 > 0.f && hyper->bias_correction2_sqrt > 0.f), "optimizer_step: bias corrections must be positive");
-    hipLaunchKernelGGL(optimizer_step_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, tensors, chunks, *hyper, clip_coef);
+    hipLaunchKernelGGL(optimizer_step_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, tensors, chunks, *hyper, (const sat_opt_hyper*)nullptr, clip_coef);
     return launch_ok("optimizer_step");
+}
+
+int sat_optimizer_step_dev(const sat_opt_tensor* tensors, const sat_opt_chunk* chunks, int32_t n_chunks, const sat_opt_hyper* hyper_dev,
+                           const float* clip_coef, void* stream) {
+    if (!tensors || !chunks || !hyper_dev) return fail(SAT_EINVAL, "optimizer_step_dev: null pointer");
+    if (n_chunks <= 0) return SAT_OK;
+    sat_opt_hyper none = {};
+    hipLaunchKernelGGL(optimizer_step_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, tensors, chunks, none, hyper_dev, clip_coef);
+    return launch_ok("optimizer_step_dev");
 }
 
 }

@@ -382,13 +382,15 @@ class SATDecoder(nn.Module):
             seed = int(torch.randint(0, 2 ** 62, (1,), generator=gen))
         return (p, pe, int(seed))
 
-    def train_decode(self, ann_bld, caps, lengths, epsilon=0, draw=None, with_loss=True, dropout_seed=None):
+    def train_decode(self, ann_bld, caps, lengths, epsilon=0, draw=None, with_loss=True, dropout_seed=None, teacher=None):
         """Decoder half of train_batch + the loss terms (model.py:487-557, 592-597).
 
-        ann_bld (B, L, D) on the GPU; caps (B, R, T) int64; lengths (B, R) int64 (host or device)."""
+        ann_bld (B, L, D) on the GPU; caps (B, R, T) int64; lengths (B, R) int64 (host or device).  ``teacher``: the scheduled-sampling
+        decisions of this batch when the caller has drawn them already (``PackPlan.teacher_flags``; graph.py keys its graphs by them)."""
         B, R, T = caps.shape
         plan = Dk.PackPlan.cached(lengths.reshape(-1).cpu(), T, ann_bld.device)
-        teacher = plan.teacher_flags(float(epsilon), draw)
+        if teacher is None:
+            teacher = plan.teacher_flags(float(epsilon), draw)
         caps2 = caps.reshape(B * R, T)
         caps_i32 = caps2.to(device=ann_bld.device, dtype=torch.int32).contiguous()
         logits_packed, alphas = Dk.DecoderTrainFn.apply(ann_bld, caps_i32, plan, teacher, bool(self.hp.deep_output), self.pad_idx, R,
@@ -484,14 +486,13 @@ class SAT(SATDecoder, _Base):
             return self.beam_decode(ann_bld.contiguous(), hw, beamk, max_gen_length, temperature, sample_method, sample_topk,
                                     decoder_noise, rescore_method, rescore_reward, return_all)
 
-    def train_batch(self, batch, epsilon=0, draw=None):
+    def train_batch(self, batch, epsilon=0, draw=None, teacher=None):
         img, encoded_captions, lengths = batch
         ann_bld, _ = self.encode(img)
-        res = self.train_decode(ann_bld, encoded_captions, lengths, float(epsilon), draw, with_loss=False)
+        res = self.train_decode(ann_bld, encoded_captions, lengths, float(epsilon), draw, with_loss=False, teacher=teacher)
         plan = res["plan"]
         lp = PackedSequence(res["logits_packed"], plan.batch_sizes, plan.sorted_indices_dev, plan.unsorted_indices_dev)
         tp = PackedSequence(res["targets_packed"], plan.batch_sizes, plan.sorted_indices_dev, plan.unsorted_indices_dev)
-        self._last = res
         return lp, tp, res["alphas"]
 
     def teacher_forcing_epsilon(self, current_epoch=0):
@@ -541,8 +542,9 @@ class SAT(SATDecoder, _Base):
             if type(self.scheduler) in [CosineAnnealingWarmRestarts, OneCycleLR]:
                 self.scheduler.step()
 
-    def training_step(self, batch, batch_idx=0):
-        """model.py:559-628: returns the metrics dict whose "loss" the trainer back-propagates."""
+    def _step_begin(self):
+        """host half of ``training_step`` in front of the device work (model.py:559-586): (epsilon, optimizer steps so far); unfreezes the
+        encoder at ``encoder_finetune_after``"""
         hp = self.hp
         epoch = int(getattr(self, "current_epoch", 0) or 0)        # Lightning's property, or a plain attribute set by the caller's loop
         epsilon = self.teacher_forcing_epsilon(epoch)
@@ -550,15 +552,31 @@ class SAT(SATDecoder, _Base):
         if gstep == hp.encoder_finetune_after and hp.encoder_finetune_after >= 0:
             for p in self.encoder.parameters():
                 p.requires_grad = True
-        lp, tp, alphas = self.train_batch(batch, epsilon)
+        return epsilon, gstep
+
+    def _step_losses(self, batch, epsilon, teacher=None):
+        """device half: forward + the two loss terms (model.py:588-597)"""
+        lp, tp, alphas = self.train_batch(batch, epsilon, teacher=teacher)
         loss = self.criterion(lp.data, tp.data)                                   # model.py:592
-        loss = loss + Dk.DoublyStochasticFn.apply(alphas, float(hp.att_gamma))      # model.py:594
+        loss = loss + Dk.DoublyStochasticFn.apply(alphas, float(self.hp.att_gamma))      # model.py:594
+        return loss
+
+    def _step_end(self, gstep):
+        """host half behind the device work (model.py:614-626): learning-rate recipe, optimizer-step count"""
+        hp = self.hp
         self.step_learning_rate(gstep)                                            # model.py:614-626
         micro = self.__dict__["_sat_micro_batches"] + 1
         if micro >= max(1, int(getattr(hp, "accumulate", 1) or 1)):                # the trainer steps the optimizer after this batch
             self.__dict__["_sat_global_step"] += 1
             micro = 0
         self.__dict__["_sat_micro_batches"] = micro
+
+    def training_step(self, batch, batch_idx=0):
+        """model.py:559-628: returns the metrics dict whose "loss" the trainer back-propagates.  (Split in three so that
+        ``graph.GraphedTrainStep`` can replay the device half from a hipGraph and still run the two host halves every step.)"""
+        epsilon, gstep = self._step_begin()
+        loss = self._step_losses(batch, epsilon)
+        self._step_end(gstep)
         return {"loss": loss, "accuracy": self.criterion.last_accuracy, "epsilon_tf": float(epsilon)}
 
     # ------------------------------------------------------------------ validation (model.py:630-718)

@@ -73,6 +73,63 @@ class FusedOptimizer(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        host = self._host_step()
+        if host is None:
+            return loss
+        g0, beta1, beta2, step, chunks = host
+        return self._launch(L.lib(), g0, beta1, beta2, step, chunks, loss)
+
+    # ---- the step in two halves for a replayed launch (graph.GraphedTrainStep): everything the host does - step counters, the pointer /
+    # learning-rate table and its upload, the hyper-parameters of this step written to DEVICE memory - and the kernel launches, which read
+    # nothing but device memory and can therefore sit in a captured graph
+    @torch.no_grad()
+    def step_host(self):
+        host = self._host_step()
+        if host is None:
+            raise RuntimeError("FusedOptimizer.step_host: no parameter has a gradient")
+        g0, beta1, beta2, step, _ = host
+        hyper = self._hyper(g0, beta1, beta2, step)
+        dev = self._dev.device
+        self.prepare_device_step(dev)
+        self._hyper_pos = (self._hyper_pos + 1) % len(self._hyper_ring)
+        slot = self._hyper_ring[self._hyper_pos]
+        if slot[1] is not None:
+            slot[1].synchronize()                      # the upload that last read this pinned block has executed (the host may run steps ahead)
+        C.memmove(slot[0].data_ptr(), C.addressof(hyper), C.sizeof(L.OptHyper))
+        self._hyper_dev.copy_(slot[0], non_blocking=True)
+        ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(dev)); slot[1] = ev
+
+    def step_device(self):
+        """the launches of one step (gradient-norm coefficient when clipping by norm, the update), hyper-parameters from device memory"""
+        lib = L.lib()
+        if getattr(self, "_hyper_dev", None) is None:
+            raise RuntimeError("FusedOptimizer.step_device before step_host")
+        coef = None
+        if self.grad_clip == "norm":
+            L.check(lib.sat_grad_clip_coef(L.ptr(self._dev), L.ptr(self._chunks), self._n_chunks, self.clip_value, L.ptr(self._scratch),
+                                           L.ptr(self._coef), L.stream_ptr()), "sat_grad_clip_coef")
+            coef = self._coef
+            self.last_grad_norm = self._coef[1]
+        L.check(lib.sat_optimizer_step_dev(L.ptr(self._dev), L.ptr(self._chunks), self._n_chunks, L.ptr(self._hyper_dev), L.ptr(coef), L.stream_ptr()),
+                "sat_optimizer_step_dev")
+
+    def prepare_device_step(self, dev):
+        """device / pinned blocks of the hyper-parameters (allocated once, before a capture)"""
+        if getattr(self, "_hyper_dev", None) is None or self._hyper_dev.device != dev:
+            n = C.sizeof(L.OptHyper)
+            self._hyper_dev = torch.zeros(n, dtype=torch.uint8, device=dev)
+            self._hyper_ring = [[torch.empty(n, dtype=torch.uint8).pin_memory(), None] for _ in range(4)]
+            self._hyper_pos = 0
+
+    def table_signature(self):
+        """what ``_tables`` keys the chunk / pointer tables by, for the parameters that hold a gradient now"""
+        return tuple((p.data_ptr(), p.numel()) for g in self.param_groups for p in g["params"] if p.grad is not None)
+
+    def device_buffers(self):
+        """addresses a captured ``step_device`` has baked in (graph.py re-captures when they move)"""
+        return tuple(t.data_ptr() for t in (self._dev, self._chunks, self._scratch, self._coef, self._hyper_dev))
+
+    def _host_step(self):
         lib = L.lib()
         entries = []
         for group in self.param_groups:
@@ -80,7 +137,7 @@ class FusedOptimizer(torch.optim.Optimizer):
                 if p.grad is not None:
                     entries.append((p, group))
         if not entries:
-            return loss
+            return None
         L.require_gpu(*[p for p, _ in entries])
         dev = entries[0][0].device
         g0 = self.param_groups[0]
@@ -115,7 +172,7 @@ class FusedOptimizer(torch.optim.Optimizer):
             step = float(self._fast_steps[0])
             for q in self._fast_shadowed:
                 q._sat_shadow_version = q._version
-            return self._launch(lib, g0, beta1, beta2, step, self._chunks, loss)
+            return g0, beta1, beta2, step, self._chunks
         chunks = self._tables(entries, dev)
         self._ring_pos = (self._ring_pos + 1) % len(self._ring)
         slot = self._ring[self._ring_pos]
@@ -172,7 +229,12 @@ class FusedOptimizer(torch.optim.Optimizer):
         self._fast_key, self._fast_steps = fast_key, steps
         self._fast_ok = all(e[2] is e[0].grad for e in entries)
         self._fast_shadowed = [e[0] for i, e in enumerate(entries) if table[i].shadow_bf16]      # only the copies the kernel really rewrites
-        return self._launch(lib, g0, beta1, beta2, step, chunks, loss)
+        return g0, beta1, beta2, step, chunks
+
+    def _hyper(self, g0, beta1, beta2, step):
+        return L.OptHyper(kind=KINDS[self.kind], nesterov=int(bool(g0["nesterov"])), first_step=int(step == 1), beta1=beta1, beta2=beta2,
+                          eps=g0["eps"], bias_correction1=1.0 - beta1 ** step, bias_correction2_sqrt=math.sqrt(1.0 - beta2 ** step),
+                          momentum=float(g0["momentum"]), clip_value=self.clip_value if self.grad_clip == "value" else 0.0)
 
     def _launch(self, lib, g0, beta1, beta2, step, chunks, loss):
         coef = None
@@ -181,9 +243,7 @@ class FusedOptimizer(torch.optim.Optimizer):
                                            L.ptr(self._coef), L.stream_ptr()), "sat_grad_clip_coef")
             coef = self._coef
             self.last_grad_norm = self._coef[1]
-        hyper = L.OptHyper(kind=KINDS[self.kind], nesterov=int(bool(g0["nesterov"])), first_step=int(step == 1), beta1=beta1, beta2=beta2,
-                           eps=g0["eps"], bias_correction1=1.0 - beta1 ** step, bias_correction2_sqrt=math.sqrt(1.0 - beta2 ** step),
-                           momentum=float(g0["momentum"]), clip_value=self.clip_value if self.grad_clip == "value" else 0.0)
+        hyper = self._hyper(g0, beta1, beta2, step)
         L.check(lib.sat_optimizer_step(L.ptr(self._dev), L.ptr(chunks), self._n_chunks, C.byref(hyper), L.ptr(coef), L.stream_ptr()),
                 "sat_optimizer_step")
         return loss
