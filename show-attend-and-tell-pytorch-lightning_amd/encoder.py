@@ -220,6 +220,13 @@ _DGRAD_JOIN = os.environ.get("SAT_DGRAD_JOIN", "1") != "0"
 _FWD_RES_BN = os.environ.get("SAT_FWD_RES_BN", "1") != "0"
 _WGRAD_STREAMS = int(os.environ.get("SAT_WGRAD_STREAMS", "1"))          # side streams the launches are dealt to in turn
 _WGRAD_SIDE_ONLY = int(os.environ.get("SAT_WGRAD_SIDE_ONLY", "0"))      # dev: which filters go to the side stream (0 = all)
+#: the side stream is used from this many input pixels per batch on (N x H x W of the images).  Every fork / join costs the host ~40 us
+#: (event record, stream wait, allocator bookkeeping of the tensors the side stream reads); with few images the weight-gradient kernels are
+#: shorter than that and the step becomes host-bound: C1 (8 images of 256 x 256) steps in 4.2 ms with everything on the main stream and in
+#: 4.9 ms with the side stream, C3's shard (32 images) in 15.5 vs 14.7 ms, C2 (128) in 22.0 vs 21.6 (tools/graph_step_time.py).
+#: A version with ONE library call per fork and the tensors kept referenced until the join (no record_stream) measured SLOWER
+#: (C3 14.7 -> 17.6 .. 21 ms: the allocator then cycles through far more live blocks per backward).
+_WGRAD_SIDE_MIN_INPUT_PIXELS = int(os.environ.get("SAT_WGRAD_SIDE_MIN_INPUT_PIXELS", str(16 * 256 * 256)))
 _side_streams = {}
 _JOIN_LAG = None          # dev: a list collects (main-arrival, side-done) event pairs of every join
 
@@ -701,7 +708,8 @@ class EncoderFn(torch.autograd.Function):
             for n in n_per_stage:
                 acc += n; bounds.append(acc)
             tiles = None
-            queue = _SideQueue(d.device, _WGRAD_STREAM and bf)
+            x0s = t["x0"].shape
+            queue = _SideQueue(d.device, _WGRAD_STREAM and bf and x0s[0] * x0s[1] * x0s[2] * (2 if t.get("stem_pairs") else 1) >= _WGRAD_SIDE_MIN_INPUT_PIXELS)
             for idx in range(len(recs) - 1, -1, -1):
                 d, tiles = _block_bwd(recs[idx], d, grads, True, Wt, dout_tiles=tiles, prev=(recs[idx - 1] if idx > 0 else None), queue=queue)
                 if cb is not None and idx in (bounds[2], bounds[1], bounds[0]):      # a ResNet stage just finished
