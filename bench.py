@@ -139,6 +139,118 @@ def cpu_baseline(cfg, seconds_budget=24.0, max_steps=16):
             "s_per_step": round(dt, 3)}
 
 
+
+def _build_train(cfg, dev, precision="bf16", decoder_tf="always", batch=None, rank=0, ragged=False):
+    """model + optimizer + gradient exchange + one resident synthetic batch of config ``cfg`` (the train step of bench.py's headline)"""
+    import torch
+    from sat_amd import model as M
+    from sat_amd.dist import GradSync, broadcast_parameters
+    hp, T, B, R = hparams(cfg)
+    if batch:
+        B = batch
+    if decoder_tf == "none":
+        hp["decoder_tf"] = None
+    torch.manual_seed(42)
+    model = M.SAT(**hp).to(dev).train()
+    model.set_precision(precision)
+    broadcast_parameters(model)
+    model.__dict__["_sat_global_step"] = 2          # past encoder_finetune_after: the encoder trains (and is in the optimizer)
+    opt = model.configure_optimizers()
+    sync = GradSync(model)
+    img, caps, lengths = synthetic_batch(B, R, T, hp["vocab_size"], 1234 + rank, ragged)
+    return model, opt, sync, (img.to(dev), caps.to(dev), lengths), (hp, T, B, R)
+
+
+def sub_line_train(cfg, dev, steps=5, warmup=5, decoder_tf="always", attention=False, graph=False):
+    """A short line for one more BASELINE configuration (per-GPU shard sizes of CONFIGS): ms per train step after ``warmup`` untimed steps (and at
+    least 0.6 s of them).  ``attention``: two more steps with the attention kernels bracketed by HIP events -> their time and algorithmic bytes
+    (the annotation stream once per image-step) against the HBM peak.  ``graph``: the same step replayed from a hipGraph."""
+    import torch
+    from sat_amd import _lib
+    model, opt, sync, batch, (hp, T, B, R) = _build_train(cfg, dev, decoder_tf=decoder_tf)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = model.training_step(batch, 0)
+        out["loss"].backward()
+        sync.finish()
+        opt.step()
+
+    t0 = time.perf_counter(); n = 0
+    while n < warmup or time.perf_counter() - t0 < 0.6:
+        step(); torch.cuda.synchronize(); n += 1
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    out = {"workload": "%s: %s encoder_size=%s encoder_dim=%d vocab=%d T=%d, %d images x R=%d captions on this GPU, decoder_tf=%s" % (
+               cfg.upper(), CONFIGS[cfg][0], CONFIGS[cfg][1], CONFIGS[cfg][2], hp["vocab_size"], T, B, R, decoder_tf),
+           "ms_per_step": round(dt * 1e3, 3), "value": round(B * R / dt, 1), "unit": "captions/s", "steps": steps, "warmup": n, "dtype": "bf16"}
+    if attention:
+        _lib.profile_start(only="attention*")
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        rows = {}
+        for e in _lib.profile_stop():
+            us = e["total_ms"] * 1e3 / e["launches"]
+            gbs = e["bytes"] / (e["total_ms"] * 1e-3) / 1e9
+            rows[e["name"]] = {"us_per_launch": round(us, 2), "launches_per_step": e["launches"] // 2, "algorithmic_mb_per_launch": round(e["bytes"] / e["launches"] / 1e6, 2),
+                               "gbytes_per_s": round(gbs, 1), "hbm_frac": round(gbs / PEAK_HBM_GBS, 4)}
+        out["attention"] = rows
+    if graph:
+        from sat_amd.graph import GraphedTrainStep
+        stepper = GraphedTrainStep(model, opt, sync=sync)
+        for _ in range(4):
+            stepper(batch, 0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            stepper(batch, 0)
+        torch.cuda.synchronize()
+        out["graph_replay_ms_per_step"] = round((time.perf_counter() - t0) / steps * 1e3, 3)
+        out["graph_steps"] = dict(stepper.stats)
+    sync.remove()
+    del model, opt, sync, batch
+    torch.cuda.empty_cache()
+    return out
+
+
+def sub_line_decode(model, dev, images=64, max_len=20):
+    """BASELINE configs[4] (C5): caption() on ``images`` images - the headline model (resnet50, encoder_size 7) in eval mode, batched beam search
+    of width 5 and greedy (width 1), decode-only (annotations resident) eager / replayed from a hipGraph, and end to end with the encoder."""
+    import torch
+    hp = model.hp
+    was = model.training
+    model.eval()
+    img = torch.rand(images, 3, hp.input_size, hp.input_size, device=dev)
+    out = {"workload": "C5: resnet50 encoder, %d images of %d px, max_gen_length=%d, batched beam search (sat_beam_search_batched)" % (images, hp.input_size, max_len),
+           "unit": "images/s", "dtype": "bf16"}
+    with torch.no_grad():
+        ann, hw = model.encode(img)
+        ann = ann.contiguous()
+        for beamk in (5, 1):
+            row = {}
+            for name, kw in (("decode_only", {}), ("decode_only_graph", {"graph": True})):
+                for _ in range(2):
+                    model.beam_decode_batched(ann, hw, beamk=beamk, max_gen_length=max_len, **kw)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(5):
+                    model.beam_decode_batched(ann, hw, beamk=beamk, max_gen_length=max_len, **kw)
+                torch.cuda.synchronize()
+                row[name] = round(images / ((time.perf_counter() - t0) / 5), 1)
+            model.caption(img, beamk=beamk, max_gen_length=max_len)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(3):
+                model.caption(img, beamk=beamk, max_gen_length=max_len)
+            torch.cuda.synchronize()
+            row["end_to_end"] = round(images / ((time.perf_counter() - t0) / 3), 1)
+            out["beam%d" % beamk] = row
+    model.train(was)
+    return out
+
+
 _T0 = time.time()
 
 
@@ -329,6 +441,28 @@ def main():
         dt = float(tt.item())
     loss_val = float(out["loss"].item())
     log("timed region: %.1f ms/step" % (dt / args.steps * 1e3))
+    # ---- N > 1: what the exchange costs beyond the backward pass it overlaps (three untimed steps): the time the stream spends between the end of
+    # backward() and the end of GradSync.finish() (collectives still running + the divide), and which buckets started inside the encoder backward
+    exchange = None
+    if world > 1:
+        ex = []
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            o = model.training_step((img, caps, lengths), 0)
+            o["loss"].backward()
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(); sync.finish(); e1.record()
+            opt.step()
+            torch.cuda.synchronize()
+            ex.append(e0.elapsed_time(e1))
+        del o
+        tt = torch.tensor([sorted(ex)[1]], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        exchange = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "allreduce_exposed_ms": round(float(tt.item()), 3),
+                    "buckets": [{"params": len(bk.params), "mbytes": round(bk.flat.numel() * 4 / 1e6, 1), "launched_inside_backward": i in sync.last_early}
+                                for i, bk in enumerate(sync.buckets)],
+                    "bucket_dtype": args.bucket_dtype,
+                    "what": "median over 3 untimed steps, max over ranks, of the stream time between the end of backward() and the end of GradSync.finish()"}
 
     line = None
     if rank == 0:
@@ -425,6 +559,45 @@ def main():
                                     "dtype": "f32", "note": "exact fp32 MFMA, fp32 activations: logits / alphas within 1e-4 of the reference"}
         log("fp32 parity mode: %.1f ms/step" % (d32 * 1e3))
         model.set_precision("bf16")
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+    if line is not None and exchange is not None:
+        line["exchange"] = exchange
+    # ---- every other BASELINE configuration as a short sub-line: 5 + 5 steps each, one GPU
+    if world == 1 and not args.no_extras and args.config == "c2" and args.precision == "bf16" and not args.batch:
+        subs = {}
+        try:
+            from sat_amd.graph import GraphedTrainStep
+            stepper = GraphedTrainStep(model, opt, sync=sync)
+            for _ in range(4):
+                stepper((img, caps, lengths), 0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                stepper((img, caps, lengths), 0)
+            torch.cuda.synchronize()
+            subs["c2_graph_replay"] = {"ms_per_step": round((time.perf_counter() - t0) / 10 * 1e3, 3), "steps": dict(stepper.stats),
+                                       "what": "the headline step captured into a hipGraph and replayed (sat_amd/graph.py); bit-equal to the eager step (tests/test_gpu_graph.py)"}
+            del stepper
+            log("C2 graph replay: %.1f ms/step" % subs["c2_graph_replay"]["ms_per_step"])
+            subs["c5_decode"] = sub_line_decode(model, dev)
+            log("C5 decode: beam 5 %s images/s, greedy %s images/s (decode only)" % (subs["c5_decode"]["beam5"]["decode_only"], subs["c5_decode"]["beam1"]["decode_only"]))
+            sync.remove()
+            del model, opt, sync
+            torch.cuda.empty_cache()
+            subs["c2_decoder_tf_none"] = sub_line_train("c2", dev, decoder_tf="none")
+            log("C2 decoder_tf=None: %.1f ms/step" % subs["c2_decoder_tf_none"]["ms_per_step"])
+            subs["c1"] = sub_line_train("c1", dev, steps=10, graph=True)
+            log("C1: %.2f ms/step" % subs["c1"]["ms_per_step"])
+            subs["c3_shard"] = sub_line_train("c3", dev, graph=True)
+            log("C3 shard: %.1f ms/step" % subs["c3_shard"]["ms_per_step"])
+            subs["c4_shard"] = sub_line_train("c4", dev, attention=True)
+            log("C4 shard: %.1f ms/step" % subs["c4_shard"]["ms_per_step"])
+        except Exception as exc:          # a sub-line must never cost the headline
+            subs["error"] = "%s: %s" % (type(exc).__name__, exc)
+            log("sub-lines stopped: %s" % subs["error"])
+        line["sub_lines"] = subs
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -4,6 +4,7 @@
 #include "../../include/sat_hip.h"
 #include <stdlib.h>
 #include "decoder.h"
+#include "profile.h"
 #include "decoder_kernels.h"
 #include "gemm.h"
 
@@ -180,8 +181,15 @@ static int attention_fwd_split(hipStream_t st, const TA* ann, const float* U, co
     SAT_REQUIRE(lds_s <= 160 * 1024 && lds_c <= 160 * 1024, "attention_fwd: L=%d A=%d do not fit the LDS", L, A);
     SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_scores_kernel<RN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
     SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_context_kernel<RN, TA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
-    hipLaunchKernelGGL(attention_scores_kernel<RN>, dim3(B, cdiv(L, ATTS_WAVES)), dim3(ATTS_WAVES * 64), lds_s, st, U, hc, hc_ld, wf, sc, R, L, A);
-    SAT_TRY(launch_ok("attention_scores"));
+    // algorithmic bytes (per image-step): scores read att_enc U (L x A fp32) and the R query rows, write R x L raw scores; context streams the
+    // image's annotations (L x D) ONCE for its R captions, reads scores + gates, writes alphas, z and the gated context
+    const double N = (double)B * R;
+    {
+        ProfScope prof("attention_scores", 2.0 * N * L * A, 4.0 * ((double)B * L * A + N * (A + L)), st);
+        hipLaunchKernelGGL(attention_scores_kernel<RN>, dim3(B, cdiv(L, ATTS_WAVES)), dim3(ATTS_WAVES * 64), lds_s, st, U, hc, hc_ld, wf, sc, R, L, A);
+        SAT_TRY(launch_ok("attention_scores"));
+    }
+    ProfScope prof("attention_context", 2.0 * N * L * D, (double)sizeof(TA) * B * L * D + 4.0 * N * (2.0 * L + 3.0 * D), st);
     hipLaunchKernelGGL((attention_context_kernel<RN, TA>), dim3(B, cdiv(D, ATTC_DCH)), dim3(256), lds_c, st, ann, sc, hc, hc_ld, lengths, step, alphas, T1, Z, XZ, R, L, D, A, xzb);
     return launch_ok("attention_context");
 }
@@ -245,9 +253,16 @@ static int attention_bwd_split_t(hipStream_t st, const TA* ann, const float* U, 
     SAT_REQUIRE(lds_a <= 160 * 1024 && lds_t <= 160 * 1024, "attention_bwd: L=%d D=%d do not fit the LDS", L, D);
     SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_dalpha_kernel<RN, TA>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
     SAT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_tanh_kernel<RN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
-    hipLaunchKernelGGL((attention_bwd_dalpha_kernel<RN, TA>), dim3(B, cdiv(L, 16)), dim3(1024), lds_a, st, ann, hc, hc_ld, lengths, step, dalphas, T1, Zs, dZ_out, dXZ, DZ, dhc,
-                       dhc_ld, da, R, L, D, A, dhcb);
-    SAT_TRY(launch_ok("attention_bwd_dalpha"));
+    // algorithmic bytes: dalpha streams the annotations once per image, reads the R gradient rows of z / gated z / the gate (3 x D) and z, writes dz and
+    // d(alpha); tanh reads att_enc and d(alpha), alphas, the queries, and adds into dU (read + write)
+    const double N = (double)B * R;
+    {
+        ProfScope prof("attention_bwd_dalpha", 2.0 * N * L * D, (double)sizeof(TA) * B * L * D + 4.0 * N * (5.0 * D + 2.0 * L), st);
+        hipLaunchKernelGGL((attention_bwd_dalpha_kernel<RN, TA>), dim3(B, cdiv(L, 16)), dim3(1024), lds_a, st, ann, hc, hc_ld, lengths, step, dalphas, T1, Zs, dZ_out, dXZ, DZ, dhc,
+                           dhc_ld, da, R, L, D, A, dhcb);
+        SAT_TRY(launch_ok("attention_bwd_dalpha"));
+    }
+    ProfScope prof("attention_bwd_tanh", 4.0 * N * L * A, 4.0 * (3.0 * B * L * A + N * (2.0 * A + 2.0 * L)), st);
     hipLaunchKernelGGL(attention_bwd_tanh_kernel<RN>, dim3(B, cdiv(A, ATTB_KCH)), dim3(1024), lds_t, st, U, hc, hc_ld, wf, lengths, step, alphas, T1, da, dhc, dhc_ld, dU,
                        dwf_part, R, L, A, dhcb);
     return launch_ok("attention_bwd_tanh");

@@ -70,6 +70,7 @@ class GradSync:
         self.buckets = []
         self._sig = None
         self._early = set()              # diagnostics: indices of the buckets launched from inside the encoder backward this step
+        self.last_early = []
         self._build()
 
     # ------------------------------------------------------------------ construction
@@ -262,6 +263,7 @@ class GradSync:
                 for p in b.params:
                     if p.grad is None:                           # unused this step: the mean of the ranks' zeros / gradients
                         p.grad = b.view(p)
+        self.last_early = sorted(self._early)          # diagnostics (bench.py): which buckets started from inside the encoder backward this step
         self._early = set()
 
 

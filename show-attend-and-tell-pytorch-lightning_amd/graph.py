@@ -23,7 +23,6 @@ autograd hooks), gradient accumulation, dropout (its seed is a launch argument),
         out = step(batch)                              # = zero_grad; training_step; backward; [sync.finish]; optimizer.step
 """
 import collections
-import warnings
 
 import numpy as np
 import torch
@@ -31,6 +30,19 @@ import torch
 from . import _lib as L
 from . import decoder as Dk
 from . import encoder as E
+
+
+class _Ctx:
+    """what the ``torch.autograd.Function`` bodies of this package use of their ``ctx``, without autograd: the captured step calls the static
+    ``forward`` / ``backward`` methods of EncoderFn / DecoderTrainFn / the loss functions directly, in the order autograd would.  No engine, no
+    AccumulateGrad nodes: those remember the stream they were created on and live as long as ANY tensor of an earlier step's autograd graph
+    does (a kept loss); one of them inside a capture pulls the default stream in and hipStreamEndCapture crashes."""
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tuple(tensors)
+
+    def mark_non_differentiable(self, *tensors):
+        pass
 
 
 class _Entry:
@@ -107,6 +119,63 @@ class GraphedTrainStep:
             t.record_stream(side)
         return out
 
+    # ------------------------------------------------------------------ the device half of one step without autograd
+    def _forward_backward(self, batch, epsilon, teacher):
+        """forward + losses + backward of ``SAT._step_losses`` / ``loss.backward()`` as plain calls (see _Ctx); leaves every gradient in ``p.grad``
+        (written, not accumulated: the caller has set the gradients to None) and returns (loss, accuracy)"""
+        model = self.model
+        img, caps, lengths = batch
+        hp = model.hp
+        enc = model.encoder
+        with torch.no_grad():
+            enc_params = list(enc.parameters())
+            ectx = _Ctx()
+            try:
+                ann = E.EncoderFn._forward(ectx, img, enc, *enc_params)                 # (B, D, h, w) view over NHWC memory
+            finally:
+                E._defer[0] = False
+            Bn, D, h, w = ann.shape
+            ann_bld = ann.permute(0, 2, 3, 1).reshape(Bn, h * w, D)
+            _, R, T = caps.shape
+            plan = Dk.PackPlan.cached(lengths.reshape(-1), T, img.device)
+            caps2 = caps.reshape(Bn * R, T)
+            caps_i32 = caps2.to(dtype=torch.int32).contiguous()
+            dec_params = model.param_list()
+            dctx = _Ctx()
+            logits, alphas = Dk.DecoderTrainFn.forward(dctx, ann_bld, caps_i32, plan, teacher, bool(hp.deep_output), model.pad_idx, R,
+                                                       int(model.sat_precision == "bf16"), getattr(hp, "embed_norm", None) or 0.0,
+                                                       model._dropout_args(None), *dec_params)
+            targets = plan.pack(caps2[:, 1:].unsqueeze(-1)).squeeze(-1)
+            cctx, sctx = _Ctx(), _Ctx()
+            ce, acc = Dk.LabelSmoothingFn.forward(cctx, logits, targets.to(torch.int32), model.criterion.smoothing)
+            model.criterion.last_accuracy = acc
+            ds = Dk.DoublyStochasticFn.forward(sctx, alphas, float(hp.att_gamma))
+            loss = ce + ds
+            one = torch.ones((), dtype=torch.float32, device=img.device)
+            dlogits = Dk.LabelSmoothingFn.backward(cctx, one, None)[0]
+            dalphas = Dk.DoublyStochasticFn.backward(sctx, one)[0]
+            douts = Dk.DecoderTrainFn.backward(dctx, dlogits, dalphas)
+            dann = douts[0]
+            grads = {}
+
+            def give(p, g):
+                if p is None or g is None or not p.requires_grad:
+                    return
+                if id(p) in grads:                               # a tied weight reaches the decoder twice (embedding and output layer)
+                    grads[id(p)][1].add_(g)
+                else:
+                    grads[id(p)] = (p, g)
+
+            for p, g in zip(dec_params, douts[10:]):
+                give(p, g)
+            if any(p.requires_grad for p in enc_params):
+                eouts = E.EncoderFn.backward(ectx, dann.reshape(Bn, h, w, D).permute(0, 3, 1, 2))
+                for p, g in zip(enc_params, eouts[2:]):
+                    give(p, g)
+            for p, g in grads.values():
+                p.grad = g
+        return loss, acc
+
     # ------------------------------------------------------------------ capture
     def _capture(self, key, batch, epsilon, teacher):
         img, caps, lengths = batch
@@ -119,13 +188,10 @@ class GraphedTrainStep:
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, pool=self._pool, stream=self._stream):
-            loss = self.model._step_losses((ent.img, ent.caps, ent.lengths), epsilon, teacher=teacher)
-            acc = self.model.criterion.last_accuracy
-            loss.backward()
+            out_loss, acc = self._forward_backward((ent.img, ent.caps, ent.lengths), epsilon, teacher)      # no autograd inside a capture (see _Ctx)
             if self.sync is not None:
                 self.sync.finish()                        # one process: gradients produced elsewhere move into their bucket slices
             self.opt.step_device()
-            out_loss = loss.detach()
         ent.graph = g
         ent.out = {"loss": out_loss, "accuracy": acc, "epsilon_tf": float(epsilon)}
         ent.grads = [(p, p.grad) for p in self._params if p.grad is not None]
@@ -158,21 +224,12 @@ class GraphedTrainStep:
         stale = self._stale_copies()
         if stale:
             self._graphs.clear()                          # filter copies are about to be remade: every graph points at the old ones
-        if self._graphs.get(key, "new") in ("new", "pinned"):
-            # Warm every cache with an eager step ON THE CAPTURE STREAM; the next step with this key captures.  autograd's AccumulateGrad
-            # nodes remember the stream they were created on and live as long as anything references the autograd graph of an earlier
-            # step (a kept loss, a hook).  A node of the default stream inside a capture pulls that stream into it - hipStreamEndCapture
-            # then crashes.  torch warns about the mismatch in an eager backward too: if it does here, the key stays eager for now.
-            with warnings.catch_warnings(record=True) as seen:
-                warnings.simplefilter("always")
-                out = self._eager_on_capture_stream(batch, epsilon, gstep, teacher)
-            pinned = any("AccumulateGrad" in str(w.message) for w in seen)
-            for w in seen:
-                if "AccumulateGrad" not in str(w.message):
-                    warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
-            self._graphs[key] = "pinned" if pinned else None
-            self.stats["eager: autograd graph of an earlier step still referenced" if pinned else "eager: first step of a shape / plan"] += 1
-            return out
+        if key not in self._graphs:
+            # warm every cache (plans, split-K scratch, kernel attributes, optimizer tables) with an eager step ON THE CAPTURE STREAM (the
+            # per-stream scratch buffers are then the ones the capture uses); the next step with this key captures
+            self._graphs[key] = None
+            self.stats["eager: first step of a shape / plan"] += 1
+            return self._eager_on_capture_stream(batch, epsilon, gstep, teacher)
         ent = self._graphs[key]
         self._graphs.move_to_end(key)
         if ent is None:
