@@ -303,11 +303,11 @@ def test_batched_beam_search_at_c5_decoder_shapes():
     assert b[0] == c[0] and b[1] == c[1] and all(torch.equal(u, v) for u, v in zip(flat(b[2]), flat(c[2])))
 
 
-@pytest.mark.parametrize("images,precision", [(12, "fp32"), (64, "fp32")])
-def test_c5_beam_search_against_the_cpu_oracle(images, precision):
-    """BASELINE configs[4] at its real decoder dimensions (D = 512, n = 512, A = 128, m = 256, V = 6400, L = 49, beam 5; 64 images):
-    the batched on-device search against the CPU oracle's per-image beam search (oracle.sat_oracle.beam_search = model.py:237-472
-    restated; pinned by fixture G7): captions token for token, list order included; scores, perplexities and attention maps 1e-4."""
+@pytest.mark.parametrize("images,beamk", [(12, 5), (64, 5), (64, 1)])
+def test_c5_beam_search_against_the_cpu_oracle(images, beamk):
+    """BASELINE configs[4] ("greedy-vs-beam") at its real decoder dimensions (D = 512, n = 512, A = 128, m = 256, V = 6400, L = 49; 64 images), beam 5
+    AND greedy (beam 1): the batched on-device search against the CPU oracle's per-image beam search (oracle.sat_oracle.beam_search =
+    model.py:237-472 restated; pinned by fixture G7): captions token for token, list order included; scores, perplexities and attention maps 1e-4."""
     import os
     import sat_amd  # noqa: F401
     from sat_amd import model as M
@@ -319,7 +319,7 @@ def test_c5_beam_search_against_the_cpu_oracle(images, precision):
     sd = {k: v.detach().cpu().clone() for k, v in dec.state_dict().items()}
     ann_bld = torch.from_numpy(prng.uniform((images, 49, 512), 95, 0.0, 2.0))
     ann_img = ann_bld.reshape(images, 7, 7, 512).permute(0, 3, 1, 2).contiguous()
-    kw = dict(beamk=5, max_gen_length=14, temperature=1.0, rescore_method="LN", return_all=True)
+    kw = dict(beamk=beamk, max_gen_length=14, temperature=1.0, rescore_method="LN", return_all=True)
     with torch.no_grad():
         want = O.beam_search(sd, hp, ann_img, **kw)
     got = dec.beam_decode_batched(ann_bld.cuda(), (7, 7), **kw)
@@ -331,3 +331,40 @@ def test_c5_beam_search_against_the_cpu_oracle(images, precision):
         assert abs(u - v) <= 1e-4 * max(1.0, abs(v)), (u, v)
     for u, v in zip(flat(got[2]), flat(want[2])):
         assert u.shape == v.shape and float((u - v).abs().max()) <= 1e-4
+
+
+@pytest.mark.parametrize("beamk", [5, 1])
+def test_caption_end_to_end_resnet50_at_256px_against_the_cpu_oracle(beamk):
+    """``caption()`` of BASELINE configs[4] end to end - resnet50 trunk at 256 px in eval mode, 1x1 projection, encoder_size 7, then the batched
+    search - on 4 images in fp32 parity mode against the CPU oracle (its encoder + ``beam_search``): token ids exact, scores / perplexities /
+    attention maps 1e-4.  (Untrained BatchNorm running statistics let activations grow block by block: the residual branches are damped, as in
+    the train-step tests, so that the comparison is about the arithmetic and not about 1e4-sized annotations.)"""
+    import sat_amd  # noqa: F401
+    from sat_amd import model as M
+    from oracle import prng, sat_oracle as O
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    over = dict(encoder_arch="resnet50", encoder_dim=512, input_size=256, encoder_size=7, vocab_size=6400, embed_dim=256, attention_dim=128,
+                decoder_dim=512, deep_output=True)
+    torch.manual_seed(21)
+    model = M.SAT(**vars(O.default_hparams(**over)))
+    with torch.no_grad():
+        for blk in [b for li in (5, 6, 7, 8) for b in model.encoder[li]]:
+            blk.bn3.weight.fill_(0.25)
+    model = model.cuda()
+    model.set_precision("fp32")
+    oracle = O.OracleSAT(O.default_hparams(**over), {k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+    img = torch.from_numpy(prng.uniform((4, 3, 256, 256), 77, 0.0, 1.0))
+    kw = dict(beamk=beamk, max_gen_length=12, rescore_method="LN")
+    caps, scores, alphas, ppl = model.caption(img.cuda(), **kw)
+    oracle.encoder.eval()
+    with torch.no_grad():
+        ann = oracle.encoder(img.clone())
+        ocaps, oscores, oalphas, oppl = O.beam_search(oracle.sd, oracle.hp, ann, **kw)
+    assert ann.shape == (4, 512, 7, 7)
+    assert caps == ocaps
+    for a, b in zip(scores, oscores):
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (a, b)
+    for a, b in zip(ppl, oppl):
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (a, b)
+    for a, b in zip(alphas, oalphas):
+        assert a.shape == b.shape and float((a - b).abs().max()) <= 1e-4
