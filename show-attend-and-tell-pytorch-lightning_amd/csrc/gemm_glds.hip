@@ -66,6 +66,12 @@ int launch_gemm_glds(const BArgs& k0, int amode, int bmode, int c_bf16, int BMt,
         const int deep8 = glds_stages8();
         if (ktiles > 1) k.nstage = deep8 ? (deep8 < maxs ? deep8 : maxs) : (ktiles >= 3 ? maxs : 2);
     }
+    {
+        static const int order = getenv("SAT_TILE_ORDER") ? atoi(getenv("SAT_TILE_ORDER")) : -1;      // dev: -1 automatic, 0 / 1 forced
+        const int tbm = (tile == TILE_64) ? 64 : 128, tbn = (tile == TILE_128) ? 128 : 64;
+        const int mt = cdiv(k.M, tbm), nt = cdiv(k.N, tbn);
+        k.y_fastest = order >= 0 ? order : (amode == A_ROW && bmode != B_CONV_WGRAD && mt <= 16 && nt >= 2 * mt);
+    }
     const ConvGeom& g = k.g;
     if (g.sw && g.sw != g.stride) return -1;          // anisotropic stride: register-staged kernel only
     if (k.K % 64 || k.kchunk % 64 || k.a_rows) return -1;

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_glds_kernel(BArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bx, by, bz;
-    xcd_tile(bx, by, bz);
+    xcd_tile(bx, by, bz, a.y_fastest);
     const int bm = by * BM, bn = bx * BN;
     const int kbeg = bz * a.kchunk;
     const int kend = min(a.K, kbeg + a.kchunk);
