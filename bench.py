@@ -39,7 +39,7 @@ MIN_WARM_S = 1.5
 # in-library profile name -> kernel family of profiles/*_pmc_hbm.json (tools/pmc_aggregate.py)
 PMC_FAMILY = {"bn_apply_bwd": "bn_bwd_apply_kernel", "bn_apply_fwd": "bn_apply_kernel", "bn_stats_bwd": "bn_colstats_kernel<1>",
               "bn_stats_fwd": "bn_colstats_kernel<0>"}
-PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r02_bf16_bench_c2_pmc_hbm.json", "r01_bf16_bench_c2_pmc_hbm.json")]
+PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r03_bf16_bench_c2_pmc_hbm.json", "r02_bf16_bench_c2_pmc_hbm.json", "r01_bf16_bench_c2_pmc_hbm.json")]
 
 
 def hparams(cfg, R=5):

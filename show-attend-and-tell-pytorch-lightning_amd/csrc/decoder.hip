@@ -24,7 +24,7 @@ struct Ws {
     int *emb_count, *emb_offset, *emb_cursor, *emb_list;         // embedding gradient: per-row token segments
     float *SC, *DA;                                              // attention: raw scores / score gradients of one step (N, L)
     // backward scratch
-    float *dA, *dHout, *dZout, *DZ, *DHC, *dXZ, *dHc, *dCc, *dU, *dwf_part, *dY, *colpart, *dinit_img, *df, *dmean, *slab;
+    float *dA, *dHout, *dZout, *DZ, *DHC, *dXZ, *dHc, *dCc, *dU, *dwf_part, *dY, *colpart, *colpart_side, *dinit_img, *df, *dmean, *slab, *slab_side;
     char *zero_begin, *zero_end;                                 // [dHout .. dwf_part]: what decoder_bwd zeroes in one memset
     long slab_elems;
 };
@@ -97,6 +97,9 @@ Ws layout(const sat_decoder_dims& d, char* base) {
     w.dmean = (float*)take((size_t)d.B * d.D);
     w.slab_elems = 8L << 20;   // 32 MiB of split-K partials
     w.slab = (float*)take((size_t)w.slab_elems);
+    // a second set for the output layer's parameter gradients, which run on a side stream beside the back-propagation through time
+    w.slab_side = (float*)take((size_t)w.slab_elems);
+    w.colpart_side = (float*)take((size_t)cdiv(maxrows, 256) * maxcols);
     w.total = off;
     return w;
 }
@@ -274,6 +277,29 @@ static int attention_bwd_split(int RN, hipStream_t st, const float* ann, const f
                                             : attention_bwd_split_t<RNV, float>(st, ann, U, hc, hc_ld, wf, lengths, step, alphas, dalphas, T1, Zs, dZ_out, dXZ, DZ, dhc, dhc_ld, dU, dwf_part, da, B, R, L, D, A, dhcb);
     switch (RN) { SAT_ATTB(1) SAT_ATTB(2) SAT_ATTB(3) SAT_ATTB(4) SAT_ATTB(5) SAT_ATTB(6) SAT_ATTB(7) default: SAT_ATTB(8) }
 #undef SAT_ATTB
+}
+
+
+// ------------------------------------------------------------------ side stream of the backward pass
+// The parameter gradients of the output layer (dW_out = dlogits^T u, its bias, dW_hidden, dW_context: ~250 us of throughput-bound launches at C2)
+// feed nothing in the decoder's backward chain.  The back-propagation through time is a chain of dependent ~6 us launches that leaves the
+// chip mostly idle, so those launches run beside it on a stream owned by the calling host thread (created on first use); the caller's
+// stream forks into it after the last launch they depend on and joins it right after the time loop - from outside the call is still work on
+// ONE stream.  Their split-K scratch and column-sum scratch are separate from the main stream's.
+struct SideStream { hipStream_t st = nullptr; hipEvent_t fork = nullptr, join = nullptr; int device = -1; };
+static bool bwd_side_enabled() { static const bool off = getenv("SAT_DEC_SIDE") && !atoi(getenv("SAT_DEC_SIDE")); return !off; }
+static int side_stream(SideStream*& out) {
+    static thread_local SideStream ss;
+    int dev = 0;
+    SAT_CHECK_HIP(hipGetDevice(&dev));
+    if (ss.device != dev) {
+        SAT_CHECK_HIP(hipStreamCreateWithFlags(&ss.st, hipStreamNonBlocking));
+        SAT_CHECK_HIP(hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming));
+        SAT_CHECK_HIP(hipEventCreateWithFlags(&ss.join, hipEventDisableTiming));
+        ss.device = dev;
+    }
+    out = &ss;
+    return SAT_OK;
 }
 
 // ------------------------------------------------------------------ output stage for packed rows [p0, p1)
@@ -462,7 +488,14 @@ int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
     SAT_TRY(dev_fill_bytes(st, w.zero_begin, 0, (size_t)(w.zero_end - w.zero_begin)));       // dHout, dZout, dHc, dCc, dU, dwf_part
     if (NL > 1 && KR < T1 * N) SAT_TRY(dev_fill_bytes(st, w.DGU, 0, (size_t)(NL - 1) * T1 * N * 4 * n * 4));
 
-    // ---- output layer, all packed rows at once (DeepOutput backward)
+    // ---- output layer, all packed rows at once (DeepOutput backward).  What the time loop needs (dA -> dHout, dZout) first, on the caller's
+    // stream; the parameter gradients of the layer on the side stream (see SideStream), joined after the loop.
+    SideStream* side = nullptr;
+    const bool use_side = bwd_side_enabled() && ts > 1;
+    hipStream_t sw = st;                  // stream of the output layer's parameter gradients
+    float* slab_w = slab;
+    Ws wside = w;
+    if (use_side) { SAT_TRY(side_stream(side)); sw = side->st; slab_w = w.slab_side; wside.colpart = w.colpart_side; }
     if (P > 0) {
         SAT_TRY(gemm(st, A_ROW, B_KMAJOR, dlogits, V, p.out_w, m, w.dA, m, P, m, V, 0, d.deep_output ? EPI_MUL_DTANH : EPI_NONE, nullptr,
                      nullptr, nullptr, w.Uact, m, 0, 0, slab, se));           // few output tiles, long reduction over the vocabulary: split-K
@@ -471,24 +504,31 @@ int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
                                (unsigned long long)d.dropout_seed, 2u, 0L);
             SAT_TRY(launch_ok("output dropout bwd"));
         }
-        SAT_TRY(gemm(st, A_KMAJOR, B_KMAJOR, dlogits, V, d.dropout > 0.f ? w.Udrop : w.Uact, m, g.out_w, m, V, m, P, 0, EPI_NONE, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, slab, se));
-        if (g.out_b) SAT_TRY(colsum(st, w, dlogits, V, P, V, g.out_b));
         SAT_TRY(gemm(st, A_ROW, B_KMAJOR, w.dA, m, p.out_hidden, n, w.dHout, n, P, n, m, 0, EPI_NONE, nullptr, nullptr, b.src_row));
         if (d.deep_output)
             SAT_TRY(gemm(st, A_ROW, B_KMAJOR, w.dA, m, p.out_context, D, w.dZout, D, P, D, m, 0, EPI_NONE, nullptr, nullptr, b.src_row));
-    } else {
-        SAT_TRY(dev_fill_bytes(st, g.out_w, 0, (size_t)V * m * 4));
-        if (g.out_b) SAT_TRY(dev_fill_bytes(st, g.out_b, 0, (size_t)V * 4));
     }
     // dA in time-major padded rows (zeros for finished captions): operand of the weight-grad GEMMs and of dY
     hipLaunchKernelGGL(scatter_rows_kernel, dim3(T1 * N), dim3(64), 0, st, w.dA, b.prow, w.dY, T1 * N, m);
     SAT_TRY(launch_ok("scatter dA"));
+    if (use_side) {
+        SAT_CHECK_HIP(hipEventRecord(side->fork, st));
+        SAT_CHECK_HIP(hipStreamWaitEvent(sw, side->fork, 0));
+    }
+    if (P > 0) {
+        SAT_TRY(gemm(sw, A_KMAJOR, B_KMAJOR, dlogits, V, d.dropout > 0.f ? w.Udrop : w.Uact, m, g.out_w, m, V, m, P, 0, EPI_NONE, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, slab_w, se));
+        if (g.out_b) SAT_TRY(colsum(sw, wside, dlogits, V, P, V, g.out_b));
+    } else {
+        SAT_TRY(dev_fill_bytes(sw, g.out_w, 0, (size_t)V * m * 4));
+        if (g.out_b) SAT_TRY(dev_fill_bytes(sw, g.out_b, 0, (size_t)V * 4));
+    }
     const float* H1 = Hs(1, top);
-    SAT_TRY(gemm(st, A_KMAJOR, B_KMAJOR, w.dY, m, H1, n, g.out_hidden, n, m, n, KR, 0, EPI_NONE, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, slab, se));
+    SAT_TRY(gemm(sw, A_KMAJOR, B_KMAJOR, w.dY, m, H1, n, g.out_hidden, n, m, n, KR, 0, EPI_NONE, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, slab_w, se));
     if (d.deep_output)
-        SAT_TRY(gemm(st, A_KMAJOR, B_KMAJOR, w.dY, m, w.Z, D, g.out_context, D, m, D, KR, 0, EPI_NONE, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, slab, se));
+        SAT_TRY(gemm(sw, A_KMAJOR, B_KMAJOR, w.dY, m, w.Z, D, g.out_context, D, m, D, KR, 0, EPI_NONE, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, slab_w, se));
     else
-        SAT_TRY(dev_fill_bytes(st, w.dY, 0, (size_t)T1 * N * m * 4));     // shallow output does not see the embedding
+        SAT_TRY(dev_fill_bytes(sw, w.dY, 0, (size_t)T1 * N * m * 4));     // shallow output does not see the embedding
+    if (use_side) SAT_CHECK_HIP(hipEventRecord(side->join, sw));
 
     // ---- back through time
     const size_t lds_b = att_bwd_lds(d.L, A, D);
@@ -543,6 +583,7 @@ int decoder_bwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
         }
     }
     // now dHc = dL/dh0 and dCc = dL/dc0
+    if (use_side) SAT_CHECK_HIP(hipStreamWaitEvent(st, side->join, 0));          // the output layer's parameter gradients are done (and dY is final)
 
     // ---- weight gradients, batched over every executed step (reduction length KR = ts*N)
     auto wgrad = [&](const float* dy, long ldy, const float* x, long ldx, float* out, long ldo, int M, int Nn) {
