@@ -78,7 +78,7 @@ def algorithmic_work(cfg, R=5):
     """algorithmic FLOPs (2 x MAC; training = 3 x forward for contraction work) of one caption.
     Encoder: every convolution of the torchvision ResNet at 256 px + the 1x1 projection."""
     arch, es, D, V, T, _ = CONFIGS[cfg]
-    kind, depths, wpg = _RESNETS[arch]
+    kind, depths, wpg = _RESNETS[arch][:3]
     macs = 128 * 128 * 64 * 3 * 49                       # conv1: 7x7, stride 2 on 256 px
     hw, cin = 64, 64
     for si, (planes, nblk) in enumerate(zip((64, 128, 256, 512), depths)):

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SAT_HIP_ABI_VERSION 19
+#define SAT_HIP_ABI_VERSION 20
 
 int sat_abi_version(void);
 /* dev aid: after every kernel launch wait for the device and print the launch's name to stderr (a device fault then points at the
@@ -358,6 +358,11 @@ int sat_image_normalize_nhwc4(const float* img_nchw, float* out_nhwc4, int32_t N
  * (tap 2s in slots 0-2, tap 2s + 1 in slots 4-6, the eighth tap and slots 3 / 7 zero); grad_unpairs: its fp32 gradient back. */
 int sat_image_normalize_nhwc4_padded_bf16(const float* img_nchw, void* out, int32_t N, int32_t H, int32_t W, const float* mean3_host, const float* std3_host, void* stream);
 int sat_stem_filter_pairs(const float* w3, void* w_pairs_bf16, int32_t K, void* stream);
+/* resnext archs (model.py:28 keeps torchvision's resnext50_32x4d / resnext101_32x8d in the ResNet branch): their 3x3 convolutions have `groups`
+ * groups.  The grouped filter (K, R, S, C / groups; fp32 or bf16) is expanded into the dense block-diagonal filter (K, R, S, C) that
+ * sat_conv2d_* read, and the gradient of the grouped filter is gathered from the diagonal blocks of the dense filter's fp32 gradient.       */
+int sat_grouped_filter_expand(const void* w_grouped, void* w_dense, int32_t K, int32_t C, int32_t RS, int32_t groups, int32_t bf16, void* stream);
+int sat_grouped_filter_grad_extract(const float* dw_dense, float* dw_grouped, int32_t K, int32_t C, int32_t RS, int32_t groups, void* stream);
 int sat_stem_filter_grad_unpairs(const float* dw_pairs, float* dw3, int32_t K, void* stream);
 /* (pixels, 3) <-> (pixels, 4) zero padded; used for the stem filters */
 int sat_pad_channels_3to4(const float* src, float* dst, int64_t pixels, int32_t inverse, void* stream);

@@ -71,7 +71,7 @@ rb, rf, rg = _RoundBoth.apply, _RoundFwd.apply, _RoundBwd.apply
 
 
 def _conv(x, conv):
-    return rb(F.conv2d(x, rf(conv.weight), None, conv.stride, conv.padding))
+    return rb(F.conv2d(x, rf(conv.weight), None, conv.stride, conv.padding, 1, conv.groups))
 
 
 def _bn(x, bn, residual=None, relu=True):

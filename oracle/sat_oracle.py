@@ -32,7 +32,7 @@ from torch import nn
 #     so real weights could be loaded from a local file.
 # --------------------------------------------------------------------------
 
-#: arch -> (block kind, blocks per stage, width per group)
+#: arch -> (block kind, blocks per stage, width per group[, groups of the 3x3 convolution: the resnext archs, model.py:28])
 RESNET_TABLE = {
     "resnet18": ("basic", (2, 2, 2, 2), 64),
     "resnet34": ("basic", (3, 4, 6, 3), 64),
@@ -41,6 +41,8 @@ RESNET_TABLE = {
     "resnet152": ("bottleneck", (3, 8, 36, 3), 64),
     "wide_resnet50_2": ("bottleneck", (3, 4, 6, 3), 128),
     "wide_resnet101_2": ("bottleneck", (3, 4, 23, 3), 128),
+    "resnext50_32x4d": ("bottleneck", (3, 4, 6, 3), 4, 32),
+    "resnext101_32x8d": ("bottleneck", (3, 4, 23, 3), 8, 32),
 }
 
 
@@ -48,7 +50,7 @@ class _Residual(nn.Module):
     """One residual unit.  ``kind`` selects 3x3-3x3 or 1x1-3x3-1x1 (stride on
     the 3x3, i.e. the "v1.5" layout torchvision uses)."""
 
-    def __init__(self, kind, cin, planes, stride, width_per_group):
+    def __init__(self, kind, cin, planes, stride, width_per_group, groups=1):
         super().__init__()
         self.kind = kind
         if kind == "basic":
@@ -59,10 +61,10 @@ class _Residual(nn.Module):
             self.bn2 = nn.BatchNorm2d(planes)
         else:
             cout = planes * 4
-            mid = int(planes * (width_per_group / 64.0))
+            mid = int(planes * (width_per_group / 64.0)) * groups          # torchvision Bottleneck: width = int(planes * base_width / 64) * groups
             self.conv1 = nn.Conv2d(cin, mid, 1, 1, 0, bias=False)
             self.bn1 = nn.BatchNorm2d(mid)
-            self.conv2 = nn.Conv2d(mid, mid, 3, stride, 1, bias=False)
+            self.conv2 = nn.Conv2d(mid, mid, 3, stride, 1, groups=groups, bias=False)
             self.bn2 = nn.BatchNorm2d(mid)
             self.conv3 = nn.Conv2d(mid, cout, 1, 1, 0, bias=False)
             self.bn3 = nn.BatchNorm2d(cout)
@@ -91,7 +93,8 @@ class ResNetOracle(nn.Module):
 
     def __init__(self, arch, num_classes=1000):
         super().__init__()
-        kind, depths, wpg = RESNET_TABLE[arch]
+        kind, depths, wpg = RESNET_TABLE[arch][:3]
+        groups = RESNET_TABLE[arch][3] if len(RESNET_TABLE[arch]) > 3 else 1
         self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
         self.relu = nn.ReLU(inplace=True)
@@ -100,7 +103,7 @@ class ResNetOracle(nn.Module):
         for si, (planes, nblk) in enumerate(zip((64, 128, 256, 512), depths)):
             blocks = []
             for bi in range(nblk):
-                blk = _Residual(kind, cin, planes, (2 if si > 0 and bi == 0 else 1), wpg)
+                blk = _Residual(kind, cin, planes, (2 if si > 0 and bi == 0 else 1), wpg, groups)
                 cin = blk.cout
                 blocks.append(blk)
             setattr(self, "layer%d" % (si + 1), nn.Sequential(*blocks))

@@ -158,6 +158,8 @@ SYMBOLS.update({
     "sat_image_normalize_nhwc8_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp]),
     "sat_image_normalize_nhwc4_padded_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp]),
     "sat_stem_filter_pairs": (C.c_int, [_vp, _vp, _i32, _vp]),
+    "sat_grouped_filter_expand": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "sat_grouped_filter_grad_extract": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "sat_stem_filter_grad_unpairs": (C.c_int, [_vp, _vp, _i32, _vp]),
     "sat_stem_filter_pad": (C.c_int, [_vp, _vp, _i64, _vp]),
     "sat_stem_filter_grad_unpad": (C.c_int, [_vp, _vp, _i64, _vp]),
@@ -249,8 +251,8 @@ def lib():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(handle, name)          # AttributeError if the export is missing
             fn.restype, fn.argtypes = res, args
-        if handle.sat_abi_version() != 19:
-            raise SatHipError("libsat_hip.so ABI version %d != 19 (rebuild: make -C csrc)" % handle.sat_abi_version())
+        if handle.sat_abi_version() != 20:
+            raise SatHipError("libsat_hip.so ABI version %d != 20 (rebuild: make -C csrc)" % handle.sat_abi_version())
         _lib = handle
     return _lib
 

@@ -923,6 +923,29 @@ __global__ void bilinear_bwd_kernel(const float* __restrict__ dy, float* __restr
     dx[e] = s;
 }
 
+// ---- grouped 3x3 convolutions (resnext: model.py:28 builds torchvision's resnext50_32x4d / resnext101_32x8d in the ResNet branch)
+// The grouped filter (K, R, S, C / groups) becomes the dense block-diagonal filter (K, R, S, C) the implicit-GEMM kernels read; the gradient of the
+// grouped filter is the diagonal blocks of the dense filter's gradient.  Pure data movement.
+template <typename T>
+__global__ void grouped_filter_expand_kernel(const T* __restrict__ wg, T* __restrict__ wd, int K, int C, int RS, int groups) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)K * RS * C;
+    if (e >= total) return;
+    const int c = (int)(e % C); const long t = e / C; const int rs = (int)(t % RS), k = (int)(t / RS);
+    const int cg = C / groups, kg = K / groups;
+    const int g = k / kg;
+    const int cl = c - g * cg;
+    wd[e] = (cl >= 0 && cl < cg) ? wg[((long)k * RS + rs) * cg + cl] : (T)0.f;
+}
+__global__ void grouped_filter_grad_extract_kernel(const float* __restrict__ dwd, float* __restrict__ dwg, int K, int C, int RS, int groups) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int cg = C / groups, kg = K / groups;
+    const long total = (long)K * RS * cg;
+    if (e >= total) return;
+    const int cl = (int)(e % cg); const long t = e / cg; const int rs = (int)(t % RS), k = (int)(t / RS);
+    dwg[e] = dwd[((long)k * RS + rs) * C + (k / kg) * cg + cl];
+}
+
 }  // namespace sat
 
 using namespace sat;
@@ -1426,6 +1449,19 @@ int sat_image_normalize_nhwc4_padded_bf16(const float* img_nchw, void* out, int3
     hipLaunchKernelGGL(normalize_nhwc4_padded_bf16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, img_nchw, (bf*)out, H, W, total,
                        mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2]);
     return launch_ok("normalize_nhwc4_padded_bf16");
+}
+int sat_grouped_filter_expand(const void* w_grouped, void* w_dense, int32_t K, int32_t C, int32_t RS, int32_t groups, int32_t bf16, void* stream) {
+    if (!w_grouped || !w_dense || K <= 0 || C <= 0 || RS <= 0 || groups <= 0 || K % groups || C % groups) return fail(SAT_EINVAL, "grouped_filter_expand: bad argument (K=%d C=%d groups=%d)", K, C, groups);
+    const long n = (long)K * RS * C;
+    if (bf16) hipLaunchKernelGGL(grouped_filter_expand_kernel<bf>, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf*)w_grouped, (bf*)w_dense, K, C, RS, groups);
+    else hipLaunchKernelGGL(grouped_filter_expand_kernel<float>, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)w_grouped, (float*)w_dense, K, C, RS, groups);
+    return launch_ok("grouped_filter_expand");
+}
+int sat_grouped_filter_grad_extract(const float* dw_dense, float* dw_grouped, int32_t K, int32_t C, int32_t RS, int32_t groups, void* stream) {
+    if (!dw_dense || !dw_grouped || K <= 0 || C <= 0 || RS <= 0 || groups <= 0 || K % groups || C % groups) return fail(SAT_EINVAL, "grouped_filter_grad_extract: bad argument");
+    const long n = (long)K * RS * (C / groups);
+    hipLaunchKernelGGL(grouped_filter_grad_extract_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dw_dense, dw_grouped, K, C, RS, groups);
+    return launch_ok("grouped_filter_grad_extract");
 }
 int sat_stem_filter_pairs(const float* w3, void* w_pairs_bf16, int32_t K, void* stream) {
     if (!w3 || !w_pairs_bf16 || K <= 0) return fail(SAT_EINVAL, "stem_filter_pairs: bad argument");

@@ -16,12 +16,14 @@ from torch import nn
 
 from . import _lib as L
 
-#: arch -> (block kind, blocks per stage, width per group); torchvision's table
+#: arch -> (block kind, blocks per stage, width per group[, groups of the 3x3 convolution]); torchvision's table.  The resnext archs belong to the
+#: same branch of the reference's get_encoder (model.py:28: "resnet" in arch or "resnext" in arch)
 RESNETS = {
     "resnet18": ("basic", (2, 2, 2, 2), 64), "resnet34": ("basic", (3, 4, 6, 3), 64),
     "resnet50": ("bottleneck", (3, 4, 6, 3), 64), "resnet101": ("bottleneck", (3, 4, 23, 3), 64),
     "resnet152": ("bottleneck", (3, 8, 36, 3), 64),
     "wide_resnet50_2": ("bottleneck", (3, 4, 6, 3), 128), "wide_resnet101_2": ("bottleneck", (3, 4, 23, 3), 128),
+    "resnext50_32x4d": ("bottleneck", (3, 4, 6, 3), 4, 32), "resnext101_32x8d": ("bottleneck", (3, 4, 23, 3), 8, 32),
 }
 
 
@@ -37,17 +39,17 @@ class Normalize(nn.Module):
 class Block(nn.Module):
     """Parameter holder of one torchvision BasicBlock / Bottleneck (stride on the 3x3)."""
 
-    def __init__(self, kind, cin, planes, stride, wpg):
+    def __init__(self, kind, cin, planes, stride, wpg, groups=1):
         super().__init__()
-        self.kind, self.stride = kind, stride
+        self.kind, self.stride, self.groups = kind, stride, groups
         if kind == "basic":
             self.cout = planes
             self.conv1 = nn.Conv2d(cin, planes, 3, stride, 1, bias=False); self.bn1 = nn.BatchNorm2d(planes)
             self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False); self.bn2 = nn.BatchNorm2d(planes)
         else:
-            mid = int(planes * (wpg / 64.0)); self.cout = planes * 4
+            mid = int(planes * (wpg / 64.0)) * groups; self.cout = planes * 4          # torchvision Bottleneck: width = int(planes * base_width / 64) * groups
             self.conv1 = nn.Conv2d(cin, mid, 1, 1, 0, bias=False); self.bn1 = nn.BatchNorm2d(mid)
-            self.conv2 = nn.Conv2d(mid, mid, 3, stride, 1, bias=False); self.bn2 = nn.BatchNorm2d(mid)
+            self.conv2 = nn.Conv2d(mid, mid, 3, stride, 1, groups=groups, bias=False); self.bn2 = nn.BatchNorm2d(mid)
             self.conv3 = nn.Conv2d(mid, self.cout, 1, 1, 0, bias=False); self.bn3 = nn.BatchNorm2d(self.cout)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = None
@@ -124,6 +126,30 @@ def cast_bf16(t):
         out = out.contiguous(memory_format=torch.channels_last)
     L.check(L.lib().sat_cast_f32_to_bf16(L.ptr(t), L.ptr(out), t.numel(), L.stream_ptr()), "sat_cast_f32_to_bf16")
     return out
+
+
+def grouped_dense(w, groups):
+    """Grouped filter (K, C/groups, R, S) of a resnext 3x3 convolution -> the dense block-diagonal filter (K, C, R, S) (KRSC memory, zeros off the
+    diagonal blocks) that the implicit-GEMM kernels read: the grouped convolution runs as an ordinary one.  At 4 - 8 channels per group the
+    matrix cores would idle 8 - 10x on the real products anyway and the layer is bound by its activation traffic; the dense form costs what
+    a wide_resnet 3x3 of the same width costs.  (Filter reshaping only: ``sat_grouped_filter_expand``.)"""
+    K, cg, R, S = w.shape
+    w = _krsc(w)
+    out = torch.empty(K, cg * groups, R, S, dtype=w.dtype, device=w.device).contiguous(memory_format=torch.channels_last)
+    L.check(L.lib().sat_grouped_filter_expand(L.ptr(w), L.ptr(out), K, cg * groups, R * S, groups, int(_is_bf(w)), L.stream_ptr()), "sat_grouped_filter_expand")
+    return out
+
+
+def grouped_grad(dw_dense, param, groups):
+    """gradient of the grouped filter = the diagonal blocks of the dense filter's gradient (fp32, KRSC memory) -> ``param``'s gradient buffer"""
+    K, C, R, S = dw_dense.shape
+    out = L.grad_buffer(param)
+    direct = tuple(out.shape) == tuple(param.shape) and out.permute(0, 2, 3, 1).is_contiguous()
+    dst = out if direct else torch.empty(K, R, S, C // groups, dtype=torch.float32, device=dw_dense.device)
+    src = dw_dense.permute(0, 2, 3, 1)
+    assert src.is_contiguous() and dw_dense.dtype == torch.float32
+    L.check(L.lib().sat_grouped_filter_grad_extract(L.ptr(src), L.ptr(dst), K, C, R * S, groups, L.stream_ptr()), "sat_grouped_filter_grad_extract")
+    return out if direct else dst.permute(0, 3, 1, 2)
 
 
 def conv_fwd(x, w, stride, pad, bias=None, stride_w=0):
@@ -470,7 +496,7 @@ def colsum(x2d, out=None):
 
 # ----------------------------------------------------------------------------- whole-network forward / backward
 class _Rec:
-    __slots__ = ("kind", "blk", "x", "c1", "a1", "s1", "c2", "a2", "s2", "c3", "s3", "cd", "sd", "idn", "out")
+    __slots__ = ("kind", "blk", "x", "c1", "a1", "s1", "c2", "a2", "s2", "c3", "s3", "cd", "sd", "idn", "out", "w2")
 
 
 def _block_fwd(blk, x, training, W=None):
@@ -485,7 +511,8 @@ def _block_fwd(blk, x, training, W=None):
         last, tl = conv(r.a1, W(blk.conv2.weight), 1, 1); r.c2 = last
     else:
         r.c1, tl = conv(x, W(blk.conv1.weight), 1, 0); r.a1, r.s1 = bn_fwd(r.c1, blk.bn1, None, True, training, want_mask=True, tiles=tl)
-        r.c2, tl = conv(r.a1, W(blk.conv2.weight), blk.stride, 1); r.a2, r.s2 = bn_fwd(r.c2, blk.bn2, None, True, training, want_mask=True, tiles=tl)
+        r.w2 = W(blk.conv2.weight) if blk.groups == 1 else grouped_dense(W(blk.conv2.weight), blk.groups)      # resnext: block-diagonal dense filter
+        r.c2, tl = conv(r.a1, r.w2, blk.stride, 1); r.a2, r.s2 = bn_fwd(r.c2, blk.bn2, None, True, training, want_mask=True, tiles=tl)
         last, tl = conv(r.a2, W(blk.conv3.weight), 1, 0); r.c3 = last
     res_bn = None
     if blk.downsample is not None:
@@ -531,8 +558,11 @@ def _block_bwd(r, dout, grads, need_dx, W=None, dout_tiles=None, prev=None, queu
         grads[blk.conv3.weight] = conv_wgrad(dx3, r.a2, blk.conv3.weight, 1, 0, param=blk.conv3.weight, queue=queue)
         da2, t2 = conv_dgrad(dx3, W(blk.conv3.weight), r.a2.shape, 1, 0, bn=(r.c2, r.s2))
         dx2, grads[blk.bn2.weight], grads[blk.bn2.bias] = bn_bwd(da2, r.c2, r.a2, r.s2, blk.bn2, True, tiles=t2)
-        grads[blk.conv2.weight] = conv_wgrad(dx2, r.a1, blk.conv2.weight, blk.stride, 1, param=blk.conv2.weight, queue=queue)
-        da1, t1 = conv_dgrad(dx2, W(blk.conv2.weight), r.a1.shape, blk.stride, 1, bn=(r.c1, r.s1))
+        if blk.groups == 1:
+            grads[blk.conv2.weight] = conv_wgrad(dx2, r.a1, blk.conv2.weight, blk.stride, 1, param=blk.conv2.weight, queue=queue)
+        else:          # resnext: gradient of the dense block-diagonal filter (main stream), then its diagonal blocks
+            grads[blk.conv2.weight] = grouped_grad(conv_wgrad(dx2, r.a1, r.w2, blk.stride, 1), blk.conv2.weight, blk.groups)
+        da1, t1 = conv_dgrad(dx2, r.w2, r.a1.shape, blk.stride, 1, bn=(r.c1, r.s1))
         first_w, first_stride, first_pad = blk.conv1.weight, 1, 0
     dx1, grads[blk.bn1.weight], grads[blk.bn1.bias] = bn_bwd(da1, r.c1, r.a1, r.s1, blk.bn1, True, tiles=t1)
     grads[first_w] = conv_wgrad(dx1, r.x, first_w, first_stride, first_pad, param=first_w, queue=queue)
@@ -807,7 +837,7 @@ def _probe_zero_image(conv1, bn1, layers, size):
             return F.batch_norm(x, m.running_mean, m.running_var, m.weight, m.bias, True, m.momentum, m.eps)
 
         def cv(x, m):
-            return F.conv2d(x, m.weight, None, m.stride, m.padding)
+            return F.conv2d(x, m.weight, None, m.stride, m.padding, 1, m.groups)
         x = torch.zeros(1, 3, size, size)
         x = F.max_pool2d(F.relu(bn(cv(x, conv1), bn1)), 3, 2, 1); bn1.num_batches_tracked += 1
         for layer in layers:
@@ -831,13 +861,14 @@ def get_encoder(args):
     if arch not in RESNETS:
         raise ValueError("Encoder not supported : {}".format(arch))
     ckpt = _pretrained_file(arch, getattr(args, "pretrained", False))
-    kind, depths, wpg = RESNETS[arch]
+    kind, depths, wpg = RESNETS[arch][:3]
+    groups = RESNETS[arch][3] if len(RESNETS[arch]) > 3 else 1
     conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False); bn1 = nn.BatchNorm2d(64)
     layers, cin = [], 64
     for si, (planes, nblk) in enumerate(zip((64, 128, 256, 512), depths)):
         blocks = []
         for bi in range(nblk):
-            blk = Block(kind, cin, planes, 2 if (si > 0 and bi == 0) else 1, wpg)
+            blk = Block(kind, cin, planes, 2 if (si > 0 and bi == 0) else 1, wpg, groups)
             cin = blk.cout; blocks.append(blk)
         layers.append(nn.Sequential(*blocks))
     final_dim = cin

@@ -232,6 +232,8 @@ def _damp(enc_like, value=0.25):
 
 @pytest.mark.parametrize("arch,es,px,D,nb", [("resnet18", None, 64, 32, 8), ("resnet18", 3, 64, 32, 8), ("resnet50", None, 128, 32, 8), ("resnet50", 7, 256, 32, 8),
                                              ("wide_resnet50_2", 14, 64, 32, 8), ("resnet34", None, 64, 32, 8),
+                                             # resnext (model.py:28: same branch of get_encoder): grouped 3x3 convolutions, 32 groups
+                                             ("resnext50_32x4d", 7, 256, 64, 8), ("resnext101_32x8d", None, 64, 32, 8),
                                              # BASELINE configs[2] and [3]: the encoders at their real resolution and annotation shape
                                              ("resnet101", 14, 256, 512, 4), ("wide_resnet101_2", 14, 256, 1024, 4)])
 def test_whole_encoder_against_oracle(E, arch, es, px, D, nb):
@@ -365,7 +367,7 @@ def test_residual_block_bf16_storage(E, kind, cin, planes, stride):
     assert max(errs.values()) <= 3e-2, errs
 
 
-@pytest.mark.parametrize("arch,es,px,D,nb,damp", [("resnet18", 3, 64, 32, 8, 0.25), ("resnet50", 7, 256, 256, 8, 0.25)])
+@pytest.mark.parametrize("arch,es,px,D,nb,damp", [("resnet18", 3, 64, 32, 8, 0.25), ("resnet50", 7, 256, 256, 8, 0.25), ("resnext50_32x4d", 7, 256, 64, 8, 0.25)])
 def test_whole_encoder_bf16_storage_against_the_rounding_oracle(E, arch, es, px, D, nb, damp):
     """The whole encoder in bf16 mode (bf16 activations and filter copies, fp32 statistics / accumulation / parameter gradients) against
     the CPU oracle that rounds to bf16 at the same storage points (oracle/bf16_emulation.py), forward and backward from IDENTICAL inputs

@@ -191,6 +191,23 @@ def test_encoder_structure(golden_dir):
             assert e(torch.rand(1, 3, 256, 256)).shape == (1, 16, L, L)
 
 
+def test_resnext_structure_matches_the_reference_summary():
+    """dev/encoder_summaries.txt:12: resnext50_32x4d has 22.98 M parameters and 2048 features (the trunk without pooling / fc, model.py:28-29):
+    torchvision's grouped Bottleneck (32 groups, 4 channels per group at the first stage), restated in the oracle and in the product."""
+    n, f = O.trunk_param_count("resnext50_32x4d")
+    assert round(n / 1e6, 2) == 22.98 and f == 2048
+    import sat_amd  # noqa: F401
+    from sat_amd import encoder as E
+    hp = O.default_hparams(encoder_arch="resnext50_32x4d", encoder_dim=32, input_size=64)
+    enc = E.get_encoder(hp)
+    ref = O.build_encoder(O.default_hparams(encoder_arch="resnext50_32x4d", encoder_dim=32, input_size=64))
+    assert list(enc.state_dict().keys()) == list(ref.state_dict().keys())
+    assert all(tuple(a.shape) == tuple(b.shape) for a, b in zip(enc.state_dict().values(), ref.state_dict().values()))
+    assert tuple(enc.state_dict()["5.0.conv2.weight"].shape) == (128, 4, 3, 3)          # 32 groups of 4 channels
+    trunk = sum(p.numel() for k, p in enc.named_parameters() if not k.startswith("9."))
+    assert trunk == n
+
+
 def test_fixtures_are_small(golden_dir):
     total = sum(os.path.getsize(p) for p in glob.glob(os.path.join(golden_dir, "*.npz")))
     assert total < 4 << 20
