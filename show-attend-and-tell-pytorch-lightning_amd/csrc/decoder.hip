@@ -299,9 +299,10 @@ static int flush_outputs(hipStream_t st, const sat_decoder_dims& d, const sat_de
         SAT_TRY(launch_ok("output dropout"));
         uin = ud;
     }
-    if (w.Wb_out) {          // bf16 mode: vocabulary projection on bf16 copies of both operands.  The weight is copied at every flush:
-                             // under weight tying it is the embedding table, which max-norm renormalisation edits during the loop
-        SAT_TRY(cast_bf16(st, p.out_w, w.Wb_out, (long)d.V * d.m));
+    if (w.Wb_out) {          // bf16 mode: vocabulary projection on bf16 copies of both operands.  The weight copy is made at the first flush of a
+                             // forward pass (p0 == 0) and again at every later one only under weight tying with max-norm renormalisation: the
+                             // embedding table IS the output weight then and is edited during the loop (scheduled sampling flushes every step)
+        if (p0 == 0 || (p.out_w == p.embedding && d.embed_max_norm > 0.f)) SAT_TRY(cast_bf16(st, p.out_w, w.Wb_out, (long)d.V * d.m));
         SAT_TRY(cast_bf16(st, uin, w.Ub + (long)p0 * d.m, (long)rows * d.m));
         return gemm_bb_nt(st, w.Ub + (long)p0 * d.m, d.m, w.Wb_out, d.m, logits + (long)p0 * d.V, d.V, rows, d.V, d.m, p.out_b ? EPI_BIAS : EPI_NONE, p.out_b);
     }
@@ -402,11 +403,17 @@ int decoder_fwd(const sat_decoder_dims& d, const sat_decoder_params& p, const sa
             // scheduled sampling (model.py:521-523): feed argmax of the previous step's logits
             SAT_TRY(flush_outputs(st, d, p, b, w, logits, b.step_offsets_host[pending], b.step_offsets_host[t]));
             pending = t;
-            hipLaunchKernelGGL(argmax_tokens_kernel, dim3(N), dim3(256), 0, st, logits, b.prow + (long)(t - 1) * N, b.lengths, w.Tok + (long)t * N, d.V, t);
-            SAT_TRY(launch_ok("argmax_tokens"));
-            SAT_TRY(renorm(w.Tok + (long)t * N, N));
-            hipLaunchKernelGGL(gather_rows_kernel, dim3(N), dim3(64), 0, st, p.embedding, w.Tok + (long)t * N, w.Y + (long)t * N * m, N, m, d.embedding_dropout, (unsigned long long)d.dropout_seed, (long)t * N);
-            SAT_TRY(launch_ok("embedding gather"));
+            if (d.embed_max_norm > 0.f) {       // the chosen rows are renormalised in place between the decision and the gather (model.py:158-164)
+                hipLaunchKernelGGL(argmax_tokens_kernel, dim3(N), dim3(256), 0, st, logits, b.prow + (long)(t - 1) * N, b.lengths, w.Tok + (long)t * N, d.V, t);
+                SAT_TRY(launch_ok("argmax_tokens"));
+                SAT_TRY(renorm(w.Tok + (long)t * N, N));
+                hipLaunchKernelGGL(gather_rows_kernel, dim3(N), dim3(64), 0, st, p.embedding, w.Tok + (long)t * N, w.Y + (long)t * N * m, N, m, d.embedding_dropout, (unsigned long long)d.dropout_seed, (long)t * N);
+                SAT_TRY(launch_ok("embedding gather"));
+            } else {                            // decision + embedding row in one launch
+                hipLaunchKernelGGL(argmax_gather_kernel, dim3(N), dim3(256), 0, st, logits, b.prow + (long)(t - 1) * N, b.lengths, w.Tok + (long)t * N, d.V, t, p.embedding,
+                                   w.Y + (long)t * N * m, m, d.embedding_dropout, (unsigned long long)d.dropout_seed, (long)t * N);
+                SAT_TRY(launch_ok("argmax + embedding gather"));
+            }
             SAT_TRY(gemm(st, A_ROW, B_ROW, w.Y + (long)t * N * m, m, p.w_ih, m + D, w.GY + (long)t * N * 4 * n, 4 * n, N, 4 * n, m));
         }
         // [q | beta | gates_h] = h_{t-1} * Wcat^T + bcat, sigmoid on the beta columns.  Attention and the gate read the TOP

@@ -156,6 +156,46 @@ __global__ void argmax_tokens_kernel(const float* __restrict__ logits, const int
     }
 }
 
+// the same decision and the embedding row of the chosen token in ONE launch (scheduled sampling without max-norm renormalisation: model.py:521-526):
+// token of caption i at `step` = first maximum of its previous logits row, y[i, :] = embedding[token] (zeros for finished captions)
+__global__ __launch_bounds__(256) void argmax_gather_kernel(const float* __restrict__ logits, const int* __restrict__ prow_prev, const int* __restrict__ lengths,
+                                                            int* __restrict__ tok, int V, int step, const float* __restrict__ table, float* __restrict__ out, int width,
+                                                            float p, unsigned long long seed, long row0) {
+    const int i = blockIdx.x;
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    __shared__ int s_tok;
+    const bool live = lengths[i] > step;          // uniform over the block
+    int bi = 0x7fffffff;
+    if (live) {
+        const float* row = logits + (long)prow_prev[i] * V;
+        float best = -INFINITY;
+        for (int v = threadIdx.x; v < V; v += 256) {
+            const float x = row[v];
+            if (x > best || (x == best && v < bi)) { best = x; bi = v; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        const int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { sv[w] = best; si[w] = bi; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int k = 1; k < 4; ++k)
+                if (sv[k] > best || (sv[k] == best && si[k] < bi)) { best = sv[k]; bi = si[k]; }
+            s_tok = bi; tok[i] = bi;
+        }
+        __syncthreads();
+    } else if (threadIdx.x == 0) tok[i] = -1;
+    const int t = live ? s_tok : -1;
+    for (int c = threadIdx.x; c < width; c += 256) {
+        float v = (t >= 0) ? table[(long)t * width + c] : 0.f;
+        if (p > 0.f) v *= dropout_scale(seed, 1, (unsigned long long)(row0 + i) * width + c, p);
+        out[(long)i * width + c] = v;
+    }
+}
+
 // mean over L of the annotations: mean[b, d]  (model.py:78)
 __global__ void ann_mean_kernel(const float* __restrict__ ann, float* __restrict__ mean, int L, int D) {
     int b = blockIdx.x;

@@ -430,7 +430,11 @@ class SAT(SATDecoder, _Base):
         # reference order: criterion -> encoder -> decoder parts (model.py:148-195); get_encoder writes
         # hp.encoder_dim back when no projection is needed (model.py:56)
         self._build_decoder(hp, encoder_factory=get_encoder)
-        self.set_precision(hp.get("hip_precision", "fp32"))
+        # train.py:31-32 `--precision 16` asks Lightning for torch AMP (fp16 autocast + GradScaler).  The MI355X-native reduced-precision mode is
+        # bf16 storage / bf16 MFMA with fp32 accumulation, master weights and losses (fp32 exponent range: no loss scaling needed); there is no
+        # fp16 path.  `hip_precision` overrides.
+        amp = str(hp.get("precision", 32)) in ("16", "bf16", "16-mixed", "bf16-mixed")
+        self.set_precision(hp.get("hip_precision", "bf16" if amp else "fp32"))
         if hp.pretrained_embedding is not None:
             import numpy as np
             self.embedding.weight = nn.Parameter(torch.tensor(np.load(hp.pretrained_embedding), dtype=torch.float32))

@@ -161,3 +161,16 @@ def test_packing_plans_are_cached_by_caption_lengths_and_match_pack_padded_seque
     assert a.batch_sizes.tolist() == ref.batch_sizes.tolist()
     assert torch.equal(a.pack(x.unsqueeze(-1)).squeeze(-1), ref.data)
     assert torch.equal(a.sorted_indices_dev, a.sorted_indices) and torch.equal(a.unsorted_indices_dev[a.sorted_indices], torch.arange(6))
+
+
+def test_precision_16_of_the_reference_cli_selects_the_bf16_mode():
+    """train.py:31-32: ``--precision 16`` (torch AMP under Lightning) maps to the library's reduced-precision mode; 32 stays exact fp32"""
+    import sat_amd  # noqa: F401
+    from sat_amd import model as M
+    from oracle import sat_oracle as O
+    kw = dict(vocab_size=23, encoder_dim=12, embed_dim=10, attention_dim=7, decoder_dim=9, input_size=64, encoder_arch="resnet18")
+    assert M.SAT(**vars(O.default_hparams(**kw))).sat_precision == "fp32"
+    assert M.SAT(**vars(O.default_hparams(precision=32, **kw))).sat_precision == "fp32"
+    m16 = M.SAT(**vars(O.default_hparams(precision=16, **kw)))
+    assert m16.sat_precision == "bf16" and m16.encoder.precision == "bf16"
+    assert M.SAT(**vars(O.default_hparams(precision=16, hip_precision="fp32", **kw))).sat_precision == "fp32"
