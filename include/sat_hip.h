@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SAT_HIP_ABI_VERSION 20
+#define SAT_HIP_ABI_VERSION 21
 
 int sat_abi_version(void);
 /* dev aid: after every kernel launch wait for the device and print the launch's name to stderr (a device fault then points at the
@@ -338,6 +338,34 @@ int sat_bn_train_bwd_tiles_bf16(const void* dy, const void* x, int64_t rows, int
                                 const float* save_invstd, const float* gamma, int32_t relu, void* dx, float* dgamma, float* dbeta, void* dres,
                                 int32_t dres_accumulate, const uint8_t* relu_mask, float* scratch, void* stream);
 int sat_conv2d_wgrad_bf16(const void* dy, const void* x, float* dw, const sat_conv_geom* g, float* slab, int64_t slab_elems, void* stream);
+/* ---- the residual-block loop of the trunk inside the library (training, bf16 storage; csrc/encoder_loop.hip) --------------------------------
+ * Replaces, per block, the ~10 forward and ~14 backward per-layer calls above (and the tensor allocations between them) that a host-side
+ * driver of torchvision's BasicBlock / Bottleneck (inside `self.encoder(img)`, model.py:19-29, 483, and its autograd) would issue: ONE call
+ * for the forward of a run of blocks, ONE for their backward, over one activation arena whose layout is a pure function of the descriptors.
+ * The loop calls the same per-layer entry points in the same order: results are bit-identical to driving them one by one.
+ * Pointers: filters are the bf16 KRSC copies the convolutions read; BatchNorm index 0..3 = bn1, bn2, bn3 (bottleneck only), downsample's;
+ * gradient destinations are fp32 (filters KRSC).  Backward only: dw* / dgamma / dbeta.                                                      */
+typedef struct sat_block_desc {
+    int32_t kind;                 /* 0 = BasicBlock (3x3, 3x3), 1 = Bottleneck (1x1, 3x3 strided, 1x1)                       */
+    int32_t stride, cin, mid, cout, has_ds;
+    int32_t N, H, W;              /* the block's input map (N, H, W, cin)                                                     */
+    int32_t fwd_res_bn;           /* projection blocks: the shortcut's BatchNorm applied inside the last BatchNorm's kernel   */
+    int32_t dgrad_join;           /* the block's input gradient joins identity + conv path inside the data-gradient launch    */
+    int32_t bn_bwd_epilogue;      /* BatchNorm-backward statistics out of the data-gradient epilogues                         */
+    const void *w1, *w2, *w3, *wd;
+    const float* gamma[4]; const float* beta[4]; float* running_mean[4]; float* running_var[4]; float eps[4]; float momentum[4];
+    float *dw1, *dw2, *dw3, *dwd; float* dgamma[4]; float* dbeta[4];
+} sat_block_desc;
+size_t sat_encoder_blocks_arena_bytes(const sat_block_desc* blocks, int32_t nblocks);
+/* x: bf16 (N, H, W, cin) input of blocks[0]; *out_ptr = the last block's output inside the arena; bn_scratch: sat_bn_scratch_bytes of the largest map */
+int sat_encoder_blocks_fwd(const sat_block_desc* blocks, int32_t nblocks, const void* x, void* arena, size_t arena_bytes, float* bn_scratch, void** out_ptr,
+                           void* stream);
+/* dout: bf16 gradient of the last block's output; *dx_ptr = gradient of blocks[0]'s input inside the arena.  side_stream (or NULL): the weight
+ * gradients are launched there (fork / join through `event`, a hipEvent_t of the caller; joined before the call returns), with their own split-K scratch */
+int sat_encoder_blocks_bwd(const sat_block_desc* blocks, int32_t nblocks, const void* x, void* arena, size_t arena_bytes, const void* dout, float* bn_scratch,
+                           float* slab_main, int64_t slab_main_elems, float* slab_side, int64_t slab_side_elems, void* side_stream, void* event,
+                           void** dx_ptr, void* stream);
+
 /* ResNet stem tail in one pass (model.py:19-29 keeps torchvision's bn1 -> relu -> maxpool): BatchNorm(train statistics already in
  * mean / invstd: sat_bn_train_fwd_t with y = NULL computes them and updates the running statistics) + ReLU + MaxPool2d(3, 2, 1)
  * of the NHWC convolution output x (N, H, W, C) -> y_pool (N, P, Q, C), argmax (same shape, bytes: window position of the first

@@ -123,8 +123,20 @@ class ConvGeom(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("N", "H", "W", "C", "K", "R", "S", "stride", "pad", "stride_w")]
 
 
+class BlockDesc(C.Structure):
+    """sat_block_desc (include/sat_hip.h): one residual block of the trunk for sat_encoder_blocks_fwd / _bwd"""
+    _fields_ = ([(k, C.c_int32) for k in ("kind", "stride", "cin", "mid", "cout", "has_ds", "N", "H", "W", "fwd_res_bn", "dgrad_join", "bn_bwd_epilogue")] +
+                [(k, C.c_void_p) for k in ("w1", "w2", "w3", "wd")] +
+                [("gamma", C.c_void_p * 4), ("beta", C.c_void_p * 4), ("running_mean", C.c_void_p * 4), ("running_var", C.c_void_p * 4),
+                 ("eps", C.c_float * 4), ("momentum", C.c_float * 4)] +
+                [(k, C.c_void_p) for k in ("dw1", "dw2", "dw3", "dwd")] + [("dgamma", C.c_void_p * 4), ("dbeta", C.c_void_p * 4)])
+
+
 _vp, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SYMBOLS.update({
+    "sat_encoder_blocks_arena_bytes": (C.c_size_t, [C.POINTER(BlockDesc), _i32]),
+    "sat_encoder_blocks_fwd": (C.c_int, [C.POINTER(BlockDesc), _i32, _vp, _vp, C.c_size_t, _vp, C.POINTER(C.c_void_p), _vp]),
+    "sat_encoder_blocks_bwd": (C.c_int, [C.POINTER(BlockDesc), _i32, _vp, _vp, C.c_size_t, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, C.POINTER(C.c_void_p), _vp]),
     "sat_conv2d_fwd": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(ConvGeom), _vp]),
     "sat_conv2d_dgrad": (C.c_int, [_vp, _vp, _vp, C.POINTER(ConvGeom), _i32, _vp]),
     "sat_conv2d_wgrad": (C.c_int, [_vp, _vp, _vp, C.POINTER(ConvGeom), _vp, _i64, _vp]),
@@ -251,8 +263,8 @@ def lib():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(handle, name)          # AttributeError if the export is missing
             fn.restype, fn.argtypes = res, args
-        if handle.sat_abi_version() != 20:
-            raise SatHipError("libsat_hip.so ABI version %d != 20 (rebuild: make -C csrc)" % handle.sat_abi_version())
+        if handle.sat_abi_version() != 21:
+            raise SatHipError("libsat_hip.so ABI version %d != 21 (rebuild: make -C csrc)" % handle.sat_abi_version())
         _lib = handle
     return _lib
 

@@ -592,6 +592,101 @@ def _block_bwd(r, dout, grads, need_dx, W=None, dout_tiles=None, prev=None, queu
     return conv_dgrad(dx1, W(first_w), r.x.shape, first_stride, first_pad, out=g, accumulate=True), None
 
 
+#: the residual-block loop inside the library (csrc/encoder_loop.hip): one call per direction for the whole trunk instead of ~24 calls per block.
+#: Training, bf16 storage, one process (the data-parallel exchange wants a notification per ResNet stage: it keeps the per-layer driver).
+_BLOCK_LOOP = os.environ.get("SAT_BLOCK_LOOP", "1") != "0"
+
+
+def _loop_blocks(enc):
+    return [blk for li in (5, 6, 7, 8) for blk in enc[li]]
+
+
+def _loop_eligible(enc, x, training, bf):
+    if not (_BLOCK_LOOP and training and bf and getattr(enc, "grad_ready", None) is None and _is_bf(x) and x.is_contiguous()):
+        return False
+    blocks = _loop_blocks(enc)
+    if len(blocks) > 64:
+        return False
+    for blk in blocks:
+        if blk.groups != 1 or blk.conv1.in_channels % 8 or blk.cout % 8 or blk.conv1.out_channels % 8:
+            return False
+    return True
+
+
+def _bn_ptrs(d, i, bn):
+    d.gamma[i], d.beta[i] = bn.weight.data_ptr(), bn.bias.data_ptr()
+    d.running_mean[i], d.running_var[i] = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+    d.eps[i], d.momentum[i] = float(bn.eps), 0.1 if bn.momentum is None else float(bn.momentum)
+
+
+def _loop_descs(enc, x, Wt):
+    """descriptor table of the trunk's blocks for an input map x (N, H, W, C): geometry, filters as the kernels read them, BatchNorm pointers"""
+    blocks = _loop_blocks(enc)
+    arr = (L.BlockDesc * len(blocks))()
+    N, H, W, _ = x.shape
+    bns = []
+    for d, blk in zip(arr, blocks):
+        d.kind = 0 if blk.kind == "basic" else 1
+        d.stride, d.cin, d.cout, d.has_ds = blk.stride, blk.conv1.in_channels, blk.cout, int(blk.downsample is not None)
+        d.mid = blk.conv1.out_channels if blk.kind != "basic" else blk.cout
+        d.N, d.H, d.W = N, H, W
+        d.fwd_res_bn, d.dgrad_join, d.bn_bwd_epilogue = int(_FWD_RES_BN), int(_DGRAD_JOIN), int(_BN_BWD_EPILOGUE)
+        d.w1, d.w2 = Wt(blk.conv1.weight).data_ptr(), Wt(blk.conv2.weight).data_ptr()
+        _bn_ptrs(d, 0, blk.bn1); _bn_ptrs(d, 1, blk.bn2); bns += [blk.bn1, blk.bn2]
+        if blk.kind != "basic":
+            d.w3 = Wt(blk.conv3.weight).data_ptr(); _bn_ptrs(d, 2, blk.bn3); bns.append(blk.bn3)
+        if blk.downsample is not None:
+            d.wd = Wt(blk.downsample[0].weight).data_ptr(); _bn_ptrs(d, 3, blk.downsample[1]); bns.append(blk.downsample[1])
+        H, W = _out_hw(H, W, 3, 3, blk.stride, 1)
+    return arr, blocks, bns, (N, H, W, blocks[-1].cout)
+
+
+def _loop_scratch(device, arr, blocks):
+    """BatchNorm scratch for the largest map of the trunk"""
+    best = None
+    for d, blk in zip(arr, blocks):
+        for rows, Cc in ((d.N * d.H * d.W, max(d.cin, d.mid)), (d.N * d.H * d.W, d.cout)):
+            need = L.lib().sat_bn_scratch_bytes(rows, Cc)
+            if best is None or need > best[0]:
+                best = (need, rows, Cc)
+    return _bn_scratch(device, best[1], best[2])
+
+
+def _loop_slab_bytes(arr):
+    """split-K scratch that serves every weight-gradient launch of the trunk"""
+    lib = L.lib()
+    need = 128 << 20
+    for d in arr:
+        P, Q = _out_hw(d.H, d.W, 3, 3, d.stride, 1)
+        if d.kind:
+            geoms = [(d.N, d.H, d.W, d.cin, d.mid, 1, 1, 1, 0), (d.N, d.H, d.W, d.mid, d.mid, 3, 3, d.stride, 1), (d.N, P, Q, d.mid, d.cout, 1, 1, 1, 0)]
+        else:
+            geoms = [(d.N, d.H, d.W, d.cin, d.cout, 3, 3, d.stride, 1), (d.N, P, Q, d.cout, d.cout, 3, 3, 1, 1)]
+        if d.has_ds:
+            geoms.append((d.N, d.H, d.W, d.cin, d.cout, 1, 1, d.stride, 0))
+        for g in geoms:
+            need = max(need, lib.sat_conv2d_wgrad_slab_bytes(C.byref(_geom(*g))))
+    return need
+
+
+def _arena_view(arena, ptr, shape):
+    off = ptr - arena.data_ptr()
+    n = 1
+    for v in shape:
+        n *= v
+    return arena[off:off + 2 * n].view(BF16).view(*shape)
+
+
+def _krsc_dest(param):
+    """(destination pointer tensor in KRSC fp32 memory, gradient tensor to hand to autograd) for a filter parameter"""
+    K, Cc, R, S = param.shape
+    out = L.grad_buffer(param)
+    if tuple(out.shape) == (K, Cc, R, S) and out.permute(0, 2, 3, 1).is_contiguous():
+        return out, out
+    dst = torch.empty(K, R, S, Cc, dtype=torch.float32, device=param.device)
+    return dst, dst.permute(0, 3, 1, 2)
+
+
 class EncoderFn(torch.autograd.Function):
     """img (B,3,H,W) fp32 in [0,1] -> annotations (B,D,h,w) fp32 (NHWC memory).  ``enc.precision``:
     "fp32" = fp32 activations on the exact fp32 MFMA kernel (parity mode); "bf16" = bf16 activations and
@@ -672,10 +767,22 @@ class EncoderFn(torch.autograd.Function):
             L.check(lib.sat_maxpool3x3s2_fwd_t(int(bf), L.ptr(t["a0"]), L.ptr(t["p0"]), L.ptr(t["amax"]), Nn, Hh, Ww, Cc, st), "sat_maxpool3x3s2_fwd")
         x = t["p0"]
         recs = []
-        for li in (5, 6, 7, 8):
-            for blk in enc[li]:
-                r = _block_fwd(blk, x, training, Wt)
-                recs.append(r); x = r.out
+        if _loop_eligible(enc, x, training, bf):
+            # the whole trunk in one library call over one arena (csrc/encoder_loop.hip); bit-identical to the per-layer driver below
+            arr, blocks, bns, oshape = _loop_descs(enc, x, Wt)
+            nbytes = lib.sat_encoder_blocks_arena_bytes(arr, len(blocks))
+            arena = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            outp = C.c_void_p(0)
+            L.check(lib.sat_encoder_blocks_fwd(arr, len(blocks), L.ptr(x), L.ptr(arena), nbytes, L.ptr(_loop_scratch(x.device, arr, blocks)), C.byref(outp), st),
+                    "sat_encoder_blocks_fwd")
+            _tracked.extend(bn.num_batches_tracked for bn in bns)
+            t["loop"] = (arr, blocks, arena, nbytes, x)
+            x = _arena_view(arena, outp.value, oshape)
+        else:
+            for li in (5, 6, 7, 8):
+                for blk in enc[li]:
+                    r = _block_fwd(blk, x, training, Wt)
+                    recs.append(r); x = r.out
         t["trunk"] = x
         if enc.proj is not None:
             Nn, Hh, Ww, Cc = x.shape
@@ -740,6 +847,32 @@ class EncoderFn(torch.autograd.Function):
             tiles = None
             x0s = t["x0"].shape
             queue = _SideQueue(d.device, _WGRAD_STREAM and bf and x0s[0] * x0s[1] * x0s[2] * (2 if t.get("stem_pairs") else 1) >= _WGRAD_SIDE_MIN_INPUT_PIXELS)
+            if t.get("loop") is not None:
+                arr, blocks, arena, nbytes, xin = t["loop"]
+                dests = []
+                for dsc, blk in zip(arr, blocks):          # where the parameter gradients go (bucket slices of the data-parallel exchange, or new memory)
+                    convs = [(blk.conv1, "dw1"), (blk.conv2, "dw2")] + ([(blk.conv3, "dw3")] if blk.kind != "basic" else []) + \
+                            ([(blk.downsample[0], "dwd")] if blk.downsample is not None else [])
+                    for conv, field in convs:
+                        dst, gr = _krsc_dest(conv.weight)
+                        setattr(dsc, field, dst.data_ptr()); grads[conv.weight] = gr; dests.append(dst)
+                    bnl = [(0, blk.bn1), (1, blk.bn2)] + ([(2, blk.bn3)] if blk.kind != "basic" else []) + ([(3, blk.downsample[1])] if blk.downsample is not None else [])
+                    for i, bn in bnl:
+                        gw, gb = L.grad_buffer(bn.weight), L.grad_buffer(bn.bias)
+                        dsc.dgamma[i], dsc.dbeta[i] = gw.data_ptr(), gb.data_ptr(); grads[bn.weight], grads[bn.bias] = gw, gb
+                slab_b = _loop_slab_bytes(arr)
+                slab_m = _slab(d.device, slab_b, "main")
+                side_ptr = ev_ptr = None; slab_s = None
+                if queue.enabled:
+                    slab_s = _slab(d.device, slab_b, "side0")
+                    queue.ev.record(queue.main)
+                    side_ptr, ev_ptr = queue.side_ptrs[0], C.c_void_p(queue.ev.cuda_event)
+                dxp = C.c_void_p(0)
+                L.check(lib.sat_encoder_blocks_bwd(arr, len(blocks), L.ptr(xin), L.ptr(arena), nbytes, L.ptr(d.contiguous()), L.ptr(_loop_scratch(d.device, arr, blocks)),
+                                                   L.ptr(slab_m), slab_m.numel(), L.ptr(slab_s), 0 if slab_s is None else slab_s.numel(), side_ptr, ev_ptr,
+                                                   C.byref(dxp), st), "sat_encoder_blocks_bwd")
+                d = _arena_view(arena, dxp.value, tuple(xin.shape))
+                t["loop_keep"] = dests
             for idx in range(len(recs) - 1, -1, -1):
                 d, tiles = _block_bwd(recs[idx], d, grads, True, Wt, dout_tiles=tiles, prev=(recs[idx - 1] if idx > 0 else None), queue=queue)
                 if cb is not None and idx in (bounds[2], bounds[1], bounds[0]):      # a ResNet stage just finished

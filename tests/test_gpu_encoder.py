@@ -627,3 +627,39 @@ def test_nan_is_not_swallowed_by_relu_or_max_pool(E):
     L.check(L.lib().sat_maxpool3x3s2_fwd(L.ptr(xp), L.ptr(yd), L.ptr(am), 2, 6, 6, 8, L.stream_ptr()), "maxpool")
     refp = F.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
     assert torch.equal(torch.isnan(yd.cpu()), torch.isnan(refp)) and int(torch.isnan(refp).sum()) >= 1
+
+
+@pytest.mark.parametrize("arch,px,nb,es", [("resnet18", 64, 6, 3), ("resnet50", 128, 4, 7), ("resnet34", 96, 3, None), ("wide_resnet50_2", 64, 5, 14)])
+def test_block_loop_inside_the_library_is_bit_identical_to_the_per_layer_driver(E, arch, px, nb, es):
+    """csrc/encoder_loop.hip runs the trunk's residual blocks in one call per direction over one arena; it calls the same per-layer entry points
+    in the same order as encoder.py's `_block_fwd` / `_block_bwd`, so annotations, every gradient and every BatchNorm buffer must be BIT-equal
+    (bf16 mode, training; also with the weight gradients on the side stream)."""
+    from oracle import prng, sat_oracle as O
+    outs = []
+    for loop in (True, False):
+        hp = O.default_hparams(encoder_arch=arch, encoder_dim=48, input_size=px, encoder_size=es)
+        torch.manual_seed(9)
+        enc = E.get_encoder(hp).cuda().train()
+        enc.precision = "bf16"
+        old, old_side = E._BLOCK_LOOP, E._WGRAD_SIDE_MIN_INPUT_PIXELS
+        E._BLOCK_LOOP, E._WGRAD_SIDE_MIN_INPUT_PIXELS = loop, 0          # side stream on whatever the batch size
+        try:
+            res = []
+            for it in range(2):                                       # second pass: BatchNorm buffers have moved, bf16 filter copies are reused
+                img = torch.from_numpy(prng.uniform((nb, 3, px, px), 40 + it, 0.0, 1.0)).cuda()
+                for p in enc.parameters():
+                    p.grad = None
+                y = enc(img)
+                dy = torch.from_numpy(prng.uniform(tuple(y.shape), 50 + it)).cuda()
+                y.backward(dy)
+                torch.cuda.synchronize()
+                res.append((y.detach().clone(), {k: p.grad.clone() for k, p in enc.named_parameters()}, {k: v.clone() for k, v in enc.state_dict().items()}))
+        finally:
+            E._BLOCK_LOOP, E._WGRAD_SIDE_MIN_INPUT_PIXELS = old, old_side
+        outs.append(res)
+    for (ya, ga, sa), (yb, gb, sb) in zip(*outs):
+        assert torch.equal(ya, yb), "annotations differ"
+        for k in ga:
+            assert torch.equal(ga[k], gb[k]), "gradient of %s differs (max |d| %.3e)" % (k, float((ga[k] - gb[k]).abs().max()))
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), "buffer %s differs" % k
