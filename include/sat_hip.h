@@ -360,11 +360,14 @@ size_t sat_encoder_blocks_arena_bytes(const sat_block_desc* blocks, int32_t nblo
 /* x: bf16 (N, H, W, cin) input of blocks[0]; *out_ptr = the last block's output inside the arena; bn_scratch: sat_bn_scratch_bytes of the largest map */
 int sat_encoder_blocks_fwd(const sat_block_desc* blocks, int32_t nblocks, const void* x, void* arena, size_t arena_bytes, float* bn_scratch, void** out_ptr,
                            void* stream);
-/* dout: bf16 gradient of the last block's output; *dx_ptr = gradient of blocks[0]'s input inside the arena.  side_stream (or NULL): the weight
- * gradients are launched there (fork / join through `event`, a hipEvent_t of the caller; joined before the call returns), with their own split-K scratch */
-int sat_encoder_blocks_bwd(const sat_block_desc* blocks, int32_t nblocks, const void* x, void* arena, size_t arena_bytes, const void* dout, float* bn_scratch,
-                           float* slab_main, int64_t slab_main_elems, float* slab_side, int64_t slab_side_elems, void* side_stream, void* event,
-                           void** dx_ptr, void* stream);
+/* Backward of blocks [last .. first], descending (the whole trunk, or one ResNet stage at a time so that a gradient exchange can start per stage).
+ * dout: bf16 gradient of block `last`'s output; dout_tiles / dout_tile_rows: the BatchNorm-backward statistics that came with it from the previous
+ * call (NULL / 0 for the first call).  *dx_ptr = gradient of block `first`'s input inside the arena, *dx_tiles / *dx_tile_rows its statistics.
+ * side_stream (or NULL): the weight gradients are launched there (fork / join through `event`, a hipEvent_t of the caller; joined before the call
+ * returns), with their own split-K scratch.                                                                                                   */
+int sat_encoder_blocks_bwd(const sat_block_desc* blocks, int32_t nblocks, int32_t first, int32_t last, const void* x, void* arena, size_t arena_bytes, const void* dout,
+                           const float* dout_tiles, int32_t dout_tile_rows, float* bn_scratch, float* slab_main, int64_t slab_main_elems, float* slab_side,
+                           int64_t slab_side_elems, void* side_stream, void* event, void** dx_ptr, float** dx_tiles, int32_t* dx_tile_rows, void* stream);
 
 /* ResNet stem tail in one pass (model.py:19-29 keeps torchvision's bn1 -> relu -> maxpool): BatchNorm(train statistics already in
  * mean / invstd: sat_bn_train_fwd_t with y = NULL computes them and updates the running statistics) + ReLU + MaxPool2d(3, 2, 1)

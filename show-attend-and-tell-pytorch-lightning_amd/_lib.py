@@ -136,7 +136,8 @@ _vp, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SYMBOLS.update({
     "sat_encoder_blocks_arena_bytes": (C.c_size_t, [C.POINTER(BlockDesc), _i32]),
     "sat_encoder_blocks_fwd": (C.c_int, [C.POINTER(BlockDesc), _i32, _vp, _vp, C.c_size_t, _vp, C.POINTER(C.c_void_p), _vp]),
-    "sat_encoder_blocks_bwd": (C.c_int, [C.POINTER(BlockDesc), _i32, _vp, _vp, C.c_size_t, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, C.POINTER(C.c_void_p), _vp]),
+    "sat_encoder_blocks_bwd": (C.c_int, [C.POINTER(BlockDesc), _i32, _i32, _i32, _vp, _vp, C.c_size_t, _vp, _vp, _i32, _vp, _vp, _i64, _vp, _i64, _vp, _vp,
+                                         C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32), _vp]),
     "sat_conv2d_fwd": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(ConvGeom), _vp]),
     "sat_conv2d_dgrad": (C.c_int, [_vp, _vp, _vp, C.POINTER(ConvGeom), _i32, _vp]),
     "sat_conv2d_wgrad": (C.c_int, [_vp, _vp, _vp, C.POINTER(ConvGeom), _vp, _i64, _vp]),

@@ -198,13 +198,16 @@ int sat_encoder_blocks_fwd(const sat_block_desc* blocks, int32_t nblocks, const 
     return SAT_OK;
 }
 
-// Backward of blocks [nblocks - 1 .. 0].  dout: gradient of the last block's output (bf16, its shape).  dx_ptr: where the gradient of block 0's
-// input lies (inside the arena).  Weight gradients go to `side_stream` when given (fork / join through `event`: the caller's stream waits for the
-// side stream before this call returns control of the gradients), each stream with its own split-K scratch.
-int sat_encoder_blocks_bwd(const sat_block_desc* blocks, int32_t nblocks, const void* x, void* arena, size_t arena_bytes, const void* dout, float* bn_scratch,
-                           float* slab_main, int64_t slab_main_elems, float* slab_side, int64_t slab_side_elems, void* side_stream, void* event,
-                           void** dx_ptr, void* stream) {
-    if (!blocks || !x || !arena || !dout || !bn_scratch || !slab_main || nblocks <= 0 || nblocks > MAX_BLOCKS)
+// Backward of blocks [last .. first] (descending; the whole table describes the trunk, a call may cover one ResNet stage of it so that the caller
+// can start a gradient exchange per stage).  dout: gradient of block `last`'s output (bf16, its shape) with the backward statistics of that block's
+// last BatchNorm per row tile if the launch that wrote dout produced them (dout_tiles / dout_tile_rows: what the previous call returned, else NULL / 0).
+// *dx_ptr: where the gradient of block `first`'s input lies (inside the arena), *dx_tiles / *dx_tile_rows: the statistics that came with it.
+// Weight gradients go to `side_stream` when given (fork / join through `event`: the caller's stream waits for the side stream before this call
+// returns), each stream with its own split-K scratch.
+int sat_encoder_blocks_bwd(const sat_block_desc* blocks, int32_t nblocks, int32_t first, int32_t last, const void* x, void* arena, size_t arena_bytes, const void* dout,
+                           const float* dout_tiles, int32_t dout_tile_rows, float* bn_scratch, float* slab_main, int64_t slab_main_elems, float* slab_side,
+                           int64_t slab_side_elems, void* side_stream, void* event, void** dx_ptr, float** dx_tiles, int32_t* dx_tile_rows, void* stream) {
+    if (!blocks || !x || !arena || !dout || !bn_scratch || !slab_main || nblocks <= 0 || nblocks > MAX_BLOCKS || first < 0 || last >= nblocks || first > last)
         return fail(SAT_EINVAL, "encoder_blocks_bwd: bad argument");
     if (side_stream && (!event || !slab_side)) return fail(SAT_EINVAL, "encoder_blocks_bwd: side stream without event / scratch");
     BlockBufs bufs[MAX_BLOCKS];
@@ -221,8 +224,8 @@ int sat_encoder_blocks_bwd(const sat_block_desc* blocks, int32_t nblocks, const 
         return sat_conv2d_wgrad_bf16(dy, xx, dw, &g, slab_side, slab_side_elems, side_stream);
     };
     const void* d_cur = dout;
-    const float* d_tiles = nullptr; int d_tile_rows = 0;
-    for (int i = nblocks - 1; i >= 0; --i) {
+    const float* d_tiles = (dout_tiles && dout_tile_rows > 0) ? dout_tiles : nullptr; int d_tile_rows = d_tiles ? dout_tile_rows : 0;
+    for (int i = last; i >= first; --i) {
         const sat_block_desc& b = blocks[i];
         const BlockBufs& w = bufs[i];
         const Dims d = dims_of(b);
@@ -290,6 +293,8 @@ int sat_encoder_blocks_bwd(const sat_block_desc* blocks, int32_t nblocks, const 
         SAT_CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)event, 0));
     }
     if (dx_ptr) *dx_ptr = const_cast<void*>(d_cur);
+    if (dx_tiles) *dx_tiles = const_cast<float*>(d_tiles);
+    if (dx_tile_rows) *dx_tile_rows = d_tile_rows;
     return SAT_OK;
 }
 

@@ -602,7 +602,7 @@ def _loop_blocks(enc):
 
 
 def _loop_eligible(enc, x, training, bf):
-    if not (_BLOCK_LOOP and training and bf and getattr(enc, "grad_ready", None) is None and _is_bf(x) and x.is_contiguous()):
+    if not (_BLOCK_LOOP and training and bf and _is_bf(x) and x.is_contiguous()):
         return False
     blocks = _loop_blocks(enc)
     if len(blocks) > 64:
@@ -849,17 +849,19 @@ class EncoderFn(torch.autograd.Function):
             queue = _SideQueue(d.device, _WGRAD_STREAM and bf and x0s[0] * x0s[1] * x0s[2] * (2 if t.get("stem_pairs") else 1) >= _WGRAD_SIDE_MIN_INPUT_PIXELS)
             if t.get("loop") is not None:
                 arr, blocks, arena, nbytes, xin = t["loop"]
-                dests = []
+                dests, per_block = [], []
                 for dsc, blk in zip(arr, blocks):          # where the parameter gradients go (bucket slices of the data-parallel exchange, or new memory)
+                    mine = {}
                     convs = [(blk.conv1, "dw1"), (blk.conv2, "dw2")] + ([(blk.conv3, "dw3")] if blk.kind != "basic" else []) + \
                             ([(blk.downsample[0], "dwd")] if blk.downsample is not None else [])
                     for conv, field in convs:
                         dst, gr = _krsc_dest(conv.weight)
-                        setattr(dsc, field, dst.data_ptr()); grads[conv.weight] = gr; dests.append(dst)
+                        setattr(dsc, field, dst.data_ptr()); mine[conv.weight] = gr; dests.append(dst)
                     bnl = [(0, blk.bn1), (1, blk.bn2)] + ([(2, blk.bn3)] if blk.kind != "basic" else []) + ([(3, blk.downsample[1])] if blk.downsample is not None else [])
                     for i, bn in bnl:
                         gw, gb = L.grad_buffer(bn.weight), L.grad_buffer(bn.bias)
-                        dsc.dgamma[i], dsc.dbeta[i] = gw.data_ptr(), gb.data_ptr(); grads[bn.weight], grads[bn.bias] = gw, gb
+                        dsc.dgamma[i], dsc.dbeta[i] = gw.data_ptr(), gb.data_ptr(); mine[bn.weight], mine[bn.bias] = gw, gb
+                    per_block.append(mine)
                 slab_b = _loop_slab_bytes(arr)
                 slab_m = _slab(d.device, slab_b, "main")
                 side_ptr = ev_ptr = None; slab_s = None
@@ -867,12 +869,24 @@ class EncoderFn(torch.autograd.Function):
                     slab_s = _slab(d.device, slab_b, "side0")
                     queue.ev.record(queue.main)
                     side_ptr, ev_ptr = queue.side_ptrs[0], C.c_void_p(queue.ev.cuda_event)
-                dxp = C.c_void_p(0)
-                L.check(lib.sat_encoder_blocks_bwd(arr, len(blocks), L.ptr(xin), L.ptr(arena), nbytes, L.ptr(d.contiguous()), L.ptr(_loop_scratch(d.device, arr, blocks)),
-                                                   L.ptr(slab_m), slab_m.numel(), L.ptr(slab_s), 0 if slab_s is None else slab_s.numel(), side_ptr, ev_ptr,
-                                                   C.byref(dxp), st), "sat_encoder_blocks_bwd")
-                d = _arena_view(arena, dxp.value, tuple(xin.shape))
-                t["loop_keep"] = dests
+                scratch = _loop_scratch(d.device, arr, blocks)
+                # one call for the whole trunk, or one per ResNet stage when the data-parallel exchange wants to start a bucket per stage
+                starts = [0] + bounds[:3] if cb is not None else [0]
+                ranges = [(starts[k], (starts[k + 1] if k + 1 < len(starts) else len(blocks)) - 1) for k in range(len(starts))]
+                dcur = d.contiguous(); dptr = dcur.data_ptr()
+                tptr, trows = C.c_void_p(0), C.c_int32(0)
+                for first, last in reversed(ranges):
+                    dxp = C.c_void_p(0)
+                    L.check(lib.sat_encoder_blocks_bwd(arr, len(blocks), first, last, L.ptr(xin), L.ptr(arena), nbytes, dptr, tptr, trows.value, L.ptr(scratch),
+                                                       L.ptr(slab_m), slab_m.numel(), L.ptr(slab_s), 0 if slab_s is None else slab_s.numel(), side_ptr, ev_ptr,
+                                                       C.byref(dxp), C.byref(tptr), C.byref(trows), st), "sat_encoder_blocks_bwd")
+                    dptr = dxp.value
+                    for i in range(first, last + 1):
+                        grads.update(per_block[i])
+                    if cb is not None and first > 0:          # a ResNet stage just finished (its weight gradients are joined)
+                        cb(dict(grads))
+                d = _arena_view(arena, dptr, tuple(xin.shape))
+                t["loop_keep"] = (dests, dcur)
             for idx in range(len(recs) - 1, -1, -1):
                 d, tiles = _block_bwd(recs[idx], d, grads, True, Wt, dout_tiles=tiles, prev=(recs[idx - 1] if idx > 0 else None), queue=queue)
                 if cb is not None and idx in (bounds[2], bounds[1], bounds[0]):      # a ResNet stage just finished
