@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SAT_HIP_ABI_VERSION 21
+#define SAT_HIP_ABI_VERSION 22
 
 int sat_abi_version(void);
 /* dev aid: after every kernel launch wait for the device and print the launch's name to stderr (a device fault then points at the
@@ -395,6 +395,23 @@ int sat_stem_filter_pairs(const float* w3, void* w_pairs_bf16, int32_t K, void* 
 int sat_grouped_filter_expand(const void* w_grouped, void* w_dense, int32_t K, int32_t C, int32_t RS, int32_t groups, int32_t bf16, void* stream);
 int sat_grouped_filter_grad_extract(const float* dw_dense, float* dw_grouped, int32_t K, int32_t C, int32_t RS, int32_t groups, void* stream);
 int sat_stem_filter_grad_unpairs(const float* dw_pairs, float* dw3, int32_t K, void* stream);
+/* ShuffleNetV2 trunk (the reference's CLI default --encoder_arch shufflenet_v2_x0_5, train.py:43; model.py:30-31 keeps torchvision's
+ * conv1, maxpool, stage2-4, conv5).  dtype: 0 = fp32, 1 = bf16 activations; NHWC; C a multiple of 4 (fp32) / 8 (bf16).
+ *   depthwise 3x3, pad 1, stride 1 | 2 (InvertedResidual.depthwise_conv): w = the (C, 1, 3, 3) fp32 parameter as it lies in memory ([C][9],
+ *     master weights in both modes); fp32 accumulation.  wgrad: fp32 dw [C][9] from per-chunk partial sums added in a fixed order
+ *     (scratch: sat_dwconv3x3_wgrad_scratch_bytes);
+ *   channel_shuffle(cat(a, b), groups = 2) of two (rows, Ch) branches: element c of the result = (c odd ? b : a)[c / 2].  join writes
+ *     either `full` (rows, 2 Ch), or - full == NULL - its two halves x1 = [:, :Ch], x2 = [:, Ch:] as separate dense tensors (what the
+ *     next stride-1 unit's x.chunk(2, dim = 1) reads); split is the backward: (d full | its halves) -> (da, db).                        */
+int sat_dwconv3x3_fwd_t(int32_t dtype, const void* x, const float* w, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t stride, void* stream);
+int sat_dwconv3x3_dgrad_t(int32_t dtype, const void* dy, const float* w, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t stride, void* stream);
+size_t sat_dwconv3x3_wgrad_scratch_bytes(int32_t N, int32_t H, int32_t W, int32_t C, int32_t stride);
+int sat_dwconv3x3_wgrad_t(int32_t dtype, const void* dy, const void* x, float* dw, int32_t N, int32_t H, int32_t W, int32_t C, int32_t stride,
+                          float* scratch, void* stream);
+int sat_shuffle_join_t(int32_t dtype, const void* a, const void* b, void* full, void* x1, void* x2, int64_t rows, int32_t Ch, void* stream);
+int sat_shuffle_split_t(int32_t dtype, const void* dfull, const void* dx1, const void* dx2, void* da, void* db, int64_t rows, int32_t Ch, void* stream);
+/* bf16 -> fp32 copy (n % 8 == 0): the annotations of a bf16 trunk without the 1x1 projection (encoder_dim == trunk width, model.py:56-57) */
+int sat_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
 /* (pixels, 3) <-> (pixels, 4) zero padded; used for the stem filters */
 int sat_pad_channels_3to4(const float* src, float* dst, int64_t pixels, int32_t inverse, void* stream);
 /* nn.BatchNorm2d in training mode over a (rows, C) NHWC view, fused with the residual add and ReLU of the

@@ -92,10 +92,54 @@ def _block(blk, x):
     return rb(_bn(_conv(y, blk.conv3), blk.bn3, skip))
 
 
+def _dwconv(x, conv):
+    """depthwise 3x3 of the shufflenet units: the kernel reads the fp32 master filter (csrc/depthwise.hip), only the activations are bf16"""
+    return rb(F.conv2d(x, conv.weight, None, conv.stride, conv.padding, 1, conv.groups))
+
+
+def _shuffle_branch(x, mods):
+    """conv / BatchNorm / ReLU chain of a unit; bf16 storage after every convolution and after every BatchNorm(+ReLU)"""
+    mods = list(mods)
+    for i, m in enumerate(mods):
+        if isinstance(m, nn.Conv2d):
+            x = _dwconv(x, m) if m.groups > 1 else _conv(x, m)
+        elif isinstance(m, nn.BatchNorm2d):
+            relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+            x = rb(_bn(x, m, None, relu))
+    return x
+
+
+def _shufflenet_forward(mods, x):
+    """children: Normalize, conv1 (conv, bn, relu), maxpool, stage2..4, conv5 (conv, bn, relu)[, 1x1 conv][, resize]"""
+    conv1, bn1 = mods[1][0], mods[1][1]
+    x = rb(F.conv2d(x, rf(conv1.weight), None, conv1.stride, conv1.padding))
+    x = rb(F.max_pool2d(_bn(x, bn1), 3, 2, 1))
+    for stage in mods[3:6]:
+        for u in stage:
+            if u.stride == 1:
+                x1, x2 = x.chunk(2, dim=1)
+                out = torch.cat((x1, _shuffle_branch(x2, u.branch2)), 1)
+            else:
+                out = torch.cat((_shuffle_branch(x, u.branch1), _shuffle_branch(x, u.branch2)), 1)
+            x = O.channel_shuffle(out, 2)
+    x = _shuffle_branch(x, mods[6])
+    return x, mods[7:]
+
+
 def encoder_forward(enc, img):
-    """``enc`` = oracle.build_encoder(hp) (children: Normalize, conv1, bn1, relu, maxpool, layer1..4[, 1x1 conv][, resize]);
-    img (B, 3, H, W) fp32 in [0, 1].  Returns the annotations (B, D, h, w) fp32."""
+    """``enc`` = oracle.build_encoder(hp) (children: Normalize, conv1, bn1, relu, maxpool, layer1..4[, 1x1 conv][, resize]; or the
+    shufflenet_v2 children); img (B, 3, H, W) fp32 in [0, 1].  Returns the annotations (B, D, h, w) fp32."""
     mods = list(enc.children())
+    if isinstance(mods[1], nn.Sequential):
+        norm = mods[0]
+        m = torch.as_tensor(norm.mean, dtype=torch.float32).view(1, -1, 1, 1); s = torch.as_tensor(norm.std, dtype=torch.float32).view(1, -1, 1, 1)
+        x, rest = _shufflenet_forward(mods, bf((img - m) / s))
+        for mod in rest:
+            if isinstance(mod, nn.Conv2d):
+                x = rg(F.conv2d(x, rf(mod.weight), None)) + mod.bias.view(1, -1, 1, 1)
+            else:
+                x = mod(x)
+        return x
     norm, conv1, bn1 = mods[0], mods[1], mods[2]
     m = torch.as_tensor(norm.mean, dtype=torch.float32).view(1, -1, 1, 1); s = torch.as_tensor(norm.std, dtype=torch.float32).view(1, -1, 1, 1)
     x = bf((img - m) / s)

@@ -123,6 +123,79 @@ class ResNetOracle(nn.Module):
         return self.fc(torch.flatten(self.avgpool(x), 1))
 
 
+# torchvision's ShuffleNetV2 (third party, absent from the reference tree like the ResNets): the reference's CLI default encoder_arch is
+# shufflenet_v2_x0_5 (train.py:43) and get_encoder keeps every child but the classifier (model.py:30-31).  Restated from the published
+# architecture (Ma et al. 2018, "ShuffleNet V2", fig. 3 c/d and table 5); pinned structurally by dev/encoder_summaries.txt:28-35
+# (features 1024 / 2048, 0.34 / 1.25 / 2.48 / 5.34 M parameters without the classifier).
+#: arch -> (units per stage, output channels of conv1, stage2, stage3, stage4, conv5)
+SHUFFLENET_TABLE = {
+    "shufflenet_v2_x0_5": ((4, 8, 4), (24, 48, 96, 192, 1024)),
+    "shufflenet_v2_x1_0": ((4, 8, 4), (24, 116, 232, 464, 1024)),
+    "shufflenet_v2_x1_5": ((4, 8, 4), (24, 176, 352, 704, 1024)),
+    "shufflenet_v2_x2_0": ((4, 8, 4), (24, 244, 488, 976, 2048)),
+}
+
+
+def channel_shuffle(x, groups):
+    """(B, g * n, H, W): channel j * n + i -> channel i * g + j (the transpose of the (g, n) channel grid)"""
+    B, Cc, H, W = x.shape
+    return x.view(B, groups, Cc // groups, H, W).transpose(1, 2).reshape(B, Cc, H, W)
+
+
+class _ShuffleUnit(nn.Module):
+    """One ShuffleNetV2 unit.  stride 1: the first half of the channels passes through, the second goes through 1x1 -> depthwise 3x3 -> 1x1;
+    stride 2: both branches see the whole input (the left one is depthwise 3x3 -> 1x1).  Then the halves are concatenated and shuffled."""
+
+    def __init__(self, inp, oup, stride):
+        super().__init__()
+        self.stride = stride
+        bfeat = oup // 2
+        assert stride != 1 or inp == bfeat << 1
+
+        def dw(c, s):
+            return nn.Conv2d(c, c, 3, s, 1, bias=False, groups=c)
+
+        if stride > 1:
+            self.branch1 = nn.Sequential(dw(inp, stride), nn.BatchNorm2d(inp), nn.Conv2d(inp, bfeat, 1, 1, 0, bias=False), nn.BatchNorm2d(bfeat),
+                                         nn.ReLU(inplace=True))
+        else:
+            self.branch1 = nn.Sequential()
+        self.branch2 = nn.Sequential(nn.Conv2d(inp if stride > 1 else bfeat, bfeat, 1, 1, 0, bias=False), nn.BatchNorm2d(bfeat), nn.ReLU(inplace=True),
+                                     dw(bfeat, stride), nn.BatchNorm2d(bfeat), nn.Conv2d(bfeat, bfeat, 1, 1, 0, bias=False), nn.BatchNorm2d(bfeat),
+                                     nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        if self.stride == 1:
+            x1, x2 = x.chunk(2, dim=1)
+            out = torch.cat((x1, self.branch2(x2)), dim=1)
+        else:
+            out = torch.cat((self.branch1(x), self.branch2(x)), dim=1)
+        return channel_shuffle(out, 2)
+
+
+class ShuffleNetOracle(nn.Module):
+    """Child order conv1, maxpool, stage2, stage3, stage4, conv5, fc so that the reference's ``list(m.children())[:-1]`` (model.py:31) keeps
+    the trunk.  Default PyTorch initialisation (the architecture defines none of its own)."""
+
+    def __init__(self, arch, num_classes=1000):
+        super().__init__()
+        repeats, chans = SHUFFLENET_TABLE[arch]
+        self.conv1 = nn.Sequential(nn.Conv2d(3, chans[0], 3, 2, 1, bias=False), nn.BatchNorm2d(chans[0]), nn.ReLU(inplace=True))
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        cin = chans[0]
+        for name, rep, cout in zip(("stage2", "stage3", "stage4"), repeats, chans[1:4]):
+            units = [_ShuffleUnit(cin, cout, 2)] + [_ShuffleUnit(cout, cout, 1) for _ in range(rep - 1)]
+            setattr(self, name, nn.Sequential(*units))
+            cin = cout
+        self.conv5 = nn.Sequential(nn.Conv2d(cin, chans[4], 1, 1, 0, bias=False), nn.BatchNorm2d(chans[4]), nn.ReLU(inplace=True))
+        self.fc = nn.Linear(chans[4], num_classes)
+        self.feature_dim = chans[4]
+
+    def forward(self, x):
+        x = self.conv5(self.stage4(self.stage3(self.stage2(self.maxpool(self.conv1(x))))))
+        return self.fc(x.mean([2, 3]))
+
+
 class NormalizeInplace(nn.Module):
     """torchvision.transforms.Normalize(mean, std, inplace=True) on a batch:
     ``x.sub_(mean).div_(std)`` (used at model.py:59; mutates its input, F9)."""
@@ -152,15 +225,19 @@ def resnet_factory(arch):
 
 
 def build_encoder(hp):
-    """Restates get_encoder (model.py:16-63) for the resnet family, plus the
+    """Restates get_encoder (model.py:16-63) for the resnet and shufflenet_v2 families, plus the
     ``encoder_size`` resize the README documents (readme.md:118-121, F2).
 
     Returns nn.Sequential whose state-dict keys equal the reference's
     (``1.weight`` conv1, ``2.*`` bn1, ``5..8`` layer1..4, ``9.*`` 1x1 proj)."""
-    if hp.encoder_arch not in RESNET_TABLE:
+    if hp.encoder_arch in SHUFFLENET_TABLE:          # model.py:30-31 (keys: 1.* conv1, 3..5 stage2..4, 6.* conv5, 7.* 1x1 projection)
+        net = ShuffleNetOracle(hp.encoder_arch)
+        trunk = [net.conv1, net.maxpool, net.stage2, net.stage3, net.stage4, net.conv5]
+    elif hp.encoder_arch in RESNET_TABLE:
+        net = ResNetOracle(hp.encoder_arch)
+        trunk = [net.conv1, net.bn1, net.relu, net.maxpool, net.layer1, net.layer2, net.layer3, net.layer4]
+    else:
         raise ValueError("Encoder not supported : {}".format(hp.encoder_arch))
-    net = ResNetOracle(hp.encoder_arch)
-    trunk = [net.conv1, net.bn1, net.relu, net.maxpool, net.layer1, net.layer2, net.layer3, net.layer4]
     # model.py:46-48: a zero image is pushed through the (train-mode) trunk to read the
     # feature dim; as a side effect every BatchNorm's running stats see one batch.
     probe = nn.Sequential(*trunk)(torch.zeros(1, 3, hp.input_size, hp.input_size))
@@ -180,7 +257,7 @@ def build_encoder(hp):
 
 def trunk_param_count(arch):
     """Parameters of the trunk without fc (dev/encoder_summaries.txt:2-18)."""
-    net = ResNetOracle(arch)
+    net = ShuffleNetOracle(arch) if arch in SHUFFLENET_TABLE else ResNetOracle(arch)
     return sum(p.numel() for n, p in net.named_parameters() if not n.startswith("fc.")), net.feature_dim
 
 

@@ -271,6 +271,8 @@ def default_buckets(model):
     """[decoder] + encoder stages in the order their gradients appear (projection+layer4, layer3, layer2, layer1+stem)."""
     named = list(model.named_parameters())
     dec = [p for k, p in named if not k.startswith("encoder.")]
+    if getattr(getattr(model, "encoder", None), "single_bucket", False):          # shufflenet_v2: 0.3 - 2.5 M parameters, one exchange
+        return [dec, [p for k, p in named if k.startswith("encoder.")]]
     groups = {"a": [], "b": [], "c": [], "d": []}
     for k, p in named:
         if not k.startswith("encoder."):

@@ -687,6 +687,86 @@ def _krsc_dest(param):
     return dst, dst.permute(0, 3, 1, 2)
 
 
+def _weight_reader(bf):
+    """Wt(p): the tensor the kernels read for filter parameter p (its bf16 copy in bf16 mode), remembered for one forward / backward pair"""
+    if not bf:
+        return lambda p: p
+    wcopy = {}
+
+    def Wt(p):
+        c = wcopy.get(p)
+        if c is None:
+            # the copy lives on the parameter: FusedOptimizer rewrites it in its update kernel, so a training loop casts
+            # each filter once; any other in-place change of p bumps p._version and the copy is remade here
+            c = getattr(p, "_sat_bf16_shadow", None)
+            if c is None or getattr(p, "_sat_shadow_version", -1) != p._version or c.device != p.device:
+                c = cast_bf16(p)
+                p._sat_bf16_shadow, p._sat_shadow_version = c, p._version
+            wcopy[p] = c
+        return c
+    return Wt
+
+
+def _head_fwd(enc, x, t, Wt, bf):
+    """what follows the trunk: the optional 1x1 projection to ``encoder_dim`` (model.py:53) and the optional ``encoder_size`` resize; x NHWC"""
+    lib = L.lib()
+    st = L.stream_ptr()
+    t["trunk"] = x
+    if enc.proj is not None:
+        Nn, Hh, Ww, Cc = x.shape
+        D = enc.proj.out_channels
+        if bf:        # 1x1 projection: bf16 x bf16 -> fp32 annotations (+bias) on the bf16 MFMA kernel
+            from .decoder import gemm
+            y = torch.empty(Nn, Hh, Ww, D, dtype=torch.float32, device=x.device)
+            gemm(x.view(-1, Cc), Wt(enc.proj.weight).view(D, Cc), out=y.view(-1, D), bias=enc.proj.bias, epi=1, bf16_mfma=True)
+            x = y
+        else:
+            x = conv_fwd(x, enc.proj.weight, 1, 0, enc.proj.bias)
+    elif bf:          # no projection (encoder_dim None or equal to the trunk width, model.py:56-57): the annotations are the trunk output as fp32
+        y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        L.check(lib.sat_cast_bf16_to_f32(L.ptr(x), L.ptr(y), x.numel(), st), "sat_cast_bf16_to_f32")
+        x = y
+    t["proj_out"] = x
+    if enc.out_size is not None and enc.out_size != x.shape[1]:
+        Nn, Hh, Ww, Cc = x.shape
+        y = torch.empty(Nn, enc.out_size, enc.out_size, Cc, dtype=torch.float32, device=x.device)
+        L.check(lib.sat_resize_fwd(L.ptr(x), L.ptr(y), Nn, Hh, Ww, Cc, enc.out_size, enc.out_size, st), "sat_resize_fwd")
+        x = y
+    return x
+
+
+def _head_bwd(enc, t, dann, grads, Wt, bf):
+    """gradient of ``_head_fwd``: fills the projection's gradients, returns the gradient of the trunk output (NHWC, the trunk's storage type) or
+    None when the trunk is frozen"""
+    lib = L.lib()
+    st = L.stream_ptr()
+    d = dann.permute(0, 2, 3, 1).contiguous()                                 # NHWC fp32 (no copy when it already is)
+    if enc.out_size is not None and enc.out_size != t["proj_out"].shape[1]:
+        Nn, Hh, Ww, Cc = t["proj_out"].shape
+        dx = torch.empty_like(t["proj_out"])
+        L.check(lib.sat_resize_bwd(L.ptr(d), L.ptr(dx), Nn, Hh, Ww, Cc, enc.out_size, enc.out_size, st), "sat_resize_bwd")
+        d = dx
+    if enc.proj is not None:
+        grads[enc.proj.bias] = colsum(d.reshape(-1, d.shape[-1]), out=L.grad_buffer(enc.proj.bias))
+        if bf:
+            from .decoder import gemm
+            D = enc.proj.out_channels; Cc = t["trunk"].shape[-1]
+            db = cast_bf16(d.reshape(-1, D))
+            dw = L.grad_buffer(enc.proj.weight)                                   # (D, Cc, 1, 1): D x Cc row-major underneath
+            gemm(db, t["trunk"].view(-1, Cc), amode=1, bmode=1, out=dw.view(D, Cc), slab=_slab(d.device, 128 << 20), bf16_mfma=True)
+            grads[enc.proj.weight] = dw
+            if enc.trunk_trainable:
+                dtr = torch.empty(t["trunk"].shape, dtype=BF16, device=d.device)
+                gemm(db, Wt(enc.proj.weight).view(D, Cc), amode=0, bmode=1, out=dtr.view(-1, Cc), bf16_mfma=True)
+                d = dtr
+        else:
+            grads[enc.proj.weight] = conv_wgrad(d, t["trunk"], enc.proj.weight, 1, 0, param=enc.proj.weight)
+            d = conv_dgrad(d, enc.proj.weight, t["trunk"].shape, 1, 0) if enc.trunk_trainable else None
+    elif bf and enc.trunk_trainable:
+        d = cast_bf16(d.reshape(-1, d.shape[-1])).view(d.shape)
+    return d
+
+
 class EncoderFn(torch.autograd.Function):
     """img (B,3,H,W) fp32 in [0,1] -> annotations (B,D,h,w) fp32 (NHWC memory).  ``enc.precision``:
     "fp32" = fp32 activations on the exact fp32 MFMA kernel (parity mode); "bf16" = bf16 activations and
@@ -713,21 +793,7 @@ class EncoderFn(torch.autograd.Function):
         N, _, H, W = img.shape
         st = L.stream_ptr()
         t = {}
-        wcopy = {}
-
-        def Wt(p):                       # the tensor the kernels read for filter parameter p (bf16 copy in bf16 mode)
-            if not bf:
-                return p
-            c = wcopy.get(p)
-            if c is None:
-                # the copy lives on the parameter: FusedOptimizer rewrites it in its update kernel, so a training loop casts
-                # each filter once; any other in-place change of p bumps p._version and the copy is remade here
-                c = getattr(p, "_sat_bf16_shadow", None)
-                if c is None or getattr(p, "_sat_shadow_version", -1) != p._version or c.device != p.device:
-                    c = cast_bf16(p)
-                    p._sat_bf16_shadow, p._sat_shadow_version = c, p._version
-                wcopy[p] = c
-            return c
+        Wt = _weight_reader(bf)
 
         mean = (C.c_float * 3)(*enc[0].mean); std = (C.c_float * 3)(*enc[0].std)
         conv1 = enc[1]
@@ -783,25 +849,7 @@ class EncoderFn(torch.autograd.Function):
                 for blk in enc[li]:
                     r = _block_fwd(blk, x, training, Wt)
                     recs.append(r); x = r.out
-        t["trunk"] = x
-        if enc.proj is not None:
-            Nn, Hh, Ww, Cc = x.shape
-            D = enc.proj.out_channels
-            if bf:        # 1x1 projection: bf16 x bf16 -> fp32 annotations (+bias) on the bf16 MFMA kernel
-                from .decoder import gemm
-                y = torch.empty(Nn, Hh, Ww, D, dtype=torch.float32, device=img.device)
-                gemm(x.view(-1, Cc), Wt(enc.proj.weight).view(D, Cc), out=y.view(-1, D), bias=enc.proj.bias, epi=1, bf16_mfma=True)
-                x = y
-            else:
-                x = conv_fwd(x, enc.proj.weight, 1, 0, enc.proj.bias)
-        elif bf:
-            raise NotImplementedError("bf16 encoder without the 1x1 projection (encoder_dim == trunk width) is not built")
-        t["proj_out"] = x
-        if enc.out_size is not None and enc.out_size != x.shape[1]:
-            Nn, Hh, Ww, Cc = x.shape
-            y = torch.empty(Nn, enc.out_size, enc.out_size, Cc, dtype=torch.float32, device=img.device)
-            L.check(lib.sat_resize_fwd(L.ptr(x), L.ptr(y), Nn, Hh, Ww, Cc, enc.out_size, enc.out_size, st), "sat_resize_fwd")
-            x = y
+        x = _head_fwd(enc, x, t, Wt, bf)
         _defer[0] = False
         if _tracked:
             torch._foreach_add_(_tracked, 1)
@@ -817,28 +865,7 @@ class EncoderFn(torch.autograd.Function):
         st = L.stream_ptr()
         grads = {}
         cb = getattr(enc, "grad_ready", None)          # optional hook: called with {param: grad} as stages finish
-        d = dann.permute(0, 2, 3, 1).contiguous()                                 # NHWC fp32 (no copy when it already is)
-        if enc.out_size is not None and enc.out_size != t["proj_out"].shape[1]:
-            Nn, Hh, Ww, Cc = t["proj_out"].shape
-            dx = torch.empty_like(t["proj_out"])
-            L.check(lib.sat_resize_bwd(L.ptr(d), L.ptr(dx), Nn, Hh, Ww, Cc, enc.out_size, enc.out_size, st), "sat_resize_bwd")
-            d = dx
-        if enc.proj is not None:
-            grads[enc.proj.bias] = colsum(d.reshape(-1, d.shape[-1]), out=L.grad_buffer(enc.proj.bias))
-            if bf:
-                from .decoder import gemm
-                D = enc.proj.out_channels; Cc = t["trunk"].shape[-1]
-                db = cast_bf16(d.reshape(-1, D))
-                dw = L.grad_buffer(enc.proj.weight)                                   # (D, Cc, 1, 1): D x Cc row-major underneath
-                gemm(db, t["trunk"].view(-1, Cc), amode=1, bmode=1, out=dw.view(D, Cc), slab=_slab(d.device, 128 << 20), bf16_mfma=True)
-                grads[enc.proj.weight] = dw
-                if enc.trunk_trainable:
-                    dtr = torch.empty(t["trunk"].shape, dtype=BF16, device=d.device)
-                    gemm(db, Wt(enc.proj.weight).view(D, Cc), amode=0, bmode=1, out=dtr.view(-1, Cc), bf16_mfma=True)
-                    d = dtr
-            else:
-                grads[enc.proj.weight] = conv_wgrad(d, t["trunk"], enc.proj.weight, 1, 0, param=enc.proj.weight)
-                d = conv_dgrad(d, enc.proj.weight, t["trunk"].shape, 1, 0) if enc.trunk_trainable else None
+        d = _head_bwd(enc, t, dann, grads, Wt, bf)
         if enc.trunk_trainable:
             n_per_stage = [len(enc[li]) for li in (5, 6, 7, 8)]
             bounds, acc = [], 0
@@ -917,6 +944,8 @@ class EncoderFn(torch.autograd.Function):
 
 
 class HipEncoder(nn.Sequential):
+    Fn = EncoderFn
+
     def __init__(self, norm, conv1, bn1, layers, proj, out_size):
         mods = [norm, conv1, bn1, nn.ReLU(inplace=True), nn.MaxPool2d(3, 2, 1), *layers]
         if proj is not None:
@@ -1002,9 +1031,13 @@ def _probe_zero_image(conv1, bn1, layers, size):
 
 
 def get_encoder(args):
-    """Reference get_encoder (model.py:16-63) for resnet / wide_resnet archs; adds the README's
+    """Reference get_encoder (model.py:16-63) for the resnet / wide_resnet / resnext archs and shufflenet_v2 (``encoder_shuffle.py``); adds the README's
     ``encoder_size`` resize (readme.md:118-121) when ``args.encoder_size`` is set."""
     arch = args.encoder_arch
+    if arch.startswith("shufflenet_v2"):          # model.py:30-31 (the CLI default, train.py:43)
+        from . import encoder_shuffle
+        if arch in encoder_shuffle.SHUFFLENETS:
+            return encoder_shuffle.get_shuffle_encoder(args)
     if arch not in RESNETS:
         raise ValueError("Encoder not supported : {}".format(arch))
     ckpt = _pretrained_file(arch, getattr(args, "pretrained", False))

@@ -131,7 +131,7 @@ class GraphedTrainStep:
             enc_params = list(enc.parameters())
             ectx = _Ctx()
             try:
-                ann = E.EncoderFn._forward(ectx, img, enc, *enc_params)                 # (B, D, h, w) view over NHWC memory
+                ann = enc.Fn._forward(ectx, img, enc, *enc_params)                 # (B, D, h, w) view over NHWC memory
             finally:
                 E._defer[0] = False
             Bn, D, h, w = ann.shape
@@ -169,7 +169,7 @@ class GraphedTrainStep:
             for p, g in zip(dec_params, douts[10:]):
                 give(p, g)
             if any(p.requires_grad for p in enc_params):
-                eouts = E.EncoderFn.backward(ectx, dann.reshape(Bn, h, w, D).permute(0, 3, 1, 2))
+                eouts = enc.Fn.backward(ectx, dann.reshape(Bn, h, w, D).permute(0, 3, 1, 2))
                 for p, g in zip(enc_params, eouts[2:]):
                     give(p, g)
             for p, g in grads.values():
