@@ -272,3 +272,112 @@ def test_unsupported_widths_are_refused(S):
     for arch in ("shufflenet_v2_x1_0", "shufflenet_v2_x2_0"):
         with pytest.raises(ValueError, match="Encoder not supported"):
             E.get_encoder(O.default_hparams(encoder_arch=arch, encoder_dim=None, input_size=224))
+
+
+# ----------------------------------------------------------------------------- the whole train step behind the reference's SAT surface
+def _make_model(over=None, seed=42):
+    import sat_amd  # noqa: F401
+    from sat_amd import model as M
+    from oracle import sat_oracle as O
+    kw = dict(encoder_arch="shufflenet_v2_x0_5", encoder_dim=None, input_size=64, encoder_size=None, vocab_size=120, embed_dim=24,
+              attention_dim=16, decoder_dim=40, deep_output=True, weight_decay=0.0, decoder_lr=1e-3, embedding_lr=1e-2,
+              encoder_lr=1e-4, opt="adam", adam_b1=0.9, adam_b2=0.999, momentum=0.9, nesterov=False, scheduler=None)
+    kw.update(over or {})
+    hp = O.default_hparams(**kw)
+    torch.manual_seed(seed)
+    model = M.SAT(**vars(hp))
+    oracle = O.OracleSAT(O.default_hparams(**kw), {k: v.clone() for k, v in model.state_dict().items()})
+    return model.cuda().train(), oracle, hp
+
+
+def _batch(hp, B=6, R=3, T=9, seed=5):
+    from oracle import prng
+    img = torch.from_numpy(prng.uniform((B, 3, hp.input_size, hp.input_size), seed, 0.0, 1.0))
+    caps, lengths = prng.captions(B, R, T, hp.vocab_size, seed + 1)
+    return img, torch.from_numpy(caps), torch.from_numpy(lengths)
+
+
+@pytest.mark.parametrize("eps,D", [(1.0, None), (0.0, 32)])
+def test_training_step_with_the_cli_default_encoder_matches_oracle(eps, D):
+    """SAT(encoder_arch="shufflenet_v2_x0_5") - the reference's defaults (train.py:43, :50: no projection, encoder_dim = 1024) and the
+    projected variant - one training_step against the CPU oracle: loss, accuracy, packed logits, attention maps, every gradient."""
+    model, oracle, hp = _make_model(dict(encoder_dim=D, decoder_tf="always" if eps == 1.0 else None))
+    assert model.hp.encoder_dim == (1024 if D is None else D)
+    img, caps, lengths = _batch(hp)
+    loss_o, out_o = oracle.step_loss(img, caps, lengths, eps)
+    loss_o.backward()
+    img_g = img.cuda()
+    metrics = model.training_step((img_g, caps.cuda(), lengths), 0)
+    assert torch.equal(img_g.cpu(), img)
+    assert abs(metrics["loss"].item() - loss_o.item()) <= 1e-4 * max(1.0, abs(loss_o.item()))
+    assert abs(float(metrics["accuracy"]) - float(out_o["acc"])) < 1e-6
+    lp, tp, alphas = model.train_batch((img_g, caps.cuda(), lengths), eps)
+    rel = lambda a, b: float((a.detach().cpu().double() - b.detach().double()).abs().max()) / max(1.0, float(b.detach().double().abs().max()))   # noqa: E731
+    assert rel(lp.data, out_o["logits_packed"]) <= 2e-4 and rel(alphas, out_o["alphas"]) <= 1e-4
+    metrics["loss"].backward()
+    og = oracle.named_grads()
+    worst = (0.0, "")
+    for k, p in model.named_parameters():
+        assert p.grad is not None, k
+        ref = og[k].double()
+        nrm = float(og[k[:-4] + "weight"].double().norm()) if _zero_gradient_bias(k) else float(ref.norm())
+        e = float((p.grad.cpu().double() - ref).norm()) / max(1e-9, nrm)
+        worst = max(worst, (e, k))
+        assert e <= 2e-2, "%s: relative L2 gradient error %.3e" % (k, e)        # fp32 through a batch-6 net that ends in a 2 x 2 map
+    print("worst gradient error", worst)
+
+
+def test_replayed_step_with_the_shufflenet_encoder_is_bit_equal_to_the_eager_step():
+    """sat_amd/graph.py with the shufflenet encoder in bf16 mode: the step replayed from a hipGraph leaves the same loss, parameters, BatchNorm
+    buffers and optimizer moments as the eager loop, bit for bit (see tests/test_gpu_graph.py)."""
+    from sat_amd.graph import GraphedTrainStep
+    over = dict(decoder_tf="always", lr_warmup_steps=3)
+    eager, _, hp = _make_model(over)
+    graphed, _, _ = _make_model(over)
+    eager.set_precision("bf16"); graphed.set_precision("bf16")
+    eager.configure_optimizers(); graphed.configure_optimizers()
+    opt_e, opt_g = eager._train_optimizer(), graphed._train_optimizer()
+    step = GraphedTrainStep(graphed, opt_g)
+    batches = []
+    for seed in (11, 23):
+        img, caps, lengths = _batch(hp, B=4, seed=seed)
+        batches.append((img.cuda(), caps.cuda(), lengths))
+    for it in range(7):
+        b = batches[it % 2]
+        opt_e.zero_grad(set_to_none=True)
+        out_e = eager.training_step(b, it)
+        out_e["loss"].backward()
+        opt_e.step()
+        out_g = step(b, it)
+        assert torch.equal(out_e["loss"].detach(), out_g["loss"]), "step %d: loss %r vs %r" % (it, float(out_e["loss"]), float(out_g["loss"]))
+        for (k, x), (_, y) in zip(eager.state_dict().items(), graphed.state_dict().items()):
+            assert torch.equal(x, y), "step %d: %s differs" % (it, k)
+    assert step.stats["captured"] >= 2 and step.stats["replayed"] >= 3, dict(step.stats)
+
+
+def test_cli_default_configuration_trains():
+    """The reference's own defaults end to end (train.py:43-63, :75: shufflenet_v2_x0_5 at 224 px, no projection, embed 256, attention 128,
+    decoder 512, decoder_tf None = always sample, Adam) with a batch of 16 images x 5 captions, bf16 storage (--precision 16): the loss is
+    finite and falls over 12 steps on one repeated batch."""
+    import sat_amd  # noqa: F401
+    from sat_amd import model as M
+    from oracle import sat_oracle as O
+    hp = O.default_hparams(encoder_arch="shufflenet_v2_x0_5", encoder_dim=None, input_size=224, vocab_size=2000, embed_dim=256, attention_dim=128,
+                           decoder_dim=512, decoder_tf=None, opt="adam", encoder_lr=1e-5, decoder_lr=1e-3, embedding_lr=1e-2, precision=16, weight_decay=0.0,
+                           adam_b1=0.9, adam_b2=0.999, momentum=0.9, nesterov=False, scheduler=None)
+    torch.manual_seed(0)
+    model = M.SAT(**vars(hp)).cuda().train()
+    assert model.sat_precision == "bf16" and model.hp.encoder_dim == 1024
+    model.configure_optimizers()
+    opt = model._train_optimizer()
+    img, caps, lengths = _batch(hp, B=16, R=5, T=18, seed=3)
+    b = (img.cuda(), caps.cuda(), lengths)
+    losses = []
+    for it in range(12):
+        opt.zero_grad(set_to_none=True)
+        out = model.training_step(b, it)
+        out["loss"].backward()
+        opt.step()
+        losses.append(float(out["loss"].detach()))
+    assert all(l == l and abs(l) < 1e4 for l in losses), losses
+    assert losses[-1] < losses[0], losses

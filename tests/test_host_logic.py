@@ -136,6 +136,38 @@ def test_pretrained_encoder_loads_a_local_torchvision_checkpoint_and_freezes_the
     assert not enc.trunk_trainable
 
 
+def test_pretrained_shufflenet_loads_a_local_checkpoint_and_probes_like_the_reference(tmp_path):
+    """the same for the CLI's default arch (train.py:43, model.py:30-31): torchvision keys conv1 / stage2-4 / conv5, classifier dropped"""
+    from types import SimpleNamespace
+    from oracle import sat_oracle as O
+    from sat_amd import encoder as E
+    torch.manual_seed(11)
+    net = O.ShuffleNetOracle("shufflenet_v2_x0_5")
+    with torch.no_grad():
+        for mod in net.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.uniform_(0.5, 1.5); mod.bias.uniform_(-0.3, 0.3); mod.running_mean.uniform_(-0.2, 0.2); mod.running_var.uniform_(0.5, 2.0)
+    path = os.path.join(str(tmp_path), "shufflenetv2_x0.5-f707e7126e.pth")
+    torch.save(net.state_dict(), path)
+    args = SimpleNamespace(encoder_arch="shufflenet_v2_x0_5", input_size=64, encoder_dim=48, encoder_size=None, mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225],
+                           pretrained=path)
+    enc = E.get_encoder(args)
+    trunk = torch.nn.Sequential(net.conv1, net.maxpool, net.stage2, net.stage3, net.stage4, net.conv5).train()
+    want = {k: v.clone() for k, v in net.state_dict().items() if not k.startswith("fc.")}
+    trunk(torch.zeros(1, 3, 64, 64))
+    index = {"conv1": "1", "stage2": "3", "stage3": "4", "stage4": "5", "conv5": "6"}
+    got = enc.state_dict()
+    moved = 0
+    for k, v in net.state_dict().items():
+        if k.startswith("fc."):
+            continue
+        head, _, rest = k.partition(".")
+        assert torch.allclose(got[index[head] + "." + rest].float(), v.float(), rtol=1e-5, atol=1e-6), k
+        moved += int(("running" in k) and not torch.equal(v, want[k]))
+    assert moved > 60
+    assert [n for n, p in enc.named_parameters() if p.requires_grad] == ["7.weight", "7.bias"] and not enc.trunk_trainable
+
+
 def test_pretrained_without_a_local_file_says_so(tmp_path, monkeypatch):
     from types import SimpleNamespace
     from sat_amd import encoder as E

@@ -208,6 +208,36 @@ def test_resnext_structure_matches_the_reference_summary():
     assert trunk == n
 
 
+def test_shufflenet_structure_matches_the_reference_summary():
+    """dev/encoder_summaries.txt:28-35: shufflenet_v2_x0_5 / x1_0 / x1_5 / x2_0 = 0.34 / 1.25 / 2.48 / 5.34 M parameters without the classifier and
+    1024 / 1024 / 1024 / 2048 features; the x0_5 trunk (the reference CLI's default arch, train.py:43) maps 224 px to a 7 x 7 grid."""
+    expect = {"shufflenet_v2_x0_5": (0.34, 1024), "shufflenet_v2_x1_0": (1.25, 1024), "shufflenet_v2_x1_5": (2.48, 1024), "shufflenet_v2_x2_0": (5.34, 2048)}
+    for arch, (mparams, feat) in expect.items():
+        n, f = O.trunk_param_count(arch)
+        assert round(n / 1e6, 2) == mparams and f == feat, arch
+    hp = O.default_hparams(encoder_arch="shufflenet_v2_x0_5", encoder_dim=None, input_size=224)
+    torch.manual_seed(5)
+    ref = O.build_encoder(hp)
+    assert hp.encoder_dim == 1024                                              # model.py:56-57 stores the trunk width back
+    assert ref(torch.rand(2, 3, 224, 224)).shape == (2, 1024, 7, 7)
+    keys = list(ref.state_dict().keys())
+    assert keys[0] == "1.0.weight" and "3.0.branch1.0.weight" in keys and "5.3.branch2.6.bias" in keys and "6.1.running_var" in keys
+    # channel_shuffle(groups = 2) interleaves the two halves
+    x = torch.arange(8.0).view(1, 8, 1, 1)
+    assert O.channel_shuffle(x, 2).flatten().tolist() == [0, 4, 1, 5, 2, 6, 3, 7]
+    import sat_amd  # noqa: F401
+    from sat_amd import encoder as E
+    torch.manual_seed(5)
+    hp2 = O.default_hparams(encoder_arch="shufflenet_v2_x0_5", encoder_dim=None, input_size=224)
+    enc = E.get_encoder(hp2)
+    assert hp2.encoder_dim == 1024 and keys == list(enc.state_dict().keys())
+    assert all(torch.equal(v, ref.state_dict()[k]) for k, v in enc.state_dict().items() if "running" not in k and "num_batches" not in k)
+    assert all(bool(((v - 0.9).abs() < 1e-6).all()) for k, v in enc.state_dict().items() if "running_var" in k)      # the zero-image probe
+    for arch in ("shufflenet_v2_x1_0", "shufflenet_v2_x2_0"):                   # 58- / 122-channel branches: refused, not approximated
+        with pytest.raises(ValueError, match="Encoder not supported"):
+            E.get_encoder(O.default_hparams(encoder_arch=arch, encoder_dim=None, input_size=224))
+
+
 def test_fixtures_are_small(golden_dir):
     total = sum(os.path.getsize(p) for p in glob.glob(os.path.join(golden_dir, "*.npz")))
     assert total < 4 << 20
