@@ -30,6 +30,9 @@ CONFIGS = {
     "c1": ("resnet18", 7, 256, 6400, 22, 8),
     "c3": ("resnet101", 14, 512, 6400, 22, 32),
     "c4": ("wide_resnet101_2", 14, 1024, 10000, 32, 64),
+    # not a BASELINE configuration: the reference CLI's own defaults (train.py:43-63: shufflenet_v2_x0_5 at 224 px, no projection / resize, plain
+    # output layer, decoder_tf None) at the batch its encoder table was measured with (dev/encoder_summaries.txt:28: 32 images) - a sub-line only
+    "cli": ("shufflenet_v2_x0_5", None, None, 6400, 22, 32, 224),
 }
 #: images per step of the whole job as BASELINE.json states them (--strong splits these over the ranks)
 GLOBAL_BATCH = {"c1": 8, "c2": 128, "c3": 256, "c4": 512}
@@ -43,9 +46,9 @@ PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r03_bf16_bench_c2_pmc_
 
 
 def hparams(cfg, R=5):
-    arch, es, D, V, T, B = CONFIGS[cfg]
+    arch, es, D, V, T, B = CONFIGS[cfg][:6]
     stoi = {"<PAD>": 0, "<UNK>": V - 3, "<START>": V - 2, "<END>": V - 1}
-    return dict(encoder_arch=arch, pretrained=False, input_size=256, encoder_dim=D, encoder_size=es,
+    return dict(encoder_arch=arch, pretrained=False, input_size=CONFIGS[cfg][6] if len(CONFIGS[cfg]) > 6 else 256, encoder_dim=D, encoder_size=es,
                 mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225], embed_dim=256, embed_norm=None, attention_dim=128,
                 decoder_dim=512, decoder_layers=1, dropout=0.0, embedding_dropout=0.0, label_smoothing=0.0, weight_tying=False,
                 deep_output=True, att_gamma=1.0, vocab_size=V, vocab_stoi=stoi, vocab_itos={v: k for k, v in stoi.items()},
@@ -54,11 +57,11 @@ def hparams(cfg, R=5):
                 momentum=0.9, nesterov=False, scheduler=None, lr_warmup_steps=0), T, B, R
 
 
-def synthetic_batch(B, R, T, V, seed, ragged):
+def synthetic_batch(B, R, T, V, seed, ragged, px=256):
     """img ~ U[0,1); captions [START] + U{1..V-4} + [END] + PAD; lengths all T-1 (headline) or U{8..T-1}."""
     import torch
     g = torch.Generator().manual_seed(seed)
-    img = torch.rand(B, 3, 256, 256, generator=g)
+    img = torch.rand(B, 3, px, px, generator=g)
     lengths = torch.randint(8, T, (B, R), generator=g) if ragged else torch.full((B, R), T - 1, dtype=torch.int64)
     caps = torch.zeros(B, R, T, dtype=torch.int64)
     toks = torch.randint(1, V - 3, (B, R, T), generator=g)
@@ -150,6 +153,8 @@ def _build_train(cfg, dev, precision="bf16", decoder_tf="always", batch=None, ra
         B = batch
     if decoder_tf == "none":
         hp["decoder_tf"] = None
+    if cfg == "cli":
+        hp["deep_output"] = False          # train.py:160
     torch.manual_seed(42)
     model = M.SAT(**hp).to(dev).train()
     model.set_precision(precision)
@@ -157,7 +162,8 @@ def _build_train(cfg, dev, precision="bf16", decoder_tf="always", batch=None, ra
     model.__dict__["_sat_global_step"] = 2          # past encoder_finetune_after: the encoder trains (and is in the optimizer)
     opt = model.configure_optimizers()
     sync = GradSync(model)
-    img, caps, lengths = synthetic_batch(B, R, T, hp["vocab_size"], 1234 + rank, ragged)
+    img, caps, lengths = synthetic_batch(B, R, T, hp["vocab_size"], 1234 + rank, ragged, px=hp["input_size"])
+    hp["encoder_dim"] = model.hp.encoder_dim
     return model, opt, sync, (img.to(dev), caps.to(dev), lengths), (hp, T, B, R)
 
 
@@ -184,8 +190,8 @@ def sub_line_train(cfg, dev, steps=5, warmup=5, decoder_tf="always", attention=F
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    out = {"workload": "%s: %s encoder_size=%s encoder_dim=%d vocab=%d T=%d, %d images x R=%d captions on this GPU, decoder_tf=%s" % (
-               cfg.upper(), CONFIGS[cfg][0], CONFIGS[cfg][1], CONFIGS[cfg][2], hp["vocab_size"], T, B, R, decoder_tf),
+    out = {"workload": "%s: %s at %d px encoder_size=%s encoder_dim=%d vocab=%d T=%d, %d images x R=%d captions on this GPU, decoder_tf=%s" % (
+               cfg.upper(), CONFIGS[cfg][0], hp["input_size"], CONFIGS[cfg][1], hp["encoder_dim"], hp["vocab_size"], T, B, R, decoder_tf),
            "ms_per_step": round(dt * 1e3, 3), "value": round(B * R / dt, 1), "unit": "captions/s", "steps": steps, "warmup": n, "dtype": "bf16"}
     if attention:
         _lib.profile_start(only="attention*")
@@ -291,7 +297,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default="c2", choices=sorted(c for c in CONFIGS if c != "cli"))
     ap.add_argument("--ragged", action="store_true", help="lengths ~ U{8..T-1} instead of all T-1")
     ap.add_argument("--decoder-tf", default="always", choices=["always", "none"],
                     help="teacher forcing: always (epsilon = 1, the headline) or none (train.py:63 default: argmax feedback after step 2)")
@@ -590,6 +596,8 @@ def main():
             log("C2 decoder_tf=None: %.1f ms/step" % subs["c2_decoder_tf_none"]["ms_per_step"])
             subs["c1"] = sub_line_train("c1", dev, steps=10, graph=True)
             log("C1: %.2f ms/step" % subs["c1"]["ms_per_step"])
+            subs["cli_defaults_shufflenet"] = sub_line_train("cli", dev, steps=10, decoder_tf="none", graph=True)
+            log("reference CLI defaults (shufflenet_v2_x0_5): %.2f ms/step" % subs["cli_defaults_shufflenet"]["ms_per_step"])
             subs["c3_shard"] = sub_line_train("c3", dev, graph=True)
             log("C3 shard: %.1f ms/step" % subs["c3_shard"]["ms_per_step"])
             subs["c4_shard"] = sub_line_train("c4", dev, attention=True)

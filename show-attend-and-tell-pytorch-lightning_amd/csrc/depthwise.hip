@@ -106,10 +106,16 @@ __global__ __launch_bounds__(256) void dw3x3_dgrad_kernel(const T* __restrict__ 
 }
 
 // dw[c][r][s] = sum over output pixels of dy * x(tap): block (channel vector group, pixel chunk) -> partial [chunk][9][C], then a fixed-order finish
-constexpr int DW_CHUNK = 2048;      // output pixels per block
+// output pixels per block: ~1024 blocks per launch (the maps of a 32-image batch have 1.5 k .. 100 k pixels: with a fixed 2048-pixel chunk the
+// stage-2 launch was 12 blocks on 256 CUs and took 185 us), at least 64 pixels, at most 2048
+static inline int dw_chunk(long npix) {
+    long c = (npix + 1023) / 1024;
+    c = (c + 63) / 64 * 64;
+    return (int)(c < 64 ? 64 : (c > 2048 ? 2048 : c));
+}
 template <typename T>
 __global__ __launch_bounds__(256) void dw3x3_wgrad_part_kernel(const T* __restrict__ dy, const T* __restrict__ x, float* __restrict__ part, int N, int H, int W, int C,
-                                                               int P, int Q, int stride) {
+                                                               int P, int Q, int stride, int chunk) {
     constexpr int V = Vec<T>::V;
     const int cv = C / V;
     // thread: channel vector tid % cv (all threads of a block walk different pixels of the chunk for their vector); blockDim is a multiple of cv's divisor
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_part_kernel(const T* __restri
 #pragma unroll
         for (int i = 0; i < V; ++i) acc[k][i] = 0.f;
     const long npix = (long)N * P * Q;
-    const long p0 = (long)blockIdx.x * DW_CHUNK, p1 = p0 + DW_CHUNK < npix ? p0 + DW_CHUNK : npix;
+    const long p0 = (long)blockIdx.x * chunk, p1 = p0 + chunk < npix ? p0 + chunk : npix;
     if (pl < pix_par) {
         for (long pix = p0 + pl; pix < p1; pix += pix_par) {
             const int q = (int)(pix % Q); long t = pix / Q; const int p = (int)(t % P); const int n = (int)(t / P);
@@ -161,13 +167,17 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_part_kernel(const T* __restri
         __syncthreads();
     }
 }
-__global__ void dw3x3_wgrad_finish_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ dw) {
-    const int o = blockIdx.x * blockDim.x + threadIdx.x;          // o = k * C + c in the partials; dw is [C][9]
-    if (o >= 9 * C) return;
+// one wave per filter element: lane l adds partials l, l + 64, ... (double), then a fixed-order butterfly
+__global__ __launch_bounds__(64) void dw3x3_wgrad_finish_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ dw) {
+    const int o = blockIdx.x;                                     // o = k * C + c in the partials; dw is [C][9]
     double s = 0.0;
-    for (int b = 0; b < nparts; ++b) s += (double)part[(long)b * 9 * C + o];
-    const int k = o / C, c = o - k * C;
-    dw[c * 9 + k] = (float)s;
+    for (int b = threadIdx.x; b < nparts; b += 64) s += (double)part[(long)b * 9 * C + o];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+    if (threadIdx.x == 0) {
+        const int k = o / C, c = o - k * C;
+        dw[c * 9 + k] = (float)s;
+    }
 }
 
 // channel_shuffle(cat(a, b), 2): full[row][c] = (c odd ? b : a)[row][c / 2]; halves: x1 = full[:, :Ch], x2 = full[:, Ch:]
@@ -237,7 +247,7 @@ int sat_dwconv3x3_dgrad_t(int32_t dtype, const void* dy, const float* w, void* d
 size_t sat_dwconv3x3_wgrad_scratch_bytes(int32_t N, int32_t H, int32_t W, int32_t C, int32_t stride) {
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (stride != 1 && stride != 2)) return 0;
     const int P = (H + 2 - 3) / stride + 1, Q = (W + 2 - 3) / stride + 1;
-    return (size_t)cdiv((long)N * P * Q, (long)DW_CHUNK) * 9 * C * sizeof(float);
+    return (size_t)cdiv((long)N * P * Q, (long)dw_chunk((long)N * P * Q)) * 9 * C * sizeof(float);
 }
 
 int sat_dwconv3x3_wgrad_t(int32_t dtype, const void* dy, const void* x, float* dw, int32_t N, int32_t H, int32_t W, int32_t C, int32_t stride, float* scratch,
@@ -247,14 +257,15 @@ int sat_dwconv3x3_wgrad_t(int32_t dtype, const void* dy, const void* x, float* d
     const int V = dtype ? 8 : 4, cv = C / V;
     SAT_REQUIRE(cv <= 256, "dwconv3x3_wgrad: C=%d channels exceed %d", C, 256 * V);
     const int P = (H + 2 - 3) / stride + 1, Q = (W + 2 - 3) / stride + 1;
-    const int nparts = cdiv((long)N * P * Q, (long)DW_CHUNK);
+    const int chunk = dw_chunk((long)N * P * Q);
+    const int nparts = cdiv((long)N * P * Q, (long)chunk);
     const int pix_par = 256 / cv;
     const size_t lds = (size_t)pix_par * C * sizeof(float);
     SAT_REQUIRE(lds <= 64 * 1024, "dwconv3x3_wgrad: C=%d needs %zu bytes of LDS", C, lds);
-    if (dtype) hipLaunchKernelGGL(dw3x3_wgrad_part_kernel<bf>, dim3(nparts), dim3(256), lds, (hipStream_t)stream, (const bf*)dy, (const bf*)x, scratch, N, H, W, C, P, Q, stride);
-    else hipLaunchKernelGGL(dw3x3_wgrad_part_kernel<float>, dim3(nparts), dim3(256), lds, (hipStream_t)stream, (const float*)dy, (const float*)x, scratch, N, H, W, C, P, Q, stride);
+    if (dtype) hipLaunchKernelGGL(dw3x3_wgrad_part_kernel<bf>, dim3(nparts), dim3(256), lds, (hipStream_t)stream, (const bf*)dy, (const bf*)x, scratch, N, H, W, C, P, Q, stride, chunk);
+    else hipLaunchKernelGGL(dw3x3_wgrad_part_kernel<float>, dim3(nparts), dim3(256), lds, (hipStream_t)stream, (const float*)dy, (const float*)x, scratch, N, H, W, C, P, Q, stride, chunk);
     SAT_TRY(launch_ok("dwconv3x3_wgrad (partials)"));
-    hipLaunchKernelGGL(dw3x3_wgrad_finish_kernel, dim3(cdiv(9 * C, 256)), dim3(256), 0, (hipStream_t)stream, scratch, nparts, C, dw);
+    hipLaunchKernelGGL(dw3x3_wgrad_finish_kernel, dim3(9 * C), dim3(64), 0, (hipStream_t)stream, scratch, nparts, C, dw);
     return launch_ok("dwconv3x3_wgrad (finish)");
 }
 

@@ -1,5 +1,5 @@
 """Dev tool: one train step eager vs replayed from a hipGraph (sat_amd/graph.py): ms per step and host time to issue it.
-usage: CFG=c1|c2|c3|c4 python tools/graph_step_time.py"""
+usage: CFG=c1|c2|c3|c4|cli python tools/graph_step_time.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,14 +11,16 @@ from sat_amd.graph import GraphedTrainStep
 
 cfg = os.environ.get("CFG", "c2")
 hp, T, B, R = bench.hparams(cfg)
-if os.environ.get("TF") == "none":
+if os.environ.get("TF") == "none" or cfg == "cli":
     hp["decoder_tf"] = None
+if cfg == "cli":
+    hp["deep_output"] = False
 torch.manual_seed(42)
 model = M.SAT(**hp).cuda().train(); model.set_precision("bf16")
 model.__dict__["_sat_global_step"] = 2
 opt = model.configure_optimizers()
 sync = GradSync(model)
-img, caps, lengths = bench.synthetic_batch(B, R, T, hp["vocab_size"], 1234, False)
+img, caps, lengths = bench.synthetic_batch(B, R, T, hp["vocab_size"], 1234, False, px=hp["input_size"])
 img, caps = img.cuda(), caps.cuda()
 stepper = GraphedTrainStep(model, opt, sync=sync)
 
