@@ -57,6 +57,13 @@ class ShuffleUnit(nn.Module):
                                      dw(bfeat, stride), nn.BatchNorm2d(bfeat), nn.Conv2d(bfeat, bfeat, 1, 1, 0, bias=False), nn.BatchNorm2d(bfeat),
                                      nn.ReLU(inplace=True))
 
+    def branches(self):
+        """(branch1, branch2) as plain lists: ``nn.Sequential.__getitem__`` walks an OrderedDict per lookup (~440 lookups per x0_5 step)"""
+        b = self.__dict__.get("_branch_lists")
+        if b is None:
+            b = self.__dict__["_branch_lists"] = (list(self.branch1), list(self.branch2))
+        return b
+
 
 # ----------------------------------------------------------------------------- raw layer calls
 def _dw_weight(conv):
@@ -139,15 +146,14 @@ def _unit_fwd(u, xin, training, Wt, halves):
     """xin: the whole NHWC tensor (stride 2) or the pair of its channel halves (stride 1).  Returns (record, output as ``halves`` asks)."""
     conv = E.conv_fwd_stats if training else (lambda *a: (E.conv_fwd(*a), None))
     r = _URec(); r.u = u
+    b1, b2 = u.branches()
     if u.stride == 1:
         a, r.src = xin
     else:
         r.src = xin
-        b1 = u.branch1
         r.d1 = dw_fwd(xin, b1[0]); r.e1, r.sd1 = E.bn_fwd(r.d1, b1[1], None, False, training)
         r.c1, tl = conv(r.e1, Wt(b1[2].weight), 1, 0); r.a, r.sa = E.bn_fwd(r.c1, b1[3], None, True, training, want_mask=True, tiles=tl)
         a = r.a
-    b2 = u.branch2
     r.c2, tl = conv(r.src, Wt(b2[0].weight), 1, 0); r.a2, r.s2 = E.bn_fwd(r.c2, b2[1], None, True, training, want_mask=True, tiles=tl)
     r.d2 = dw_fwd(r.a2, b2[3]); r.e2, r.sd2 = E.bn_fwd(r.d2, b2[4], None, False, training)
     r.c3, tl = conv(r.e2, Wt(b2[5].weight), 1, 0); r.b, r.s3 = E.bn_fwd(r.c3, b2[6], None, True, training, want_mask=True, tiles=tl)
@@ -162,7 +168,7 @@ def _bn_g(grads, bn, res):
 def _unit_bwd(r, dout, grads, Wt, need_dx=True):
     """dout: gradient of the unit's output (whole, or its halves).  Returns the gradient of the unit's input in the form the input had."""
     u = r.u
-    b2 = u.branch2
+    b1, b2 = u.branches()
     da, db = shuffle_split(dout)
     dc3 = _bn_g(grads, b2[6], E.bn_bwd(db, r.c3, r.b, r.s3, b2[6], True))
     grads[b2[5].weight] = E.conv_wgrad(dc3, r.e2, b2[5].weight, 1, 0, param=b2[5].weight)
@@ -174,7 +180,6 @@ def _unit_bwd(r, dout, grads, Wt, need_dx=True):
     grads[b2[0].weight] = E.conv_wgrad(dc2, r.src, b2[0].weight, 1, 0, param=b2[0].weight)
     if u.stride == 1:
         return da, E.conv_dgrad(dc2, Wt(b2[0].weight), r.src.shape, 1, 0)
-    b1 = u.branch1
     dc1 = _bn_g(grads, b1[3], E.bn_bwd(da, r.c1, r.a, r.sa, b1[3], True))
     grads[b1[2].weight] = E.conv_wgrad(dc1, r.e1, b1[2].weight, 1, 0, param=b1[2].weight)
     de1, tl = E.conv_dgrad(dc1, Wt(b1[2].weight), r.e1.shape, 1, 0, bn=(r.d1, r.sd1))
@@ -212,7 +217,7 @@ class ShuffleEncoderFn(torch.autograd.Function):
         t = {}
         Wt = E._weight_reader(bf)
         mean = (C.c_float * 3)(*enc[0].mean); std = (C.c_float * 3)(*enc[0].std)
-        conv1, bn1 = enc[1][0], enc[1][1]
+        conv1, bn1, conv5, bn5, units = enc.layers()
         K = conv1.out_channels
         w3 = E._krsc(conv1.weight)                                                  # (K,3,3,3), memory K,3,3,3(c)
         cpad = 8 if bf else 4
@@ -234,13 +239,11 @@ class ShuffleEncoderFn(torch.autograd.Function):
             x = torch.empty(Nn, (Hh + 2 - 3) // 2 + 1, (Ww + 2 - 3) // 2 + 1, Cc, dtype=adt, device=img.device)
             amax = torch.empty(x.shape, dtype=torch.uint8, device=img.device)
             L.check(lib.sat_maxpool3x3s2_fwd_t(int(bf), L.ptr(a0), L.ptr(x), L.ptr(amax), Nn, Hh, Ww, Cc, st), "sat_maxpool3x3s2_fwd")
-        units = [u for li in (3, 4, 5) for u in enc[li]]
         recs = []
         for i, u in enumerate(units):
             halves = i + 1 < len(units) and units[i + 1].stride == 1
             r, x = _unit_fwd(u, x, training, Wt, halves)
             recs.append(r)
-        conv5, bn5 = enc[6][0], enc[6][1]
         t["x5"] = x
         t["c5"], tl = E.conv_fwd_stats(x, Wt(conv5.weight), 1, 0) if training else (E.conv_fwd(x, Wt(conv5.weight), 1, 0), None)
         t["a5"], t["s5"] = E.bn_fwd(t["c5"], bn5, None, True, training, want_mask=True, tiles=tl)
@@ -261,8 +264,7 @@ class ShuffleEncoderFn(torch.autograd.Function):
         grads = {}
         d = E._head_bwd(enc, t, dann, grads, Wt, bf)
         if enc.trunk_trainable:
-            conv1, bn1 = enc[1][0], enc[1][1]
-            conv5, bn5 = enc[6][0], enc[6][1]
+            conv1, bn1, conv5, bn5, _ = enc.layers()
             dc5 = _bn_g(grads, bn5, E.bn_bwd(d, t["c5"], t["a5"], t["s5"], bn5, True))
             grads[conv5.weight] = E.conv_wgrad(dc5, t["x5"], conv5.weight, 1, 0, param=conv5.weight)
             d = E.conv_dgrad(dc5, Wt(conv5.weight), t["x5"].shape, 1, 0)
@@ -297,6 +299,13 @@ class HipShuffleEncoder(nn.Sequential):
     @property
     def trunk_trainable(self):
         return any(p.requires_grad for p in self[1].parameters())
+
+    def layers(self):
+        """(conv1, bn1, conv5, bn5, [units of stage2..4]) looked up once"""
+        ls = self.__dict__.get("_layers")
+        if ls is None:
+            ls = self.__dict__["_layers"] = (self[1][0], self[1][1], self[6][0], self[6][1], [u for li in (3, 4, 5) for u in self[li]])
+        return ls
 
     def forward(self, img):
         params = self.__dict__.get("_plist")

@@ -207,3 +207,20 @@ def test_a_gradient_slice_is_handed_out_once_per_backward():
         for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
             assert torch.allclose(p.grad, q.grad, atol=1e-7, rtol=1e-6), k
     sync.remove()
+
+
+def test_shufflenet_encoder_is_one_bucket():
+    """the CLI's default encoder (0.34 M parameters) is exchanged as one bucket behind the decoder's; the ResNets keep one bucket per stage"""
+    import sat_amd  # noqa: F401
+    from oracle import sat_oracle as O
+    from sat_amd import model as M
+    from sat_amd.dist import default_buckets
+    kw = dict(input_size=64, vocab_size=50, embed_dim=16, attention_dim=8, decoder_dim=24, weight_decay=0.0, decoder_lr=1e-3, embedding_lr=1e-2,
+              encoder_lr=1e-4, opt="adam", adam_b1=0.9, adam_b2=0.999, momentum=0.9, nesterov=False, scheduler=None)
+    shuffle = M.SAT(**vars(O.default_hparams(encoder_arch="shufflenet_v2_x0_5", encoder_dim=None, **kw)))
+    buckets = default_buckets(shuffle)
+    assert len(buckets) == 2
+    assert sum(len(b) for b in buckets) == len(list(shuffle.parameters()))
+    assert {id(p) for p in buckets[1]} == {id(p) for p in shuffle.encoder.parameters()}
+    resnet = M.SAT(**vars(O.default_hparams(encoder_arch="resnet18", encoder_dim=32, **kw)))
+    assert len(default_buckets(resnet)) == 5

@@ -6,11 +6,13 @@ import bench
 import sat_amd  # noqa
 from sat_amd import model as M
 hp, T, B, R = bench.hparams(os.environ.get("CFG", "c2"))
+if os.environ.get("CFG") == "cli":
+    hp["decoder_tf"] = None; hp["deep_output"] = False
 torch.manual_seed(42)
 model = M.SAT(**hp).cuda().train(); model.set_precision("bf16")
 model.__dict__["_sat_global_step"] = 2
 opt = model.configure_optimizers()
-img, caps, lengths = bench.synthetic_batch(B, R, T, hp["vocab_size"], 1234, False)
+img, caps, lengths = bench.synthetic_batch(B, R, T, hp["vocab_size"], 1234, False, px=hp["input_size"])
 img, caps = img.cuda(), caps.cuda()
 def step():
     opt.zero_grad(set_to_none=True)
