@@ -97,16 +97,35 @@ def _dwconv(x, conv):
     return rb(F.conv2d(x, conv.weight, None, conv.stride, conv.padding, 1, conv.groups))
 
 
-def _shuffle_branch(x, mods):
-    """conv / BatchNorm / ReLU chain of a unit; bf16 storage after every convolution and after every BatchNorm(+ReLU)"""
-    mods = list(mods)
-    for i, m in enumerate(mods):
+def _shuffle_branch(x, mods, residual=None):
+    """conv / BatchNorm / ReLU | ReLU6 chain (nested Sequentials flattened); bf16 storage after every convolution and after every
+    BatchNorm(+ activation); ``residual`` is added inside the LAST BatchNorm's kernel (fp32, before the one rounding)"""
+    flat = []
+
+    def walk(ms):
+        for m in ms:
+            walk(m) if isinstance(m, nn.Sequential) else flat.append(m)
+    walk(mods)
+    last_bn = max(i for i, m in enumerate(flat) if isinstance(m, nn.BatchNorm2d))
+    for i, m in enumerate(flat):
         if isinstance(m, nn.Conv2d):
             x = _dwconv(x, m) if m.groups > 1 else _conv(x, m)
         elif isinstance(m, nn.BatchNorm2d):
-            relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
-            x = rb(_bn(x, m, None, relu))
+            act = flat[i + 1] if i + 1 < len(flat) else None
+            y = _bn(x, m, residual if i == last_bn else None, isinstance(act, nn.ReLU))
+            x = rb(torch.clamp(y, 0.0, 6.0) if isinstance(act, nn.ReLU6) else y)
     return x
+
+
+def _mobilenet_forward(mods, x):
+    """children: Normalize, features (stem ConvBNReLU6, inverted residuals, last 1x1 ConvBNReLU6)[, 1x1 conv][, resize]"""
+    feats = list(mods[1])
+    conv1, bn1 = feats[0][0], feats[0][1]
+    x = rb(F.conv2d(x, rf(conv1.weight), None, conv1.stride, conv1.padding))
+    x = rb(torch.clamp(_bn(x, bn1, None, False), 0.0, 6.0))
+    for blk in feats[1:-1]:
+        x = _shuffle_branch(x, blk.conv, residual=x if blk.use_res_connect else None)
+    return _shuffle_branch(x, feats[-1]), mods[2:]
 
 
 def _shufflenet_forward(mods, x):
@@ -133,7 +152,8 @@ def encoder_forward(enc, img):
     if isinstance(mods[1], nn.Sequential):
         norm = mods[0]
         m = torch.as_tensor(norm.mean, dtype=torch.float32).view(1, -1, 1, 1); s = torch.as_tensor(norm.std, dtype=torch.float32).view(1, -1, 1, 1)
-        x, rest = _shufflenet_forward(mods, bf((img - m) / s))
+        mobilenet = len(mods[1]) > 3                    # mobilenet_v2: one ``features`` child; shufflenet: conv1 (conv, bn, relu) first
+        x, rest = (_mobilenet_forward if mobilenet else _shufflenet_forward)(mods, bf((img - m) / s))
         for mod in rest:
             if isinstance(mod, nn.Conv2d):
                 x = rg(F.conv2d(x, rf(mod.weight), None)) + mod.bias.view(1, -1, 1, 1)

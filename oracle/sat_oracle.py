@@ -196,6 +196,61 @@ class ShuffleNetOracle(nn.Module):
         return self.fc(x.mean([2, 3]))
 
 
+# torchvision's MobileNetV2 (third party, absent from the reference tree): get_encoder keeps ``m.features`` (model.py:38-39 drops the classifier).
+# Restated from the published architecture (Sandler et al. 2018, table 2) with torchvision's module layout (ConvBNReLU = Sequential(conv, bn,
+# ReLU6); InvertedResidual.conv = [expand 1x1 ConvBNReLU unless t == 1, depthwise 3x3 ConvBNReLU, 1x1 Conv2d, BatchNorm2d]) and initialisers
+# (kaiming_normal fan_out, BatchNorm ones / zeros, Linear normal(0, 0.01)); pinned structurally by dev/encoder_summaries.txt:36-37 (1280
+# features, 2.22 M parameters without the classifier).
+MOBILENET_V2_SETTING = ((1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2), (6, 96, 3, 1), (6, 160, 3, 2), (6, 320, 1, 1))      # t, c, n, s
+
+
+def _conv_bn_relu6(cin, cout, k=3, stride=1, groups=1):
+    return nn.Sequential(nn.Conv2d(cin, cout, k, stride, (k - 1) // 2, groups=groups, bias=False), nn.BatchNorm2d(cout), nn.ReLU6(inplace=True))
+
+
+class _InvertedResidual(nn.Module):
+    def __init__(self, inp, oup, stride, expand_ratio):
+        super().__init__()
+        hidden = int(round(inp * expand_ratio))
+        self.stride = stride
+        self.use_res_connect = stride == 1 and inp == oup
+        layers = []
+        if expand_ratio != 1:
+            layers.append(_conv_bn_relu6(inp, hidden, k=1))
+        layers.extend([_conv_bn_relu6(hidden, hidden, stride=stride, groups=hidden), nn.Conv2d(hidden, oup, 1, 1, 0, bias=False), nn.BatchNorm2d(oup)])
+        self.conv = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return x + self.conv(x) if self.use_res_connect else self.conv(x)
+
+
+class MobileNetV2Oracle(nn.Module):
+    """Children: features, classifier - the reference's ``list(m.children())[:-1]`` (model.py:39) keeps ``features``."""
+
+    def __init__(self, num_classes=1000):
+        super().__init__()
+        cin, last = 32, 1280
+        feats = [_conv_bn_relu6(3, cin, stride=2)]
+        for t, c, n, s in MOBILENET_V2_SETTING:
+            for i in range(n):
+                feats.append(_InvertedResidual(cin, c, s if i == 0 else 1, t))
+                cin = c
+        feats.append(_conv_bn_relu6(cin, last, k=1))
+        self.features = nn.Sequential(*feats)
+        self.classifier = nn.Sequential(nn.Dropout(0.2), nn.Linear(last, num_classes))
+        self.feature_dim = last
+        for mod in self.modules():
+            if isinstance(mod, nn.Conv2d):
+                nn.init.kaiming_normal_(mod.weight, mode="fan_out")
+            elif isinstance(mod, nn.BatchNorm2d):
+                nn.init.ones_(mod.weight); nn.init.zeros_(mod.bias)
+            elif isinstance(mod, nn.Linear):
+                nn.init.normal_(mod.weight, 0, 0.01); nn.init.zeros_(mod.bias)
+
+    def forward(self, x):
+        return self.classifier(self.features(x).mean([2, 3]))
+
+
 class NormalizeInplace(nn.Module):
     """torchvision.transforms.Normalize(mean, std, inplace=True) on a batch:
     ``x.sub_(mean).div_(std)`` (used at model.py:59; mutates its input, F9)."""
@@ -225,7 +280,7 @@ def resnet_factory(arch):
 
 
 def build_encoder(hp):
-    """Restates get_encoder (model.py:16-63) for the resnet and shufflenet_v2 families, plus the
+    """Restates get_encoder (model.py:16-63) for the resnet, shufflenet_v2 and mobilenet_v2 families, plus the
     ``encoder_size`` resize the README documents (readme.md:118-121, F2).
 
     Returns nn.Sequential whose state-dict keys equal the reference's
@@ -233,6 +288,9 @@ def build_encoder(hp):
     if hp.encoder_arch in SHUFFLENET_TABLE:          # model.py:30-31 (keys: 1.* conv1, 3..5 stage2..4, 6.* conv5, 7.* 1x1 projection)
         net = ShuffleNetOracle(hp.encoder_arch)
         trunk = [net.conv1, net.maxpool, net.stage2, net.stage3, net.stage4, net.conv5]
+    elif hp.encoder_arch == "mobilenet_v2":           # model.py:38-39 (keys: 1.<i>.* features, 2.* 1x1 projection)
+        net = MobileNetV2Oracle()
+        trunk = [net.features]
     elif hp.encoder_arch in RESNET_TABLE:
         net = ResNetOracle(hp.encoder_arch)
         trunk = [net.conv1, net.bn1, net.relu, net.maxpool, net.layer1, net.layer2, net.layer3, net.layer4]
@@ -257,8 +315,8 @@ def build_encoder(hp):
 
 def trunk_param_count(arch):
     """Parameters of the trunk without fc (dev/encoder_summaries.txt:2-18)."""
-    net = ShuffleNetOracle(arch) if arch in SHUFFLENET_TABLE else ResNetOracle(arch)
-    return sum(p.numel() for n, p in net.named_parameters() if not n.startswith("fc.")), net.feature_dim
+    net = ShuffleNetOracle(arch) if arch in SHUFFLENET_TABLE else (MobileNetV2Oracle() if arch == "mobilenet_v2" else ResNetOracle(arch))
+    return sum(p.numel() for n, p in net.named_parameters() if not n.startswith(("fc.", "classifier."))), net.feature_dim
 
 
 # --------------------------------------------------------------------------

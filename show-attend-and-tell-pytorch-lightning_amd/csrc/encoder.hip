@@ -464,12 +464,13 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict
             for (int i = 0; i < E; ++i) rv[i] = (float)(T)((rv[i] - rmu[i]) * ris[i] * rgm[i] + rbt[i]);
         }
         unsigned bits = 0;
+        const float hi = relu == 2 ? 6.f : __builtin_inff();       // relu == 2: ReLU6 (mobilenet_v2); the mask bit = "the gradient passes" = 0 < v < 6, as hardtanh's backward
 #pragma unroll
         for (int i = 0; i < E; ++i) {
             float v = (xv[i] - mu[i]) * isd[i] * gm[i] + bt[i];          // this association everywhere (the stem-tail kernel must match bit for bit)
             if (res) v += rv[i];
-            bits |= (v > 0.f ? 1u : 0u) << i;
-            o[i] = relu ? (v < 0.f ? 0.f : v) : v;            // like torch's ReLU a NaN stays a NaN (fmaxf would turn it into 0 and hide it)
+            bits |= ((v > 0.f && v < hi) ? 1u : 0u) << i;
+            o[i] = relu ? (v < 0.f ? 0.f : (v > hi ? hi : v)) : v;            // like torch's ReLU a NaN stays a NaN (fmaxf would turn it into 0 and hide it)
         }
         if (rmask) {
             if (E == 8) rmask[idx] = (unsigned char)bits;
@@ -1228,6 +1229,7 @@ static int bn_train_bwd_t(const T* dy, const T* x, const T* y, int64_t rows, int
                           const uint8_t* relu_mask, float* scratch, hipStream_t st, const float* tile_stats = nullptr, int tile_rows = 0) {
     if (!dy || !x || !save_mean || !save_invstd || !gamma || !dx || !dgamma || !dbeta || !scratch) return fail(SAT_EINVAL, "bn_train_bwd: null pointer");
     if (relu && !y && !relu_mask) return fail(SAT_EINVAL, "bn_train_bwd: relu needs the forward output or its sign mask");
+    if (relu == 2 && !relu_mask) return fail(SAT_EINVAL, "bn_train_bwd: ReLU6 needs the forward's mask (the output alone does not tell 6 from > 6)");
     SAT_REQUIRE(!relu_mask || C % 8 == 0, "bn_train_bwd: the ReLU sign mask needs C %% 8 == 0 (C=%d)", C);
     SAT_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, "bn_train_bwd: bad shape");
     constexpr int E = EPT<T>::n;
@@ -1260,7 +1262,6 @@ static int bn_train_bwd_t(const T* dy, const T* x, const T* y, int64_t rows, int
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, p0, p1, nparts, C, dbeta, dgamma);
         SAT_TRY(launch_ok("bn_bwd_finalize"));
     }
-    long totalv = rows * (C / E);
     ProfScope prof("bn_apply_bwd", 0.0, (double)rows * C * (sizeof(T) * (3 + (dres ? (dres_accumulate ? 2 : 1) : 0)) + (relu ? (relu_mask ? 0.125 : (double)sizeof(T)) : 0.0)), st);
     launch_bn_bwd_apply<T>(x, dy, y, relu_mask, save_mean, save_invstd, gamma, dbeta, dgamma, relu, 1.0f / (float)rows, dx, dres, dres_accumulate, (long)rows, C / E, st);
     return launch_ok("bn_bwd_apply");

@@ -1031,13 +1031,16 @@ def _probe_zero_image(conv1, bn1, layers, size):
 
 
 def get_encoder(args):
-    """Reference get_encoder (model.py:16-63) for the resnet / wide_resnet / resnext archs and shufflenet_v2 (``encoder_shuffle.py``); adds the README's
+    """Reference get_encoder (model.py:16-63) for the resnet / wide_resnet / resnext archs shufflenet_v2 (``encoder_shuffle.py``) and mobilenet_v2 (``encoder_mobilenet.py``); adds the README's
     ``encoder_size`` resize (readme.md:118-121) when ``args.encoder_size`` is set."""
     arch = args.encoder_arch
     if arch.startswith("shufflenet_v2"):          # model.py:30-31 (the CLI default, train.py:43)
         from . import encoder_shuffle
         if arch in encoder_shuffle.SHUFFLENETS:
             return encoder_shuffle.get_shuffle_encoder(args)
+    if arch == "mobilenet_v2":                    # model.py:38-39
+        from . import encoder_mobilenet
+        return encoder_mobilenet.get_mobilenet_encoder(args)
     if arch not in RESNETS:
         raise ValueError("Encoder not supported : {}".format(arch))
     ckpt = _pretrained_file(arch, getattr(args, "pretrained", False))

@@ -168,6 +168,35 @@ def test_pretrained_shufflenet_loads_a_local_checkpoint_and_probes_like_the_refe
     assert [n for n, p in enc.named_parameters() if p.requires_grad] == ["7.weight", "7.bias"] and not enc.trunk_trainable
 
 
+def test_pretrained_mobilenet_v2_loads_a_local_checkpoint_and_probes_like_the_reference(tmp_path):
+    """model.py:38-39: torchvision keys ``features.*``, classifier dropped; the probe moves the BatchNorm buffers as the reference's does"""
+    from types import SimpleNamespace
+    from oracle import sat_oracle as O
+    from sat_amd import encoder as E
+    torch.manual_seed(12)
+    net = O.MobileNetV2Oracle()
+    with torch.no_grad():
+        for mod in net.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.uniform_(0.5, 1.5); mod.bias.uniform_(-0.3, 0.3); mod.running_mean.uniform_(-0.2, 0.2); mod.running_var.uniform_(0.5, 2.0)
+    path = os.path.join(str(tmp_path), "mobilenet_v2-b0353104.pth")
+    torch.save(net.state_dict(), path)
+    args = SimpleNamespace(encoder_arch="mobilenet_v2", input_size=64, encoder_dim=48, encoder_size=None, mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225],
+                           pretrained=path)
+    enc = E.get_encoder(args)
+    want = {k: v.clone() for k, v in net.state_dict().items()}
+    net.features.train()(torch.zeros(1, 3, 64, 64))
+    got = enc.state_dict()
+    moved = 0
+    for k, v in net.state_dict().items():
+        if k.startswith("classifier."):
+            continue
+        assert torch.allclose(got["1." + k[len("features."):]].float(), v.float(), rtol=1e-5, atol=1e-6), k
+        moved += int(("running" in k) and not torch.equal(v, want[k]))
+    assert moved > 60
+    assert [n for n, p in enc.named_parameters() if p.requires_grad] == ["2.weight", "2.bias"] and not enc.trunk_trainable
+
+
 def test_pretrained_without_a_local_file_says_so(tmp_path, monkeypatch):
     from types import SimpleNamespace
     from sat_amd import encoder as E

@@ -238,6 +238,30 @@ def test_shufflenet_structure_matches_the_reference_summary():
             E.get_encoder(O.default_hparams(encoder_arch=arch, encoder_dim=None, input_size=224))
 
 
+def test_mobilenet_v2_structure_matches_the_reference_summary():
+    """dev/encoder_summaries.txt:36-37: mobilenet_v2 = 1280 features, 2.22 M parameters without the classifier (model.py:38-39 keeps ``features``)."""
+    n, f = O.trunk_param_count("mobilenet_v2")
+    assert round(n / 1e6, 2) == 2.22 and f == 1280
+    hp = O.default_hparams(encoder_arch="mobilenet_v2", encoder_dim=None, input_size=224)
+    torch.manual_seed(5)
+    ref = O.build_encoder(hp)
+    assert hp.encoder_dim == 1280 and ref(torch.rand(2, 3, 224, 224)).shape == (2, 1280, 7, 7)
+    keys = list(ref.state_dict().keys())
+    assert keys[0] == "1.0.0.weight" and "1.1.conv.0.0.weight" in keys and "1.1.conv.2.running_var" in keys and "1.17.conv.3.bias" in keys and "1.18.1.weight" in keys
+    assert tuple(ref.state_dict()["1.2.conv.1.0.weight"].shape) == (96, 1, 3, 3)          # depthwise 3x3 of the first t = 6 block
+    import sat_amd  # noqa: F401
+    from sat_amd import encoder as E
+    torch.manual_seed(5)
+    hp2 = O.default_hparams(encoder_arch="mobilenet_v2", encoder_dim=None, input_size=224)
+    enc = E.get_encoder(hp2)
+    assert hp2.encoder_dim == 1280 and keys == list(enc.state_dict().keys())
+    assert all(torch.equal(v, ref.state_dict()[k]) for k, v in enc.state_dict().items() if "running" not in k and "num_batches" not in k)
+    assert all(bool(((v - 0.9).abs() < 1e-6).all()) for k, v in enc.state_dict().items() if "running_var" in k)      # the zero-image probe
+    for arch in ("mobilenet_v3_large", "squeezenet1_1", "densenet121", "mnasnet1_0"):          # model.py:32-41: not built, refused like an unknown name
+        with pytest.raises(ValueError, match="Encoder not supported"):
+            E.get_encoder(O.default_hparams(encoder_arch=arch, encoder_dim=None, input_size=224))
+
+
 def test_fixtures_are_small(golden_dir):
     total = sum(os.path.getsize(p) for p in glob.glob(os.path.join(golden_dir, "*.npz")))
     assert total < 4 << 20
