@@ -432,7 +432,8 @@ int sat_bn_train_bwd(const float* dy, const float* x, const float* y, int64_t ro
 int sat_bn_train_fwd_t(int32_t dtype, const void* x, int64_t rows, int32_t C, const float* gamma, const float* beta, float eps, float momentum,
                        float* running_mean, float* running_var, float* save_mean, float* save_invstd,
                        const void* residual, int32_t relu, void* y,
-                       uint8_t* relu_mask /* or NULL; rows*C/8 bytes, C % 8 == 0: bit i of byte b = (element 8b+i of y > 0) */,
+                       uint8_t* relu_mask /* or NULL; rows*C/8 bytes, C % 8 == 0: bit i of byte b = (element 8b+i of y > 0); relu == 2 (ReLU6,
+                                             mobilenet_v2: y clamped to [0, 6]): bit = (0 < pre-clamp value < 6), i.e. "the gradient passes" */,
                        float* scratch, void* stream);
 int sat_bn_eval_fwd_t(int32_t dtype, const void* x, int64_t rows, int32_t C, const float* running_mean, const float* running_var, float eps,
                       const float* gamma, const float* beta, const void* residual, int32_t relu, void* y, void* stream);
