@@ -39,70 +39,149 @@ template <typename T, int V> __device__ __forceinline__ void store_vec(T* p, con
     }
 }
 
-// w: the (C, 1, 3, 3) parameter in its own memory order = [C][9] fp32 (master weights; the filter is tiny: read through the caches)
+// w: the (C, 1, 3, 3) parameter in its own memory order = [C][9] fp32 (master weights).  A thread keeps the 9 x V taps of its V channels in
+// registers (V * 9 consecutive floats of w: 16-byte loads) and walks R consecutive rows of one column of the map: per element 9 (overlapping,
+// L1-served) 16-byte loads and one store.  (The first version read its taps with one 4-byte load per tap and channel, 72 of them per output
+// vector: 0.03 - 0.1 of the HBM peak on the 56 x 56 x 144 maps of a 128-image mobilenet_v2 batch.)
+template <int V>
+__device__ __forceinline__ void load_taps(const float* __restrict__ w, int c, float (&wr)[9][V]) {
+    float flat[V * 9];
+    const float4* wp = reinterpret_cast<const float4*>(w + (long)c * 9);          // c % V == 0: (c * 9) floats = a multiple of 16 bytes
+#pragma unroll
+    for (int j = 0; j < V * 9 / 4; ++j) { const float4 f = wp[j]; flat[4 * j] = f.x; flat[4 * j + 1] = f.y; flat[4 * j + 2] = f.z; flat[4 * j + 3] = f.w; }
+#pragma unroll
+    for (int i = 0; i < V; ++i)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wr[k][i] = flat[i * 9 + k];
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void dw3x3_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y, int N, int H, int W, int C,
-                                                        int P, int Q, int stride) {
+                                                        int P, int Q, int stride, int R) {
     constexpr int V = Vec<T>::V;
-    const int cv = C / V;
+    const int cv = C / V, PB = (P + R - 1) / R;
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = (long)N * P * Q * cv;
-    if (e >= total) return;
+    if (e >= (long)N * PB * Q * cv) return;
     const int c = (int)(e % cv) * V; long t = e / cv;
-    const int q = (int)(t % Q); t /= Q; const int p = (int)(t % P); const int n = (int)(t / P);
-    float acc[V];
+    const int q = (int)(t % Q); t /= Q; const int pb = (int)(t % PB); const int n = (int)(t / PB);
+    float wr[9][V];
+    load_taps<V>(w, c, wr);
+    for (int p = pb * R; p < pb * R + R && p < P; ++p) {
+        float acc[V];
 #pragma unroll
-    for (int i = 0; i < V; ++i) acc[i] = 0.f;
+        for (int i = 0; i < V; ++i) acc[i] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const int h = p * stride + r - 1;
-        if (h < 0 || h >= H) continue;
+        for (int r = 0; r < 3; ++r) {
+            const int h = p * stride + r - 1;
+            if (h < 0 || h >= H) continue;
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const int ww = q * stride + s - 1;
-            if (ww < 0 || ww >= W) continue;
-            float xv[V];
-            load_vec<T, V>(x + (((long)n * H + h) * W + ww) * C + c, xv);
+            for (int s = 0; s < 3; ++s) {
+                const int ww = q * stride + s - 1;
+                if (ww < 0 || ww >= W) continue;
+                float xv[V];
+                load_vec<T, V>(x + (((long)n * H + h) * W + ww) * C + c, xv);
 #pragma unroll
-            for (int i = 0; i < V; ++i) acc[i] = fmaf(xv[i], w[(c + i) * 9 + r * 3 + s], acc[i]);
+                for (int i = 0; i < V; ++i) acc[i] = fmaf(xv[i], wr[r * 3 + s][i], acc[i]);
+            }
         }
+        store_vec<T, V>(y + (((long)n * P + p) * Q + q) * C + c, acc);
     }
-    store_vec<T, V>(y + e * V, acc);
 }
 
 // dx[n, h, w, c] = sum over taps (r, s) with (h + 1 - r) = p * stride, (w + 1 - s) = q * stride of dy[n, p, q, c] * w[c, r, s]
 template <typename T>
 __global__ __launch_bounds__(256) void dw3x3_dgrad_kernel(const T* __restrict__ dy, const float* __restrict__ w, T* __restrict__ dx, int N, int H, int W, int C,
-                                                          int P, int Q, int stride) {
+                                                          int P, int Q, int stride, int R) {
     constexpr int V = Vec<T>::V;
-    const int cv = C / V;
+    const int cv = C / V, HB = (H + R - 1) / R;
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = (long)N * H * W * cv;
-    if (e >= total) return;
+    if (e >= (long)N * HB * W * cv) return;
     const int c = (int)(e % cv) * V; long t = e / cv;
-    const int ww = (int)(t % W); t /= W; const int h = (int)(t % H); const int n = (int)(t / H);
-    float acc[V];
+    const int ww = (int)(t % W); t /= W; const int hb = (int)(t % HB); const int n = (int)(t / HB);
+    float wr[9][V];
+    load_taps<V>(w, c, wr);
+    for (int h = hb * R; h < hb * R + R && h < H; ++h) {
+        float acc[V];
 #pragma unroll
-    for (int i = 0; i < V; ++i) acc[i] = 0.f;
+        for (int i = 0; i < V; ++i) acc[i] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const int ph = h + 1 - r;
-        if (ph < 0 || ph % stride) continue;
-        const int p = ph / stride;
-        if (p >= P) continue;
+        for (int r = 0; r < 3; ++r) {
+            const int ph = h + 1 - r;
+            if (ph < 0 || ph % stride) continue;
+            const int p = ph / stride;
+            if (p >= P) continue;
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const int qw = ww + 1 - s;
-            if (qw < 0 || qw % stride) continue;
-            const int q = qw / stride;
-            if (q >= Q) continue;
-            float gv[V];
-            load_vec<T, V>(dy + (((long)n * P + p) * Q + q) * C + c, gv);
+            for (int s = 0; s < 3; ++s) {
+                const int qw = ww + 1 - s;
+                if (qw < 0 || qw % stride) continue;
+                const int q = qw / stride;
+                if (q >= Q) continue;
+                float gv[V];
+                load_vec<T, V>(dy + (((long)n * P + p) * Q + q) * C + c, gv);
 #pragma unroll
-            for (int i = 0; i < V; ++i) acc[i] = fmaf(gv[i], w[(c + i) * 9 + r * 3 + s], acc[i]);
+                for (int i = 0; i < V; ++i) acc[i] = fmaf(gv[i], wr[r * 3 + s][i], acc[i]);
+            }
         }
+        store_vec<T, V>(dx + (((long)n * H + h) * W + ww) * C + c, acc);
     }
-    store_vec<T, V>(dx + e * V, acc);
+}
+
+// Stride 1 (13 of the 16 / 17 depthwise layers of shufflenet_v2 / mobilenet_v2), forward and - with the taps flipped - data gradient: the map
+// keeps its size and consecutive rows of one column share two of their three input rows.  The thread keeps a rolling window of 3 x 3 packed
+// input vectors: 3 new 16-byte loads per output vector instead of 9.  Out-of-range taps are zero vectors (they add nothing).
+template <typename T>
+__device__ __forceinline__ void fetch_row(const T* __restrict__ xn, int h, int q, int H, int W, int C, uint4& a, uint4& b, uint4& c) {
+    const bool hv = h >= 0 && h < H;
+    const uint4* p = reinterpret_cast<const uint4*>(xn + ((long)h * W + q) * C);
+    const int cs = C * (int)sizeof(T) / 16;          // one pixel to the right, in 16-byte units
+    a = (hv && q > 0) ? p[-cs] : make_uint4(0u, 0u, 0u, 0u);
+    b = hv ? p[0] : make_uint4(0u, 0u, 0u, 0u);
+    c = (hv && q + 1 < W) ? p[cs] : make_uint4(0u, 0u, 0u, 0u);
+}
+template <typename T, int V>
+__device__ __forceinline__ void tap_fma(const uint4& pk, const float (&wk)[V], float (&acc)[V]) {
+    if constexpr (sizeof(T) == 4) {
+        acc[0] = fmaf(__uint_as_float(pk.x), wk[0], acc[0]); acc[1] = fmaf(__uint_as_float(pk.y), wk[1], acc[1]);
+        acc[2] = fmaf(__uint_as_float(pk.z), wk[2], acc[2]); acc[3] = fmaf(__uint_as_float(pk.w), wk[3], acc[3]);
+    } else {
+        acc[0] = fmaf(__uint_as_float(pk.x << 16), wk[0], acc[0]); acc[1] = fmaf(__uint_as_float(pk.x & 0xffff0000u), wk[1], acc[1]);
+        acc[2] = fmaf(__uint_as_float(pk.y << 16), wk[2], acc[2]); acc[3] = fmaf(__uint_as_float(pk.y & 0xffff0000u), wk[3], acc[3]);
+        acc[4] = fmaf(__uint_as_float(pk.z << 16), wk[4], acc[4]); acc[5] = fmaf(__uint_as_float(pk.z & 0xffff0000u), wk[5], acc[5]);
+        acc[6] = fmaf(__uint_as_float(pk.w << 16), wk[6], acc[6]); acc[7] = fmaf(__uint_as_float(pk.w & 0xffff0000u), wk[7], acc[7]);
+    }
+}
+template <typename T, bool FLIP>
+__global__ __launch_bounds__(256) void dw3x3_s1_kernel(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y, int N, int H, int W, int C, int R) {
+    constexpr int V = Vec<T>::V;
+    const int cv = C / V, HB = (H + R - 1) / R;
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)N * HB * W * cv) return;
+    const int c = (int)(e % cv) * V; long t = e / cv;
+    const int q = (int)(t % W); t /= W; const int hb = (int)(t % HB); const int n = (int)(t / HB);
+    float wr[9][V];
+    load_taps<V>(w, c, wr);
+    const T* xn = x + (long)n * H * W * C + c;
+    const int h0 = hb * R, h1 = (h0 + R < H) ? h0 + R : H;
+    uint4 a0, a1, a2, b0, b1, b2, c0, c1, c2;          // rows h - 1, h, h + 1; columns q - 1, q, q + 1  (a fourth, prefetched row costs the third wave per SIMD: 176 VGPRs)
+    fetch_row<T>(xn, h0 - 1, q, H, W, C, a0, a1, a2); fetch_row<T>(xn, h0, q, H, W, C, b0, b1, b2);
+    constexpr int K0 = FLIP ? 8 : 0, KS = FLIP ? -1 : 1;          // tap of window position (row a, column b): a * 3 + b, or its mirror image
+    for (int h = h0; h < h1; ++h) {
+        fetch_row<T>(xn, h + 1, q, H, W, C, c0, c1, c2);
+        float acc[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc[i] = 0.f;
+        tap_fma<T, V>(a0, wr[K0 + KS * 0], acc); tap_fma<T, V>(a1, wr[K0 + KS * 1], acc); tap_fma<T, V>(a2, wr[K0 + KS * 2], acc);
+        tap_fma<T, V>(b0, wr[K0 + KS * 3], acc); tap_fma<T, V>(b1, wr[K0 + KS * 4], acc); tap_fma<T, V>(b2, wr[K0 + KS * 5], acc);
+        tap_fma<T, V>(c0, wr[K0 + KS * 6], acc); tap_fma<T, V>(c1, wr[K0 + KS * 7], acc); tap_fma<T, V>(c2, wr[K0 + KS * 8], acc);
+        store_vec<T, V>(y + (((long)n * H + h) * W + q) * C + c, acc);
+        a0 = b0; a1 = b1; a2 = b2; b0 = c0; b1 = c1; b2 = c2;
+    }
+}
+
+// rows per thread: 8 when that still leaves >= ~4 waves per SIMD of the chip, fewer on small maps
+static inline int dw_rows(long vectors) {
+    const long r = vectors / 262144;
+    return (int)(r < 1 ? 1 : (r > 8 ? 8 : r));
 }
 
 // dw[c][r][s] = sum over output pixels of dy * x(tap): block (channel vector group, pixel chunk) -> partial [chunk][9][C], then a fixed-order finish
@@ -115,13 +194,15 @@ static inline int dw_chunk(long npix) {
 }
 template <typename T>
 __global__ __launch_bounds__(256) void dw3x3_wgrad_part_kernel(const T* __restrict__ dy, const T* __restrict__ x, float* __restrict__ part, int N, int H, int W, int C,
-                                                               int P, int Q, int stride, int chunk) {
+                                                               int P, int Q, int stride, int chunk, int cvb) {
     constexpr int V = Vec<T>::V;
     const int cv = C / V;
-    // thread: channel vector tid % cv (all threads of a block walk different pixels of the chunk for their vector); blockDim is a multiple of cv's divisor
-    const int lanes_per_pix = cv;                      // threads needed for one pixel
-    const int pix_par = blockDim.x / lanes_per_pix;    // pixels in flight per block
-    const int vi = threadIdx.x % lanes_per_pix, pl = threadIdx.x / lanes_per_pix;
+    // block = (pixel chunk blockIdx.x, group blockIdx.y of <= cvb channel vectors); thread = channel vector tid % cvb of the group, pixel lane
+    // tid / cvb: 256 / cvb pixels of the chunk in flight (16 at least - with all of a 960-channel map's 120 vectors in one block it was 2)
+    const int pix_par = blockDim.x / cvb;
+    const int vl = threadIdx.x % cvb, pl = threadIdx.x / cvb;
+    const int vi = blockIdx.y * cvb + vl;
+    const bool live = pl < pix_par && vi < cv;
     const int c = vi * V;
     float acc[9][V];
 #pragma unroll
@@ -130,7 +211,7 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_part_kernel(const T* __restri
         for (int i = 0; i < V; ++i) acc[k][i] = 0.f;
     const long npix = (long)N * P * Q;
     const long p0 = (long)blockIdx.x * chunk, p1 = p0 + chunk < npix ? p0 + chunk : npix;
-    if (pl < pix_par) {
+    if (live) {
         for (long pix = p0 + pl; pix < p1; pix += pix_par) {
             const int q = (int)(pix % Q); long t = pix / Q; const int p = (int)(t % P); const int n = (int)(t / P);
             float gv[V];
@@ -151,18 +232,22 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_part_kernel(const T* __restri
             }
         }
     }
-    // combine the block's pixel lanes in a fixed order through LDS, one tap at a time: [pix lane][C]
+    // combine the block's pixel lanes in a fixed order through LDS, one tap at a time: [pixel lane][cvb * V]
     extern __shared__ float sm[];
+    const int CB = cvb * V;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
         if (pl < pix_par)
 #pragma unroll
-            for (int i = 0; i < V; ++i) sm[pl * C + c + i] = acc[k][i];
+            for (int i = 0; i < V; ++i) sm[pl * CB + vl * V + i] = acc[k][i];
         __syncthreads();
-        for (int o = threadIdx.x; o < C; o += blockDim.x) {
-            float t = 0.f;
-            for (int l = 0; l < pix_par; ++l) t += sm[l * C + o];
-            part[((long)blockIdx.x * 9 + k) * C + o] = t;
+        for (int o = threadIdx.x; o < CB; o += blockDim.x) {
+            const int ch = blockIdx.y * CB + o;
+            if (ch < C) {
+                float t = 0.f;
+                for (int l = 0; l < pix_par; ++l) t += sm[l * CB + o];
+                part[((long)blockIdx.x * 9 + k) * C + ch] = t;
+            }
         }
         __syncthreads();
     }
@@ -229,18 +314,30 @@ static int dw_check(const void* a, const void* b, const void* c, int N, int H, i
 int sat_dwconv3x3_fwd_t(int32_t dtype, const void* x, const float* w, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t stride, void* stream) {
     SAT_TRY(dw_check(x, w, y, N, H, W, C, stride, dtype, "dwconv3x3_fwd"));
     const int P = (H + 2 - 3) / stride + 1, Q = (W + 2 - 3) / stride + 1;
-    const long total = (long)N * P * Q * (C / (dtype ? 8 : 4));
-    if (dtype) hipLaunchKernelGGL(dw3x3_fwd_kernel<bf>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf*)x, w, (bf*)y, N, H, W, C, P, Q, stride);
-    else hipLaunchKernelGGL(dw3x3_fwd_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)x, w, (float*)y, N, H, W, C, P, Q, stride);
+    const int cv = C / (dtype ? 8 : 4), R = dw_rows((long)N * P * Q * cv);
+    const long total = (long)N * cdiv(P, R) * Q * cv;
+    if (stride == 1 && R > 1) {          // (one row per thread: nothing to roll, the plain kernel is 2 us faster on the small maps)
+        if (dtype) hipLaunchKernelGGL((dw3x3_s1_kernel<bf, false>), dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf*)x, w, (bf*)y, N, H, W, C, R);
+        else hipLaunchKernelGGL((dw3x3_s1_kernel<float, false>), dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)x, w, (float*)y, N, H, W, C, R);
+        return launch_ok("dwconv3x3_fwd (stride 1)");
+    }
+    if (dtype) hipLaunchKernelGGL(dw3x3_fwd_kernel<bf>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf*)x, w, (bf*)y, N, H, W, C, P, Q, stride, R);
+    else hipLaunchKernelGGL(dw3x3_fwd_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)x, w, (float*)y, N, H, W, C, P, Q, stride, R);
     return launch_ok("dwconv3x3_fwd");
 }
 
 int sat_dwconv3x3_dgrad_t(int32_t dtype, const void* dy, const float* w, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t stride, void* stream) {
     SAT_TRY(dw_check(dy, w, dx, N, H, W, C, stride, dtype, "dwconv3x3_dgrad"));
     const int P = (H + 2 - 3) / stride + 1, Q = (W + 2 - 3) / stride + 1;
-    const long total = (long)N * H * W * (C / (dtype ? 8 : 4));
-    if (dtype) hipLaunchKernelGGL(dw3x3_dgrad_kernel<bf>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf*)dy, w, (bf*)dx, N, H, W, C, P, Q, stride);
-    else hipLaunchKernelGGL(dw3x3_dgrad_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)dy, w, (float*)dx, N, H, W, C, P, Q, stride);
+    const int cv = C / (dtype ? 8 : 4), R = dw_rows((long)N * H * W * cv);
+    const long total = (long)N * cdiv(H, R) * W * cv;
+    if (stride == 1 && R > 1) {
+        if (dtype) hipLaunchKernelGGL((dw3x3_s1_kernel<bf, true>), dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf*)dy, w, (bf*)dx, N, H, W, C, R);
+        else hipLaunchKernelGGL((dw3x3_s1_kernel<float, true>), dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)dy, w, (float*)dx, N, H, W, C, R);
+        return launch_ok("dwconv3x3_dgrad (stride 1)");
+    }
+    if (dtype) hipLaunchKernelGGL(dw3x3_dgrad_kernel<bf>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf*)dy, w, (bf*)dx, N, H, W, C, P, Q, stride, R);
+    else hipLaunchKernelGGL(dw3x3_dgrad_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)dy, w, (float*)dx, N, H, W, C, P, Q, stride, R);
     return launch_ok("dwconv3x3_dgrad");
 }
 
@@ -255,15 +352,16 @@ int sat_dwconv3x3_wgrad_t(int32_t dtype, const void* dy, const void* x, float* d
     SAT_TRY(dw_check(dy, x, dw, N, H, W, C, stride, dtype, "dwconv3x3_wgrad"));
     if (!scratch) return fail(SAT_EINVAL, "dwconv3x3_wgrad: null scratch");
     const int V = dtype ? 8 : 4, cv = C / V;
-    SAT_REQUIRE(cv <= 256, "dwconv3x3_wgrad: C=%d channels exceed %d", C, 256 * V);
     const int P = (H + 2 - 3) / stride + 1, Q = (W + 2 - 3) / stride + 1;
     const int chunk = dw_chunk((long)N * P * Q);
     const int nparts = cdiv((long)N * P * Q, (long)chunk);
-    const int pix_par = 256 / cv;
-    const size_t lds = (size_t)pix_par * C * sizeof(float);
-    SAT_REQUIRE(lds <= 64 * 1024, "dwconv3x3_wgrad: C=%d needs %zu bytes of LDS", C, lds);
-    if (dtype) hipLaunchKernelGGL(dw3x3_wgrad_part_kernel<bf>, dim3(nparts), dim3(256), lds, (hipStream_t)stream, (const bf*)dy, (const bf*)x, scratch, N, H, W, C, P, Q, stride, chunk);
-    else hipLaunchKernelGGL(dw3x3_wgrad_part_kernel<float>, dim3(nparts), dim3(256), lds, (hipStream_t)stream, (const float*)dy, (const float*)x, scratch, N, H, W, C, P, Q, stride, chunk);
+    int cvb = cv < 32 ? cv : 32;          // channel vectors per block: the largest divisor of cv up to 32 (no idle lanes; >= 8 pixels in flight per block)
+    while (cv % cvb) --cvb;
+    const int pix_par = 256 / cvb;
+    const size_t lds = (size_t)pix_par * cvb * V * sizeof(float);
+    const dim3 grid(nparts, cdiv(cv, cvb));
+    if (dtype) hipLaunchKernelGGL(dw3x3_wgrad_part_kernel<bf>, grid, dim3(256), lds, (hipStream_t)stream, (const bf*)dy, (const bf*)x, scratch, N, H, W, C, P, Q, stride, chunk, cvb);
+    else hipLaunchKernelGGL(dw3x3_wgrad_part_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, (const float*)dy, (const float*)x, scratch, N, H, W, C, P, Q, stride, chunk, cvb);
     SAT_TRY(launch_ok("dwconv3x3_wgrad (partials)"));
     hipLaunchKernelGGL(dw3x3_wgrad_finish_kernel, dim3(9 * C), dim3(64), 0, (hipStream_t)stream, scratch, nparts, C, dw);
     return launch_ok("dwconv3x3_wgrad (finish)");

@@ -464,13 +464,22 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict
             for (int i = 0; i < E; ++i) rv[i] = (float)(T)((rv[i] - rmu[i]) * ris[i] * rgm[i] + rbt[i]);
         }
         unsigned bits = 0;
-        const float hi = relu == 2 ? 6.f : __builtin_inff();       // relu == 2: ReLU6 (mobilenet_v2); the mask bit = "the gradient passes" = 0 < v < 6, as hardtanh's backward
+        if (relu == 2) {          // ReLU6 (mobilenet_v2), a wave-uniform branch: clamp to [0, 6]; the mask bit = "the gradient passes" = 0 < v < 6, hardtanh's rule
 #pragma unroll
-        for (int i = 0; i < E; ++i) {
-            float v = (xv[i] - mu[i]) * isd[i] * gm[i] + bt[i];          // this association everywhere (the stem-tail kernel must match bit for bit)
-            if (res) v += rv[i];
-            bits |= ((v > 0.f && v < hi) ? 1u : 0u) << i;
-            o[i] = relu ? (v < 0.f ? 0.f : (v > hi ? hi : v)) : v;            // like torch's ReLU a NaN stays a NaN (fmaxf would turn it into 0 and hide it)
+            for (int i = 0; i < E; ++i) {
+                float v = (xv[i] - mu[i]) * isd[i] * gm[i] + bt[i];
+                if (res) v += rv[i];
+                bits |= ((v > 0.f && v < 6.f) ? 1u : 0u) << i;
+                o[i] = v < 0.f ? 0.f : (v > 6.f ? 6.f : v);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                float v = (xv[i] - mu[i]) * isd[i] * gm[i] + bt[i];          // this association everywhere (the stem-tail kernel must match bit for bit)
+                if (res) v += rv[i];
+                bits |= (v > 0.f ? 1u : 0u) << i;
+                o[i] = relu ? (v < 0.f ? 0.f : v) : v;            // like torch's ReLU a NaN stays a NaN (fmaxf would turn it into 0 and hide it)
+            }
         }
         if (rmask) {
             if (E == 8) rmask[idx] = (unsigned char)bits;

@@ -15,6 +15,7 @@ if os.environ.get("TF") == "none" or cfg == "cli":
     hp["decoder_tf"] = None
 if cfg == "cli":
     hp["deep_output"] = False
+    hp["encoder_arch"] = os.environ.get("ARCH", hp["encoder_arch"])
 torch.manual_seed(42)
 model = M.SAT(**hp).cuda().train(); model.set_precision("bf16")
 model.__dict__["_sat_global_step"] = 2

@@ -8,6 +8,6 @@ TAG=r3 bash tools/collect_profiles.sh c4 > gpurun_out/r3_collect_c4.log 2>&1 || 
 root=$(pwd)
 cd /tmp && rm -rf /tmp/tr && ROUNDS=1 PER=6 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -o run -- python3 $root/tools/ab_step.py base > $root/gpurun_out/r3_trace.log 2>&1
 cd $root && python3 tools/critical_path.py /tmp/tr/run_kernel_trace.csv > gpurun_out/r3_critical_c2.txt 2>&1
-for c in c1 c2 c3 c4; do CFG=$c N=15 timeout -k 5 300 python3 tools/graph_step_time.py 2>&1 | grep -v amdgpu; done > gpurun_out/r3_graph_time_final.txt
+for c in c1 c2 c3 c4 cli; do CFG=$c N=15 timeout -k 5 300 python3 tools/graph_step_time.py 2>&1 | grep -v amdgpu; done > gpurun_out/r3_graph_time_final.txt
 python bench.py > gpurun_out/r3_bench_default.json 2> gpurun_out/r3_bench_default.err; echo "bench rc=$?"
 tail -c 300 gpurun_out/r3_bench_default.json
