@@ -252,6 +252,62 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_part_kernel(const T* __restri
         __syncthreads();
     }
 }
+// Stride 1: the filter gradient with the rolling window of dw3x3_s1_kernel.  A thread owns one channel vector of one column of the map over R rows
+// (3 new input vectors + 1 gradient vector per pixel instead of 9 + 1); a block = `cvb` channel vectors x 256 / cvb columns, combined through
+// LDS in a fixed order; one partial [9][C] slice per block.
+template <typename T>
+__global__ __launch_bounds__(256) void dw3x3_wgrad_s1_kernel(const T* __restrict__ dy, const T* __restrict__ x, float* __restrict__ part, int N, int H, int W, int C,
+                                                             int R, int cvb) {
+    constexpr int V = Vec<T>::V;
+    const int cv = C / V, HB = (H + R - 1) / R;
+    const int pix_par = blockDim.x / cvb;
+    const int vl = threadIdx.x % cvb, pl = threadIdx.x / cvb;
+    const int vi = blockIdx.y * cvb + vl;
+    const bool live = pl < pix_par && vi < cv;
+    const int c = vi * V;
+    float acc[9][V];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc[k][i] = 0.f;
+    const long ncols = (long)N * HB * W;
+    for (long col = (long)blockIdx.x * pix_par + pl; live && col < ncols; col += (long)gridDim.x * pix_par) {          // column = (n, hb, q)
+        const int q = (int)(col % W); long t = col / W; const int hb = (int)(t % HB); const int n = (int)(t / HB);
+        const T* xn = x + (long)n * H * W * C + c;
+        const T* gn = dy + (long)n * H * W * C + c;
+        const int h0 = hb * R, h1 = (h0 + R < H) ? h0 + R : H;
+        uint4 a0, a1, a2, b0, b1, b2, c0, c1, c2;
+        fetch_row<T>(xn, h0 - 1, q, H, W, C, a0, a1, a2); fetch_row<T>(xn, h0, q, H, W, C, b0, b1, b2);
+        for (int h = h0; h < h1; ++h) {
+            fetch_row<T>(xn, h + 1, q, H, W, C, c0, c1, c2);
+            float gv[V];
+            load_vec<T, V>(gn + ((long)h * W + q) * C, gv);
+            tap_fma<T, V>(a0, gv, acc[0]); tap_fma<T, V>(a1, gv, acc[1]); tap_fma<T, V>(a2, gv, acc[2]);
+            tap_fma<T, V>(b0, gv, acc[3]); tap_fma<T, V>(b1, gv, acc[4]); tap_fma<T, V>(b2, gv, acc[5]);
+            tap_fma<T, V>(c0, gv, acc[6]); tap_fma<T, V>(c1, gv, acc[7]); tap_fma<T, V>(c2, gv, acc[8]);
+            a0 = b0; a1 = b1; a2 = b2; b0 = c0; b1 = c1; b2 = c2;
+        }
+    }
+    extern __shared__ float sm[];
+    const int CB = cvb * V;
+    const long slice = (long)blockIdx.x;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        if (pl < pix_par)
+#pragma unroll
+            for (int i = 0; i < V; ++i) sm[pl * CB + vl * V + i] = acc[k][i];
+        __syncthreads();
+        for (int o = threadIdx.x; o < CB; o += blockDim.x) {
+            const int ch = blockIdx.y * CB + o;
+            if (ch < C) {
+                float tsum = 0.f;
+                for (int l = 0; l < pix_par; ++l) tsum += sm[l * CB + o];
+                part[(slice * 9 + k) * C + ch] = tsum;
+            }
+        }
+        __syncthreads();
+    }
+}
 // one wave per filter element: lane l adds partials l, l + 64, ... (double), then a fixed-order butterfly
 __global__ __launch_bounds__(64) void dw3x3_wgrad_finish_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ dw) {
     const int o = blockIdx.x;                                     // o = k * C + c in the partials; dw is [C][9]
@@ -301,6 +357,17 @@ __global__ void cast_bf16_f32_kernel(const bf* __restrict__ src, float* __restri
 
 using namespace sat;
 
+// launch shape of dw3x3_wgrad_s1_kernel: rows per thread R (<= 1: use the generic kernel), channel vectors per block, number of blocks along x
+static int dw_wgrad_s1_blocks(int N, int H, int W, int C, int V, int& R, int& cvb) {
+    const int cv = C / V;
+    cvb = cv < 32 ? cv : 32;          // the largest divisor of cv up to 32 (no idle lanes; >= 8 columns in flight per block)
+    while (cv % cvb) --cvb;
+    R = dw_rows((long)N * H * W * cv * 4);          // the reduction wants long columns: 8 rows from 64 k vectors on
+    if (R <= 1) return 0;
+    const int nb = cdiv((long)N * cdiv(H, R) * W, (long)(256 / cvb));
+    return nb < 1024 ? nb : 1024;          // more columns than that: the blocks take several (fewer partials for the finish to add)
+}
+
 extern "C" {
 
 static int dw_check(const void* a, const void* b, const void* c, int N, int H, int W, int C, int stride, int dtype, const char* what) {
@@ -344,7 +411,14 @@ int sat_dwconv3x3_dgrad_t(int32_t dtype, const void* dy, const float* w, void* d
 size_t sat_dwconv3x3_wgrad_scratch_bytes(int32_t N, int32_t H, int32_t W, int32_t C, int32_t stride) {
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (stride != 1 && stride != 2)) return 0;
     const int P = (H + 2 - 3) / stride + 1, Q = (W + 2 - 3) / stride + 1;
-    return (size_t)cdiv((long)N * P * Q, (long)dw_chunk((long)N * P * Q)) * 9 * C * sizeof(float);
+    size_t parts = (size_t)cdiv((long)N * P * Q, (long)dw_chunk((long)N * P * Q));
+    if (stride == 1)          // the rolling form writes one partial per block; whichever storage type the call will have
+        for (int V = 4; V <= 8; V += 4) {
+            int R, cvb;
+            const size_t nb = C % V ? 0 : (size_t)dw_wgrad_s1_blocks(N, H, W, C, V, R, cvb);
+            if (nb > parts) parts = nb;
+        }
+    return parts * 9 * C * sizeof(float);
 }
 
 int sat_dwconv3x3_wgrad_t(int32_t dtype, const void* dy, const void* x, float* dw, int32_t N, int32_t H, int32_t W, int32_t C, int32_t stride, float* scratch,
@@ -355,10 +429,19 @@ int sat_dwconv3x3_wgrad_t(int32_t dtype, const void* dy, const void* x, float* d
     const int P = (H + 2 - 3) / stride + 1, Q = (W + 2 - 3) / stride + 1;
     const int chunk = dw_chunk((long)N * P * Q);
     const int nparts = cdiv((long)N * P * Q, (long)chunk);
-    int cvb = cv < 32 ? cv : 32;          // channel vectors per block: the largest divisor of cv up to 32 (no idle lanes; >= 8 pixels in flight per block)
-    while (cv % cvb) --cvb;
+    int R, cvb;
+    int nblk = dw_wgrad_s1_blocks(N, H, W, C, V, R, cvb);          // (also sets cvb for the generic form)
+    if (stride != 1) nblk = 0;
     const int pix_par = 256 / cvb;
     const size_t lds = (size_t)pix_par * cvb * V * sizeof(float);
+    if (nblk > 0) {          // stride 1, long enough columns: the rolling-window form
+        const dim3 g1(nblk, cdiv(cv, cvb));
+        if (dtype) hipLaunchKernelGGL(dw3x3_wgrad_s1_kernel<bf>, g1, dim3(256), lds, (hipStream_t)stream, (const bf*)dy, (const bf*)x, scratch, N, H, W, C, R, cvb);
+        else hipLaunchKernelGGL(dw3x3_wgrad_s1_kernel<float>, g1, dim3(256), lds, (hipStream_t)stream, (const float*)dy, (const float*)x, scratch, N, H, W, C, R, cvb);
+        SAT_TRY(launch_ok("dwconv3x3_wgrad (stride 1, partials)"));
+        hipLaunchKernelGGL(dw3x3_wgrad_finish_kernel, dim3(9 * C), dim3(64), 0, (hipStream_t)stream, scratch, nblk, C, dw);
+        return launch_ok("dwconv3x3_wgrad (finish)");
+    }
     const dim3 grid(nparts, cdiv(cv, cvb));
     if (dtype) hipLaunchKernelGGL(dw3x3_wgrad_part_kernel<bf>, grid, dim3(256), lds, (hipStream_t)stream, (const bf*)dy, (const bf*)x, scratch, N, H, W, C, P, Q, stride, chunk, cvb);
     else hipLaunchKernelGGL(dw3x3_wgrad_part_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, (const float*)dy, (const float*)x, scratch, N, H, W, C, P, Q, stride, chunk, cvb);
