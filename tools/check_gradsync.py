@@ -1,6 +1,6 @@
 """Dev: the real SAT model under GradSync with several ranks on ONE GPU (gloo): the synchronised gradients must equal the mean
 of the ranks' local gradients, bucket by bucket, including the stages announced from inside the encoder backward.
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29561 tools/check_gradsync.py"""
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29561 tools/check_gradsync.py      (ARCH=shufflenet_v2_x0_5 | mobilenet_v2 for the other encoder families)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,7 +13,7 @@ from oracle import prng, sat_oracle as O
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 torch.cuda.set_device(0)
-over = dict(encoder_arch="resnet18", encoder_dim=32, input_size=64, encoder_size=3, vocab_size=120, embed_dim=24, attention_dim=16, decoder_dim=40,
+over = dict(encoder_arch=os.environ.get("ARCH", "resnet18"), encoder_dim=32, input_size=64, encoder_size=3, vocab_size=120, embed_dim=24, attention_dim=16, decoder_dim=40,
             deep_output=True, decoder_tf="always", weight_decay=0.0, decoder_lr=1e-3, embedding_lr=1e-2, encoder_lr=1e-5, opt="adam", adam_b1=0.9,
             adam_b2=0.999, momentum=0.9, nesterov=False, scheduler=None)
 for prec in ("fp32", "bf16"):
