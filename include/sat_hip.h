@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SAT_HIP_ABI_VERSION 22
+#define SAT_HIP_ABI_VERSION 23
 
 int sat_abi_version(void);
 /* dev aid: after every kernel launch wait for the device and print the launch's name to stderr (a device fault then points at the
@@ -402,14 +402,16 @@ int sat_stem_filter_grad_unpairs(const float* dw_pairs, float* dw3, int32_t K, v
  *     (scratch: sat_dwconv3x3_wgrad_scratch_bytes);
  *   channel_shuffle(cat(a, b), groups = 2) of two (rows, Ch) branches: element c of the result = (c odd ? b : a)[c / 2].  join writes
  *     either `full` (rows, 2 Ch), or - full == NULL - its two halves x1 = [:, :Ch], x2 = [:, Ch:] as separate dense tensors (what the
- *     next stride-1 unit's x.chunk(2, dim = 1) reads); split is the backward: (d full | its halves) -> (da, db).                        */
+ *     next stride-1 unit's x.chunk(2, dim = 1) reads); split is the backward: (d full | its halves) -> (da, db).
+ *     Ch = the real branch width, Chp >= Ch (a multiple of 4) the width of the branch tensors and of the halves in memory: channels past Ch
+ *     are zero padding and stay zero (x1_0 / x2_0: 58- / 122-channel branches held in 64 / 128); `full` has (2 Ch rounded up to 8) channels. */
 int sat_dwconv3x3_fwd_t(int32_t dtype, const void* x, const float* w, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t stride, void* stream);
 int sat_dwconv3x3_dgrad_t(int32_t dtype, const void* dy, const float* w, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t stride, void* stream);
 size_t sat_dwconv3x3_wgrad_scratch_bytes(int32_t N, int32_t H, int32_t W, int32_t C, int32_t stride);
 int sat_dwconv3x3_wgrad_t(int32_t dtype, const void* dy, const void* x, float* dw, int32_t N, int32_t H, int32_t W, int32_t C, int32_t stride,
                           float* scratch, void* stream);
-int sat_shuffle_join_t(int32_t dtype, const void* a, const void* b, void* full, void* x1, void* x2, int64_t rows, int32_t Ch, void* stream);
-int sat_shuffle_split_t(int32_t dtype, const void* dfull, const void* dx1, const void* dx2, void* da, void* db, int64_t rows, int32_t Ch, void* stream);
+int sat_shuffle_join_t(int32_t dtype, const void* a, const void* b, void* full, void* x1, void* x2, int64_t rows, int32_t Ch, int32_t Chp, void* stream);
+int sat_shuffle_split_t(int32_t dtype, const void* dfull, const void* dx1, const void* dx2, void* da, void* db, int64_t rows, int32_t Ch, int32_t Chp, void* stream);
 /* bf16 -> fp32 copy (n % 8 == 0): the annotations of a bf16 trunk without the 1x1 projection (encoder_dim == trunk width, model.py:56-57) */
 int sat_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
 /* (pixels, 3) <-> (pixels, 4) zero padded; used for the stem filters */

@@ -175,8 +175,8 @@ SYMBOLS.update({
     "sat_dwconv3x3_dgrad_t": (C.c_int, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "sat_dwconv3x3_wgrad_scratch_bytes": (C.c_size_t, [_i32, _i32, _i32, _i32, _i32]),
     "sat_dwconv3x3_wgrad_t": (C.c_int, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
-    "sat_shuffle_join_t": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
-    "sat_shuffle_split_t": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "sat_shuffle_join_t": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "sat_shuffle_split_t": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "sat_cast_bf16_to_f32": (C.c_int, [_vp, _vp, _i64, _vp]),
     "sat_grouped_filter_expand": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "sat_grouped_filter_grad_extract": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
@@ -271,8 +271,8 @@ def lib():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(handle, name)          # AttributeError if the export is missing
             fn.restype, fn.argtypes = res, args
-        if handle.sat_abi_version() != 22:
-            raise SatHipError("libsat_hip.so ABI version %d != 22 (rebuild: make -C csrc)" % handle.sat_abi_version())
+        if handle.sat_abi_version() != 23:
+            raise SatHipError("libsat_hip.so ABI version %d != 23 (rebuild: make -C csrc)" % handle.sat_abi_version())
         _lib = handle
     return _lib
 

@@ -321,26 +321,40 @@ __global__ __launch_bounds__(64) void dw3x3_wgrad_finish_kernel(const float* __r
     }
 }
 
-// channel_shuffle(cat(a, b), 2): full[row][c] = (c odd ? b : a)[row][c / 2]; halves: x1 = full[:, :Ch], x2 = full[:, Ch:]
+// channel_shuffle(cat(a, b), 2): full[row][c] = (c odd ? b : a)[row][c / 2]; halves: x1 = full[:, :Ch], x2 = full[:, Ch:].
+// Ch = the real branch width, Chp >= Ch the width the branch tensors have in memory (channels past Ch are zero padding, kept zero here:
+// shufflenet_v2 x1_0 / x2_0 have 58- / 122-channel branches held in 64 / 128); the whole tensor has Fp >= 2 Ch channels in memory.
 template <typename T>
-__global__ void shuffle_join_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ full, T* __restrict__ x1, T* __restrict__ x2, long rows, int Ch) {
+__global__ void shuffle_join_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ full, T* __restrict__ x1, T* __restrict__ x2, long rows, int Ch,
+                                    int Chp, int Fp) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= rows * 2 * Ch) return;
-    const long row = e / (2 * Ch); const int c = (int)(e - row * 2 * Ch);
-    const T v = (c & 1) ? b[row * Ch + (c >> 1)] : a[row * Ch + (c >> 1)];
-    if (full) full[e] = v;
-    else if (c < Ch) x1[row * Ch + c] = v;
-    else x2[row * Ch + c - Ch] = v;
+    const int wide = full ? Fp : 2 * Chp;
+    if (e >= rows * wide) return;
+    const long row = e / wide; const int c = (int)(e - row * wide);
+    const T zero = (T)0.f;
+    if (full) {
+        full[e] = c < 2 * Ch ? ((c & 1) ? b[row * Chp + (c >> 1)] : a[row * Chp + (c >> 1)]) : zero;
+        return;
+    }
+    const int half = c >= Chp, cc = c - half * Chp;          // channel cc of x1 / x2 = channel half * Ch + cc of the whole tensor
+    const int g = half * Ch + cc;
+    const T v = cc < Ch ? ((g & 1) ? b[row * Chp + (g >> 1)] : a[row * Chp + (g >> 1)]) : zero;
+    (half ? x2 : x1)[row * Chp + cc] = v;
 }
 // its backward: da[row][i] = d full[row][2 i], db[row][i] = d full[row][2 i + 1] (d full given whole, or as its two halves)
 template <typename T>
 __global__ void shuffle_split_kernel(const T* __restrict__ dfull, const T* __restrict__ dx1, const T* __restrict__ dx2, T* __restrict__ da, T* __restrict__ db, long rows,
-                                     int Ch) {
+                                     int Ch, int Chp, int Fp) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= rows * 2 * Ch) return;
-    const long row = e / (2 * Ch); const int c = (int)(e - row * 2 * Ch);
-    const T v = dfull ? dfull[e] : (c < Ch ? dx1[row * Ch + c] : dx2[row * Ch + c - Ch]);
-    if (c & 1) db[row * Ch + (c >> 1)] = v; else da[row * Ch + (c >> 1)] = v;
+    if (e >= rows * 2 * Chp) return;
+    const long row = e / (2 * Chp); const int c = (int)(e - row * 2 * Chp);
+    const int which = c >= Chp, i = c - which * Chp;          // which = 1: db
+    T v = (T)0.f;
+    if (i < Ch) {
+        const int g = 2 * i + which;
+        v = dfull ? dfull[row * Fp + g] : (g < Ch ? dx1[row * Chp + g] : dx2[row * Chp + g - Ch]);
+    }
+    (which ? db : da)[row * Chp + i] = v;
 }
 
 __global__ void cast_bf16_f32_kernel(const bf* __restrict__ src, float* __restrict__ dst, long n8) {
@@ -450,19 +464,29 @@ int sat_dwconv3x3_wgrad_t(int32_t dtype, const void* dy, const void* x, float* d
     return launch_ok("dwconv3x3_wgrad (finish)");
 }
 
-int sat_shuffle_join_t(int32_t dtype, const void* a, const void* b, void* full, void* x1, void* x2, int64_t rows, int32_t Ch, void* stream) {
-    if (!a || !b || (!full && !(x1 && x2)) || rows <= 0 || Ch <= 0) return fail(SAT_EINVAL, "shuffle_join: bad argument");
-    const long total = rows * 2 * Ch;
-    if (dtype) hipLaunchKernelGGL(shuffle_join_kernel<bf>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf*)a, (const bf*)b, (bf*)full, (bf*)x1, (bf*)x2, (long)rows, Ch);
-    else hipLaunchKernelGGL(shuffle_join_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)a, (const float*)b, (float*)full, (float*)x1, (float*)x2, (long)rows, Ch);
+static int shuffle_check(int64_t rows, int32_t Ch, int32_t Chp, const char* what) {
+    SAT_REQUIRE(rows > 0 && Ch > 0 && Chp >= Ch && Chp % 4 == 0, "%s: rows=%ld Ch=%d Chp=%d (Chp >= Ch, a multiple of 4)", what, (long)rows, Ch, Chp);
+    return SAT_OK;
+}
+static inline int full_width(int Ch) { return (2 * Ch + 7) / 8 * 8; }
+
+int sat_shuffle_join_t(int32_t dtype, const void* a, const void* b, void* full, void* x1, void* x2, int64_t rows, int32_t Ch, int32_t Chp, void* stream) {
+    if (!a || !b || (!full && !(x1 && x2))) return fail(SAT_EINVAL, "shuffle_join: null pointer");
+    SAT_TRY(shuffle_check(rows, Ch, Chp, "shuffle_join"));
+    const int Fp = full_width(Ch);
+    const long total = rows * (full ? Fp : 2 * Chp);
+    if (dtype) hipLaunchKernelGGL(shuffle_join_kernel<bf>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf*)a, (const bf*)b, (bf*)full, (bf*)x1, (bf*)x2, (long)rows, Ch, Chp, Fp);
+    else hipLaunchKernelGGL(shuffle_join_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)a, (const float*)b, (float*)full, (float*)x1, (float*)x2, (long)rows, Ch, Chp, Fp);
     return launch_ok("shuffle_join");
 }
 
-int sat_shuffle_split_t(int32_t dtype, const void* dfull, const void* dx1, const void* dx2, void* da, void* db, int64_t rows, int32_t Ch, void* stream) {
-    if ((!dfull && !(dx1 && dx2)) || !da || !db || rows <= 0 || Ch <= 0) return fail(SAT_EINVAL, "shuffle_split: bad argument");
-    const long total = rows * 2 * Ch;
-    if (dtype) hipLaunchKernelGGL(shuffle_split_kernel<bf>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf*)dfull, (const bf*)dx1, (const bf*)dx2, (bf*)da, (bf*)db, (long)rows, Ch);
-    else hipLaunchKernelGGL(shuffle_split_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)dfull, (const float*)dx1, (const float*)dx2, (float*)da, (float*)db, (long)rows, Ch);
+int sat_shuffle_split_t(int32_t dtype, const void* dfull, const void* dx1, const void* dx2, void* da, void* db, int64_t rows, int32_t Ch, int32_t Chp, void* stream) {
+    if ((!dfull && !(dx1 && dx2)) || !da || !db) return fail(SAT_EINVAL, "shuffle_split: null pointer");
+    SAT_TRY(shuffle_check(rows, Ch, Chp, "shuffle_split"));
+    const int Fp = full_width(Ch);
+    const long total = rows * 2 * Chp;
+    if (dtype) hipLaunchKernelGGL(shuffle_split_kernel<bf>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf*)dfull, (const bf*)dx1, (const bf*)dx2, (bf*)da, (bf*)db, (long)rows, Ch, Chp, Fp);
+    else hipLaunchKernelGGL(shuffle_split_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)dfull, (const float*)dx1, (const float*)dx2, (float*)da, (float*)db, (long)rows, Ch, Chp, Fp);
     return launch_ok("shuffle_split");
 }
 

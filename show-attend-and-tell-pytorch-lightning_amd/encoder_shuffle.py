@@ -15,8 +15,13 @@ convolutions and the shuffle are streaming kernels (``csrc/depthwise.hip``).  Th
 separate dense tensors in front of a stride-1 unit (so ``x.chunk(2, dim=1)`` costs nothing and the pass-through half is never copied on its
 own), the whole tensor in front of a stride-2 unit / conv5.
 
-Archs: the branch widths must be multiples of 8 channels (16-byte vectors of bf16): x0_5 (24 / 48 / 96) and x1_5 (88 / 176 / 352).  x1_0 and
-x2_0 have 58- and 122-channel branches and are refused.
+Widths: the kernels move 16-byte vectors (8 bf16 channels).  x0_5 (branches of 24 / 48 / 96 channels) and x1_5 (88 / 176 / 352) fit; x1_0
+(58 / 116 / 232) and x2_0 (122 / 244 / 488) do not: their parameters and activations are HELD zero-padded to the next multiple of 8 (58 -> 64,
+116 -> 120, 122 -> 128, 244 -> 248).  The padding is exact, not an approximation: a padded output channel has zero filter rows and a zero
+BatchNorm scale / shift, so it is exactly 0 forward, its gradients are exactly 0 backward (the BatchNorm backward multiplies by the zero scale;
+a padded INPUT channel meets zero filter columns), and an optimizer step of a zero gradient on a zero weight with zero moments leaves zero -
+also with weight decay.  ``state_dict()`` / ``load_state_dict()`` slice / pad at the module boundary (``_hold_padded_``), so checkpoints have
+the reference's shapes; ``parameters()`` are the padded tensors.
 """
 import ctypes as C
 
@@ -36,6 +41,67 @@ SHUFFLENETS = {
 }
 
 
+def _pad8(c):
+    return (c + 7) // 8 * 8
+
+
+def _slice_to(t, shape):
+    return t[tuple(slice(0, n) for n in shape)]
+
+
+def _hold_padded_(mod, shapes):
+    """Replace the parameters / buffers of leaf module ``mod`` named in ``shapes`` (name -> padded shape) by zero-padded tensors holding the old
+    values in their leading corner, and make the module's state dict speak the ORIGINAL shapes (save: slice; load: pad)."""
+    real = {}
+    for name, shape in shapes.items():
+        old = getattr(mod, name)
+        if tuple(old.shape) == tuple(shape):
+            continue
+        real[name] = tuple(old.shape)
+        new = torch.zeros(shape, dtype=old.dtype, device=old.device)
+        _slice_to(new, old.shape).copy_(old.detach())
+        if isinstance(old, nn.Parameter):
+            setattr(mod, name, nn.Parameter(new, requires_grad=old.requires_grad))
+        else:
+            mod.register_buffer(name, new)
+    if not real:
+        return
+    mod.__dict__["_sat_real_shapes"] = real
+
+    def save_hook(m, sd, prefix, local_metadata):
+        for name, shape in real.items():
+            if prefix + name in sd:
+                sd[prefix + name] = _slice_to(sd[prefix + name], shape).clone()
+
+    def load_hook(sd, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        for name, shape in real.items():
+            t = sd.get(prefix + name)
+            if t is not None and tuple(t.shape) == shape:
+                full = torch.zeros(getattr(mod, name).shape, dtype=t.dtype, device=t.device)
+                _slice_to(full, shape).copy_(t)
+                sd[prefix + name] = full
+
+    mod._register_state_dict_hook(save_hook)
+    mod._register_load_state_dict_pre_hook(load_hook)
+
+
+def _pad_conv_(conv, cin_p, cout_p):
+    """(K, C / groups, R, S) filter -> (cout_p, cin_p or 1, R, S), zeros outside the original block"""
+    dw = conv.groups > 1
+    _hold_padded_(conv, {"weight": (cout_p, 1 if dw else cin_p) + tuple(conv.weight.shape[2:])})
+    conv.in_channels, conv.out_channels = cin_p, cout_p
+    if dw:
+        conv.groups = cout_p
+
+
+def _pad_bn_(bn, c_p):
+    if bn.num_features == c_p:
+        return
+    # the padded channels get scale 0 and shift 0 (``_hold_padded_`` fills zeros): their output and every gradient are exactly 0
+    _hold_padded_(bn, {"weight": (c_p,), "bias": (c_p,), "running_mean": (c_p,), "running_var": (c_p,)})
+    bn.num_features = c_p
+
+
 class ShuffleUnit(nn.Module):
     """Parameter holder of one torchvision InvertedResidual (same child indices inside branch1 / branch2)."""
 
@@ -43,6 +109,7 @@ class ShuffleUnit(nn.Module):
         super().__init__()
         self.stride = stride
         bfeat = oup // 2
+        self.bfeat = bfeat          # the real branch width (``pad_()`` may hold the tensors wider)
         if stride == 1 and inp != 2 * bfeat:
             raise ValueError("a stride-1 unit keeps its width")
 
@@ -56,6 +123,18 @@ class ShuffleUnit(nn.Module):
         self.branch2 = nn.Sequential(nn.Conv2d(inp if stride > 1 else bfeat, bfeat, 1, 1, 0, bias=False), nn.BatchNorm2d(bfeat), nn.ReLU(inplace=True),
                                      dw(bfeat, stride), nn.BatchNorm2d(bfeat), nn.Conv2d(bfeat, bfeat, 1, 1, 0, bias=False), nn.BatchNorm2d(bfeat),
                                      nn.ReLU(inplace=True))
+
+    def pad_(self, inp_p):
+        """hold every tensor of the unit at multiples of 8 channels: ``inp_p`` = the width of the unit's input in memory (stride 2; the halves of
+        a stride-1 unit are branch-wide).  Returns the width of the unit's whole output in memory."""
+        bp = _pad8(self.bfeat)
+        if self.stride > 1:
+            b1 = list(self.branch1)
+            _pad_conv_(b1[0], inp_p, inp_p); _pad_bn_(b1[1], inp_p); _pad_conv_(b1[2], inp_p, bp); _pad_bn_(b1[3], bp)
+        b2 = list(self.branch2)
+        _pad_conv_(b2[0], inp_p if self.stride > 1 else bp, bp); _pad_bn_(b2[1], bp); _pad_conv_(b2[3], bp, bp); _pad_bn_(b2[4], bp)
+        _pad_conv_(b2[5], bp, bp); _pad_bn_(b2[6], bp)
+        return _pad8(2 * self.bfeat)
 
     def branches(self):
         """(branch1, branch2) as plain lists: ``nn.Sequential.__getitem__`` walks an OrderedDict per lookup (~440 lookups per x0_5 step)"""
@@ -108,32 +187,38 @@ def dw_wgrad(dy, x, conv):
     return dst
 
 
-def shuffle_join(a, b, halves):
-    """channel_shuffle(cat(a, b), 2) of two NHWC branches: the full tensor, or (x1, x2) = its channel halves as separate tensors"""
-    N, H, W, Ch = a.shape
+def shuffle_join(a, b, halves, ch=None):
+    """channel_shuffle(cat(a, b), 2) of two NHWC branches: the full tensor, or (x1, x2) = its channel halves as separate tensors.  ``ch``: the real
+    branch width when the tensors are held wider (zero channels past it, see the module docstring)"""
+    N, H, W, Chp = a.shape
+    ch = Chp if ch is None else ch
     assert tuple(b.shape) == tuple(a.shape) and a.dtype == b.dtype and a.is_contiguous() and b.is_contiguous()
     rows = N * H * W
     if halves:
         x1, x2 = torch.empty_like(a), torch.empty_like(a)
-        L.check(L.lib().sat_shuffle_join_t(int(E._is_bf(a)), L.ptr(a), L.ptr(b), None, L.ptr(x1), L.ptr(x2), rows, Ch, L.stream_ptr()), "sat_shuffle_join")
+        L.check(L.lib().sat_shuffle_join_t(int(E._is_bf(a)), L.ptr(a), L.ptr(b), None, L.ptr(x1), L.ptr(x2), rows, ch, Chp, L.stream_ptr()), "sat_shuffle_join")
         return x1, x2
-    full = torch.empty(N, H, W, 2 * Ch, dtype=a.dtype, device=a.device)
-    L.check(L.lib().sat_shuffle_join_t(int(E._is_bf(a)), L.ptr(a), L.ptr(b), L.ptr(full), None, None, rows, Ch, L.stream_ptr()), "sat_shuffle_join")
+    full = torch.empty(N, H, W, _pad8(2 * ch), dtype=a.dtype, device=a.device)
+    L.check(L.lib().sat_shuffle_join_t(int(E._is_bf(a)), L.ptr(a), L.ptr(b), L.ptr(full), None, None, rows, ch, Chp, L.stream_ptr()), "sat_shuffle_join")
     return full
 
 
-def shuffle_split(d):
-    """backward of ``shuffle_join``: d = the full gradient or the pair of its halves -> (da, db)"""
+def shuffle_split(d, ch=None, chp=None):
+    """backward of ``shuffle_join``: d = the full gradient or the pair of its halves -> (da, db); ``ch`` / ``chp``: real / held branch width"""
     if isinstance(d, tuple):
         d1, d2 = d
-        N, H, W, Ch = d1.shape
+        N, H, W, Chp = d1.shape
+        ch = Chp if ch is None else ch
         da, db = torch.empty_like(d1), torch.empty_like(d1)
-        L.check(L.lib().sat_shuffle_split_t(int(E._is_bf(d1)), None, L.ptr(d1), L.ptr(d2), L.ptr(da), L.ptr(db), N * H * W, Ch, L.stream_ptr()), "sat_shuffle_split")
+        L.check(L.lib().sat_shuffle_split_t(int(E._is_bf(d1)), None, L.ptr(d1), L.ptr(d2), L.ptr(da), L.ptr(db), N * H * W, ch, Chp, L.stream_ptr()), "sat_shuffle_split")
         return da, db
-    N, H, W, C2 = d.shape
+    N, H, W, Fp = d.shape
+    ch = Fp // 2 if ch is None else ch
+    chp = ch if chp is None else chp
+    assert Fp == _pad8(2 * ch) or (Fp == 2 * ch and ch == chp)
     d = d.contiguous()
-    da = torch.empty(N, H, W, C2 // 2, dtype=d.dtype, device=d.device); db = torch.empty_like(da)
-    L.check(L.lib().sat_shuffle_split_t(int(E._is_bf(d)), L.ptr(d), None, None, L.ptr(da), L.ptr(db), N * H * W, C2 // 2, L.stream_ptr()), "sat_shuffle_split")
+    da = torch.empty(N, H, W, chp, dtype=d.dtype, device=d.device); db = torch.empty_like(da)
+    L.check(L.lib().sat_shuffle_split_t(int(E._is_bf(d)), L.ptr(d), None, None, L.ptr(da), L.ptr(db), N * H * W, ch, chp, L.stream_ptr()), "sat_shuffle_split")
     return da, db
 
 
@@ -157,7 +242,7 @@ def _unit_fwd(u, xin, training, Wt, halves):
     r.c2, tl = conv(r.src, Wt(b2[0].weight), 1, 0); r.a2, r.s2 = E.bn_fwd(r.c2, b2[1], None, True, training, want_mask=True, tiles=tl)
     r.d2 = dw_fwd(r.a2, b2[3]); r.e2, r.sd2 = E.bn_fwd(r.d2, b2[4], None, False, training)
     r.c3, tl = conv(r.e2, Wt(b2[5].weight), 1, 0); r.b, r.s3 = E.bn_fwd(r.c3, b2[6], None, True, training, want_mask=True, tiles=tl)
-    return r, shuffle_join(a, r.b, halves)
+    return r, shuffle_join(a, r.b, halves, u.bfeat)
 
 
 def _bn_g(grads, bn, res):
@@ -169,7 +254,7 @@ def _unit_bwd(r, dout, grads, Wt, need_dx=True):
     """dout: gradient of the unit's output (whole, or its halves).  Returns the gradient of the unit's input in the form the input had."""
     u = r.u
     b1, b2 = u.branches()
-    da, db = shuffle_split(dout)
+    da, db = shuffle_split(dout, u.bfeat, r.b.shape[-1])
     dc3 = _bn_g(grads, b2[6], E.bn_bwd(db, r.c3, r.b, r.s3, b2[6], True))
     grads[b2[5].weight] = E.conv_wgrad(dc3, r.e2, b2[5].weight, 1, 0, param=b2[5].weight)
     de2, tl = E.conv_dgrad(dc3, Wt(b2[5].weight), r.e2.shape, 1, 0, bn=(r.d2, r.sd2))
@@ -363,9 +448,6 @@ def get_shuffle_encoder(args):
     """Reference get_encoder (model.py:16-63) for the shufflenet_v2 archs (called by ``encoder.get_encoder``)."""
     arch = args.encoder_arch
     repeats, chans = SHUFFLENETS[arch]
-    if any((c // 2) % 8 for c in chans[1:4]):
-        raise ValueError("Encoder not supported : {} (its branches are {} channels wide; the HIP path needs multiples of 8: "
-                         "shufflenet_v2_x0_5 / shufflenet_v2_x1_5)".format(arch, chans[1] // 2))
     ckpt = E._pretrained_file(arch, getattr(args, "pretrained", False))
     # construction order = torchvision's, default initialisation: the RNG stream stays aligned with the reference's
     conv1 = nn.Sequential(nn.Conv2d(3, chans[0], 3, 2, 1, bias=False), nn.BatchNorm2d(chans[0]), nn.ReLU(inplace=True))
@@ -388,6 +470,12 @@ def get_shuffle_encoder(args):
             for prm in mod.parameters():
                 prm.requires_grad = False
         _probe_zero_image(conv1, stages, conv5, int(args.input_size))
+    if any((c // 2) % 8 for c in chans[1:4]):          # x1_0 / x2_0: hold everything at multiples of 8 channels (after initialisation / loading / the probe,
+        width = chans[0]                               # which ran on the original shapes)
+        for stage in stages:
+            for u in stage:
+                width = u.pad_(width)
+        assert width == chans[3], "the last stage's width is a multiple of 8 in every torchvision variant"
     s = int(args.input_size)
     for _ in range(5):                # conv1, maxpool, three stride-2 units: 3x3 windows, stride 2, pad 1
         s = (s + 2 - 3) // 2 + 1

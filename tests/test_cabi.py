@@ -33,7 +33,7 @@ def test_header_symbols_exported(libpath):
     for n in names:
         assert hasattr(lib, n), "libsat_hip.so does not export %s" % n
     lib.sat_abi_version.restype = ctypes.c_int
-    assert lib.sat_abi_version() == 22
+    assert lib.sat_abi_version() == 23
 
 
 def test_binding_covers_header(libpath):

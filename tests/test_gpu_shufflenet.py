@@ -85,6 +85,16 @@ def test_channel_shuffle_join_and_split(S, rows, Ch, dtype):
     assert torch.equal(da.cpu(), a) and torch.equal(db.cpu(), b)
 
 
+def _unpad(g, like):
+    """x1_0 / x2_0 hold their tensors zero-padded to multiples of 8 channels: the leading corner is the reference-shaped tensor, the rest must be 0"""
+    if tuple(g.shape) == tuple(like.shape):
+        return g
+    idx = tuple(slice(0, n) for n in like.shape)
+    rest = g.clone(); rest[idx] = 0
+    assert float(rest.abs().max()) == 0.0, "a padded channel carries a non-zero value"
+    return g[idx]
+
+
 def _zero_gradient_bias(key):
     """The BatchNorm behind a depthwise convolution feeds a 1x1 convolution and another train-mode BatchNorm with no ReLU in between: a shift of
     one of its channels is a per-channel constant after the 1x1 and the next BatchNorm subtracts it - the gradient of its bias is exactly
@@ -94,7 +104,9 @@ def _zero_gradient_bias(key):
 
 @pytest.mark.parametrize("arch,es,px,D,nb", [("shufflenet_v2_x0_5", None, 224, None, 8),          # the reference's defaults: 224 px, no projection (train.py:43-50)
                                              ("shufflenet_v2_x0_5", 3, 64, 32, 8), ("shufflenet_v2_x1_5", None, 128, 64, 4),
-                                             ("shufflenet_v2_x0_5", 14, 256, 512, 4)])
+                                             ("shufflenet_v2_x0_5", 14, 256, 512, 4),
+                                             # 58- / 122-channel branches, held zero-padded at 64 / 128 (encoder_shuffle.py): same acceptance
+                                             ("shufflenet_v2_x1_0", None, 224, None, 8), ("shufflenet_v2_x1_0", 5, 128, 48, 4), ("shufflenet_v2_x2_0", None, 128, 64, 4)])
 def test_whole_shufflenet_encoder_against_oracle(S, arch, es, px, D, nb):
     """fp32 parity mode, forward + every gradient + running statistics + eval mode against the CPU oracle; acceptance as for the ResNets
     (tests/test_gpu_encoder.py::test_whole_encoder_against_oracle): as close to the fp64 run of the oracle as the fp32 CPU run is."""
@@ -130,7 +142,7 @@ def test_whole_shufflenet_encoder_against_oracle(S, arch, es, px, D, nb):
         nrm = max(1e-12, float(exact.norm()))
         if _zero_gradient_bias(k):
             nrm = max(1e-12, float(g64[k[:-4] + "weight"].grad.norm()))
-        err_gpu = float((p.grad.cpu().double() - exact).norm()) / nrm
+        err_gpu = float((_unpad(p.grad, exact).cpu().double() - exact).norm()) / nrm
         err_cpu = float((gref[k].grad.double() - exact).norm()) / nrm
         worst = max(worst, (err_gpu, err_cpu, k))
         slack = 5e-3 if px >= 128 else 2e-2          # one ReLU decision within fp32 rounding of zero taken the other way (see the ResNet test)
@@ -147,7 +159,8 @@ def test_whole_shufflenet_encoder_against_oracle(S, arch, es, px, D, nb):
         close(enc(img.cuda()), ref(img.clone()), 2e-4, "eval annotations")
 
 
-@pytest.mark.parametrize("arch,es,px,D,nb", [("shufflenet_v2_x0_5", None, 224, None, 8), ("shufflenet_v2_x0_5", 7, 256, 256, 8), ("shufflenet_v2_x1_5", None, 128, 64, 8)])
+@pytest.mark.parametrize("arch,es,px,D,nb", [("shufflenet_v2_x0_5", None, 224, None, 8), ("shufflenet_v2_x0_5", 7, 256, 256, 8), ("shufflenet_v2_x1_5", None, 128, 64, 8),
+                                             ("shufflenet_v2_x1_0", None, 224, None, 8)])
 def test_whole_shufflenet_encoder_bf16_storage_against_the_rounding_oracle(S, arch, es, px, D, nb):
     """bf16 mode against the CPU oracle that rounds to bf16 at the same storage points (oracle/bf16_emulation.py).  A freshly initialised
     ShuffleNetV2 amplifies any perturbation by ~1.2x per unit (16 units: a 1e-6 relative change of the image moves the annotations by 2e-5;
@@ -184,8 +197,9 @@ def test_whole_shufflenet_encoder_bf16_storage_against_the_rounding_oracle(S, ar
     for k, p in enc.named_parameters():          # exactly-zero gradients: rounding noise on both sides, bounded by the emulation's
         if _zero_gradient_bias(k):
             assert float(p.grad.norm()) <= 4 * float(gemu[k].grad.norm()) + 1e-3 * float(gemu[k[:-4] + "weight"].grad.norm()), k
-    rows = sorted(((l2(p.grad, g32[k].grad) - 2 * l2(gemu[k].grad, g32[k].grad), l2(p.grad, g32[k].grad), l2(gemu[k].grad, g32[k].grad), l2(p.grad, gemu[k].grad), k)
-                   for k, p in enc.named_parameters() if not _zero_gradient_bias(k)), reverse=True)
+    hip = {k: _unpad(p.grad, g32[k].grad) for k, p in enc.named_parameters()}
+    rows = sorted(((l2(hip[k], g32[k].grad) - 2 * l2(gemu[k].grad, g32[k].grad), l2(hip[k], g32[k].grad), l2(gemu[k].grad, g32[k].grad), l2(hip[k], gemu[k].grad), k)
+                   for k in hip if not _zero_gradient_bias(k)), reverse=True)
     print("bf16 shufflenet: (HIP vs fp32, emulation vs fp32, HIP vs emulation) worst margins", [(round(a, 4), round(b, 4), round(c, 4), k) for _, a, b, c, k in rows[:4]])
     assert rows[0][0] <= 2e-2, rows[:4]
     sd, sr = enc.state_dict(), ref.state_dict()
@@ -266,12 +280,42 @@ def test_frozen_trunk_trains_only_the_projection(S):
             assert p.grad is None, k
 
 
-def test_unsupported_widths_are_refused(S):
-    from oracle import sat_oracle as O
-    from sat_amd import encoder as E
-    for arch in ("shufflenet_v2_x1_0", "shufflenet_v2_x2_0"):
-        with pytest.raises(ValueError, match="Encoder not supported"):
-            E.get_encoder(O.default_hparams(encoder_arch=arch, encoder_dim=None, input_size=224))
+def test_padded_widths_stay_exactly_zero_through_training():
+    """shufflenet_v2_x1_0 (58 / 116 / 232-channel branches held at 64 / 120 / 232): after optimizer steps with weight decay and gradient clipping
+    every padded entry of every parameter, gradient and Adam moment is still exactly 0, the state dict has the reference's shapes and equals
+    the leading corner of the held tensors, and a model rebuilt from that state dict computes the same loss bit for bit."""
+    model, _, hp = _make_model(dict(encoder_arch="shufflenet_v2_x1_0", weight_decay=1e-2, opt="adamw", encoder_lr=1e-3, clip_value=1.0, grad_clip="norm",
+                                    encoder_finetune_after=1))          # > 0: the encoder's parameters are in the optimizer (model.py:777, F10)
+    model.set_precision("bf16")
+    opt = model.configure_optimizers()
+    opt = opt[0][0] if isinstance(opt, tuple) else opt
+    img, caps, lengths = _batch(hp, B=4)
+    b = (img.cuda(), caps.cuda(), lengths)
+    for it in range(4):
+        opt.zero_grad(set_to_none=True)
+        model.training_step(b, it)["loss"].backward()
+        opt.step()
+    padded = 0
+    for mod in model.encoder.modules():
+        for name, shape in mod.__dict__.get("_sat_real_shapes", {}).items():
+            t = getattr(mod, name)
+            padded += 1
+            for what, full in (("value", t), ("gradient", getattr(t, "grad", None)), ("exp_avg", opt.state.get(t, {}).get("exp_avg")), ("exp_avg_sq", opt.state.get(t, {}).get("exp_avg_sq"))):
+                if full is None:
+                    continue
+                rest = full.clone(); rest[tuple(slice(0, n) for n in shape)] = 0
+                assert float(rest.abs().max()) == 0.0, (name, what)
+    assert padded > 100
+    assert any(p is q for g in opt.param_groups for p in g["params"] for q in model.encoder.parameters())
+    sd = model.state_dict()
+    assert tuple(sd["encoder.3.0.branch1.2.weight"].shape) == (58, 24, 1, 1) and tuple(sd["encoder.4.1.branch2.3.weight"].shape) == (116, 1, 3, 3)
+    twin, _, _ = _make_model(dict(encoder_arch="shufflenet_v2_x1_0"), seed=7)
+    twin.load_state_dict(sd)
+    twin.set_precision("bf16")
+    model.eval(); twin.eval()
+    with torch.no_grad():
+        l1, l2 = model.training_step(b, 0)["loss"], twin.training_step(b, 0)["loss"]
+    assert torch.equal(l1, l2)
 
 
 # ----------------------------------------------------------------------------- the whole train step behind the reference's SAT surface
@@ -297,11 +341,11 @@ def _batch(hp, B=6, R=3, T=9, seed=5):
     return img, torch.from_numpy(caps), torch.from_numpy(lengths)
 
 
-@pytest.mark.parametrize("eps,D", [(1.0, None), (0.0, 32)])
-def test_training_step_with_the_cli_default_encoder_matches_oracle(eps, D):
+@pytest.mark.parametrize("eps,D,arch", [(1.0, None, "shufflenet_v2_x0_5"), (0.0, 32, "shufflenet_v2_x0_5"), (1.0, 32, "shufflenet_v2_x1_0")])
+def test_training_step_with_the_cli_default_encoder_matches_oracle(eps, D, arch):
     """SAT(encoder_arch="shufflenet_v2_x0_5") - the reference's defaults (train.py:43, :50: no projection, encoder_dim = 1024) and the
     projected variant - one training_step against the CPU oracle: loss, accuracy, packed logits, attention maps, every gradient."""
-    model, oracle, hp = _make_model(dict(encoder_dim=D, decoder_tf="always" if eps == 1.0 else None))
+    model, oracle, hp = _make_model(dict(encoder_arch=arch, encoder_dim=D, decoder_tf="always" if eps == 1.0 else None))
     assert model.hp.encoder_dim == (1024 if D is None else D)
     img, caps, lengths = _batch(hp)
     loss_o, out_o = oracle.step_loss(img, caps, lengths, eps)
@@ -321,7 +365,7 @@ def test_training_step_with_the_cli_default_encoder_matches_oracle(eps, D):
         assert p.grad is not None, k
         ref = og[k].double()
         nrm = float(og[k[:-4] + "weight"].double().norm()) if _zero_gradient_bias(k) else float(ref.norm())
-        e = float((p.grad.cpu().double() - ref).norm()) / max(1e-9, nrm)
+        e = float((_unpad(p.grad, og[k]).cpu().double() - ref).norm()) / max(1e-9, nrm)
         worst = max(worst, (e, k))
         assert e <= 2e-2, "%s: relative L2 gradient error %.3e" % (k, e)        # fp32 through a batch-6 net that ends in a 2 x 2 map
     print("worst gradient error", worst)

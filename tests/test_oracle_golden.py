@@ -233,9 +233,16 @@ def test_shufflenet_structure_matches_the_reference_summary():
     assert hp2.encoder_dim == 1024 and keys == list(enc.state_dict().keys())
     assert all(torch.equal(v, ref.state_dict()[k]) for k, v in enc.state_dict().items() if "running" not in k and "num_batches" not in k)
     assert all(bool(((v - 0.9).abs() < 1e-6).all()) for k, v in enc.state_dict().items() if "running_var" in k)      # the zero-image probe
-    for arch in ("shufflenet_v2_x1_0", "shufflenet_v2_x2_0"):                   # 58- / 122-channel branches: refused, not approximated
-        with pytest.raises(ValueError, match="Encoder not supported"):
-            E.get_encoder(O.default_hparams(encoder_arch=arch, encoder_dim=None, input_size=224))
+    for arch in ("shufflenet_v2_x1_0", "shufflenet_v2_x2_0"):                   # 58- / 122-channel branches are HELD at 64 / 128; the state dict keeps the reference's shapes
+        torch.manual_seed(5)
+        ref = O.build_encoder(O.default_hparams(encoder_arch=arch, encoder_dim=None, input_size=224))
+        torch.manual_seed(5)
+        enc = E.get_encoder(O.default_hparams(encoder_arch=arch, encoder_dim=None, input_size=224))
+        sd, so = enc.state_dict(), ref.state_dict()
+        assert list(sd) == list(so) and all(sd[k].shape == so[k].shape and torch.equal(sd[k], so[k]) for k in sd), arch
+        assert any(p.shape[0] % 8 == 0 and p.shape[0] != so[k].shape[0] for k, p in enc.named_parameters()), arch
+        enc.load_state_dict({k: v + 1 if v.dtype.is_floating_point else v for k, v in so.items()})
+        assert all(torch.equal(v, so[k] + 1 if v.dtype.is_floating_point else so[k]) for k, v in enc.state_dict().items()), arch
 
 
 def test_mobilenet_v2_structure_matches_the_reference_summary():
