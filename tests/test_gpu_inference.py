@@ -31,12 +31,14 @@ def test_g7_beam_search_on_hip(golden_dir):
         check_beam_against_golden(g, ci, ra, *out, tol=1e-4)
 
 
-def test_caption_end_to_end_matches_oracle():
-    """caption(img): eval-mode encoder (running statistics) + beam search, C5-style (beamk 5) on a small ResNet-18 model."""
+@pytest.mark.parametrize("arch,encoder_dim,es", [("resnet18", 32, 3), ("shufflenet_v2_x0_5", None, None), ("shufflenet_v2_x1_0", 32, None), ("mobilenet_v2", 48, 3)])
+def test_caption_end_to_end_matches_oracle(arch, encoder_dim, es):
+    """caption(img): eval-mode encoder (running statistics) + beam search, C5-style (beamk 5) on small models of every encoder family (the
+    reference CLI's default encoder without projection: 1024-dimensional annotations)."""
     import sat_amd  # noqa: F401
     from sat_amd import model as M
     from oracle import prng, sat_oracle as O
-    over = dict(encoder_arch="resnet18", encoder_dim=32, input_size=64, encoder_size=3, vocab_size=60, embed_dim=24, attention_dim=16,
+    over = dict(encoder_arch=arch, encoder_dim=encoder_dim, input_size=64, encoder_size=es, vocab_size=60, embed_dim=24, attention_dim=16,
                 decoder_dim=40, deep_output=True)
     torch.manual_seed(11)
     model = M.SAT(**vars(O.default_hparams(**over))).cuda()
