@@ -9,15 +9,13 @@ ReLU6 = ``relu = 2`` of the BatchNorm apply kernels (clamp to [0, 6]; the mask b
 residual add happens inside the last BatchNorm's apply kernel and, backward, inside the data-gradient launch of the expand convolution
 (accumulating into the block's output gradient in place).  Every channel count of the width-1.0 network is a multiple of 8.
 """
-import ctypes as C
-
 import torch
 import torch.nn.functional as F
 from torch import nn
 
 from . import _lib as L
 from . import encoder as E
-from .encoder_shuffle import dw_dgrad, dw_fwd, dw_wgrad
+from .encoder_shuffle import dw_dgrad, dw_fwd, dw_wgrad, stem3x3_fwd, stem3x3_wgrad
 
 #: torchvision's inverted_residual_setting: (expand ratio t, output channels c, repeats n, stride s)
 SETTING = ((1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2), (6, 96, 3, 1), (6, 160, 3, 2), (6, 320, 1, 1))
@@ -112,7 +110,6 @@ class MobileNetEncoderFn(torch.autograd.Function):
 
     @staticmethod
     def _forward(ctx, img, enc, *params):
-        lib = L.lib()
         L.require_gpu(img, *params)
         if img.dim() != 4 or img.shape[1] != 3 or img.dtype != torch.float32:
             raise ValueError("encoder input must be (B,3,H,W) fp32 in [0,1]")
@@ -120,27 +117,11 @@ class MobileNetEncoderFn(torch.autograd.Function):
         training = enc.training
         E._defer[0] = True; del E._tracked[:]
         bf = enc.precision == "bf16"
-        adt = E.BF16 if bf else torch.float32
-        N, _, H, W = img.shape
-        st = L.stream_ptr()
         t = {}
         Wt = E._weight_reader(bf)
         conv = E.conv_fwd_stats if training else (lambda *a: (E.conv_fwd(*a), None))
-        mean = (C.c_float * 3)(*enc[0].mean); std = (C.c_float * 3)(*enc[0].std)
         (conv1, bn1), blocks, (convL, bnL) = enc.layers()
-        K = conv1.out_channels
-        w3 = E._krsc(conv1.weight)                                                  # (32,3,3,3), memory K,3,3,3(c)
-        cpad = 8 if bf else 4
-        x0 = torch.empty(N, H, W, cpad, dtype=adt, device=img.device)
-        wp = torch.empty(K, cpad, 3, 3, dtype=adt, device=img.device).contiguous(memory_format=torch.channels_last)
-        if bf:
-            L.check(lib.sat_image_normalize_nhwc8_bf16(L.ptr(img), L.ptr(x0), N, H, W, mean, std, st), "sat_image_normalize_nhwc8_bf16")
-            L.check(lib.sat_stem_filter_pad(L.ptr(w3), L.ptr(wp), K * 9, st), "sat_stem_filter_pad")
-        else:
-            L.check(lib.sat_image_normalize_nhwc4(L.ptr(img), L.ptr(x0), N, H, W, mean, std, st), "sat_image_normalize_nhwc4")
-            L.check(lib.sat_pad_channels_3to4(L.ptr(w3), L.ptr(wp), K * 9, 0, st), "sat_pad_channels_3to4")
-        t["x0"], t["wp"] = x0, wp
-        t["c0"], tl = conv(x0, wp, 2, 1)
+        t["x0"], t["wp"], t["c0"], tl = stem3x3_fwd(enc[0], conv1, img, bf, training)
         t["a0"], t["s0"] = E.bn_fwd(t["c0"], bn1, None, RELU6, training, want_mask=True, tiles=tl)
         x = t["a0"]
         recs = []
@@ -161,9 +142,7 @@ class MobileNetEncoderFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dann):
-        lib = L.lib()
         enc, t, recs, Wt, bf = ctx.enc, ctx.t, ctx.recs, ctx.Wt, ctx.bf
-        st = L.stream_ptr()
         grads = {}
         d = E._head_bwd(enc, t, dann, grads, Wt, bf)
         if enc.trunk_trainable:
@@ -174,14 +153,7 @@ class MobileNetEncoderFn(torch.autograd.Function):
             for r in reversed(recs):
                 d = _block_bwd(r, d, grads, Wt)
             dc0 = _bn_g(grads, bn1, E.bn_bwd(d, t["c0"], t["a0"], t["s0"], bn1, RELU6))
-            dwp = E.conv_wgrad(dc0, t["x0"], t["wp"], 2, 1)                          # (K,cpad,3,3) view of K,3,3,{4,8} fp32 memory
-            dw3 = L.grad_buffer(conv1.weight)
-            dst = dw3 if dw3.permute(0, 2, 3, 1).is_contiguous() else torch.empty(conv1.weight.shape, dtype=torch.float32, device=d.device).contiguous(memory_format=torch.channels_last)
-            if bf:
-                L.check(lib.sat_stem_filter_grad_unpad(L.ptr(dwp), L.ptr(dst), conv1.out_channels * 9, st), "sat_stem_filter_grad_unpad")
-            else:
-                L.check(lib.sat_pad_channels_3to4(L.ptr(dwp), L.ptr(dst), conv1.out_channels * 9, 1, st), "sat_pad_channels_3to4")
-            grads[conv1.weight] = dst
+            grads[conv1.weight] = stem3x3_wgrad(dc0, t["x0"], t["wp"], conv1, bf)
         ctx.t = ctx.recs = ctx.Wt = None
         return (None, None, *[grads.get(p) if p.requires_grad else None for p in ctx.params])
 

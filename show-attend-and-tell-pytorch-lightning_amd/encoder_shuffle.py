@@ -276,6 +276,43 @@ def _unit_bwd(r, dout, grads, Wt, need_dx=True):
     return E.conv_dgrad(dc2, Wt(b2[0].weight), r.src.shape, 1, 0, out=dx, accumulate=True)
 
 
+def stem3x3_fwd(norm, conv1, img, bf, training):
+    """Normalize + NCHW -> NHWC with the 3 image channels padded to 4 (fp32) / 8 (bf16), then the 3x3 stride-2 stem convolution of shufflenet_v2 /
+    mobilenet_v2.  Returns (padded image, padded filter, convolution output, its BatchNorm statistics tiles or None)."""
+    lib = L.lib()
+    st = L.stream_ptr()
+    N, _, H, W = img.shape
+    adt = E.BF16 if bf else torch.float32
+    mean = (C.c_float * 3)(*norm.mean); std = (C.c_float * 3)(*norm.std)
+    K = conv1.out_channels
+    w3 = E._krsc(conv1.weight)                                                  # (K,3,3,3), memory K,3,3,3(c)
+    cpad = 8 if bf else 4
+    x0 = torch.empty(N, H, W, cpad, dtype=adt, device=img.device)
+    wp = torch.empty(K, cpad, 3, 3, dtype=adt, device=img.device).contiguous(memory_format=torch.channels_last)
+    if bf:
+        L.check(lib.sat_image_normalize_nhwc8_bf16(L.ptr(img), L.ptr(x0), N, H, W, mean, std, st), "sat_image_normalize_nhwc8_bf16")
+        L.check(lib.sat_stem_filter_pad(L.ptr(w3), L.ptr(wp), K * 9, st), "sat_stem_filter_pad")
+    else:
+        L.check(lib.sat_image_normalize_nhwc4(L.ptr(img), L.ptr(x0), N, H, W, mean, std, st), "sat_image_normalize_nhwc4")
+        L.check(lib.sat_pad_channels_3to4(L.ptr(w3), L.ptr(wp), K * 9, 0, st), "sat_pad_channels_3to4")
+    c0, tl = E.conv_fwd_stats(x0, wp, 2, 1) if training else (E.conv_fwd(x0, wp, 2, 1), None)
+    return x0, wp, c0, tl
+
+
+def stem3x3_wgrad(dc0, x0, wp, conv1, bf):
+    """gradient of the (K,3,3,3) stem filter from the gradient of the convolution output (through the padded filter's gradient)"""
+    lib = L.lib()
+    st = L.stream_ptr()
+    dwp = E.conv_wgrad(dc0, x0, wp, 2, 1)                          # (K,cpad,3,3) view of K,3,3,{4,8} fp32 memory
+    dw3 = L.grad_buffer(conv1.weight)
+    dst = dw3 if dw3.permute(0, 2, 3, 1).is_contiguous() else torch.empty(conv1.weight.shape, dtype=torch.float32, device=dc0.device).contiguous(memory_format=torch.channels_last)
+    if bf:
+        L.check(lib.sat_stem_filter_grad_unpad(L.ptr(dwp), L.ptr(dst), conv1.out_channels * 9, st), "sat_stem_filter_grad_unpad")
+    else:
+        L.check(lib.sat_pad_channels_3to4(L.ptr(dwp), L.ptr(dst), conv1.out_channels * 9, 1, st), "sat_pad_channels_3to4")
+    return dst
+
+
 class ShuffleEncoderFn(torch.autograd.Function):
     """img (B,3,H,W) fp32 in [0,1] -> annotations (B,D,h,w) fp32 (NHWC memory); ``enc.precision`` as in ``encoder.EncoderFn``."""
 
@@ -297,25 +334,11 @@ class ShuffleEncoderFn(torch.autograd.Function):
         E._defer[0] = True; del E._tracked[:]
         bf = enc.precision == "bf16"
         adt = E.BF16 if bf else torch.float32
-        N, _, H, W = img.shape
         st = L.stream_ptr()
         t = {}
         Wt = E._weight_reader(bf)
-        mean = (C.c_float * 3)(*enc[0].mean); std = (C.c_float * 3)(*enc[0].std)
         conv1, bn1, conv5, bn5, units = enc.layers()
-        K = conv1.out_channels
-        w3 = E._krsc(conv1.weight)                                                  # (K,3,3,3), memory K,3,3,3(c)
-        cpad = 8 if bf else 4
-        x0 = torch.empty(N, H, W, cpad, dtype=adt, device=img.device)
-        wp = torch.empty(K, cpad, 3, 3, dtype=adt, device=img.device).contiguous(memory_format=torch.channels_last)
-        if bf:
-            L.check(lib.sat_image_normalize_nhwc8_bf16(L.ptr(img), L.ptr(x0), N, H, W, mean, std, st), "sat_image_normalize_nhwc8_bf16")
-            L.check(lib.sat_stem_filter_pad(L.ptr(w3), L.ptr(wp), K * 9, st), "sat_stem_filter_pad")
-        else:
-            L.check(lib.sat_image_normalize_nhwc4(L.ptr(img), L.ptr(x0), N, H, W, mean, std, st), "sat_image_normalize_nhwc4")
-            L.check(lib.sat_pad_channels_3to4(L.ptr(w3), L.ptr(wp), K * 9, 0, st), "sat_pad_channels_3to4")
-        t["x0"], t["wp"] = x0, wp
-        t["c0"], tl = E.conv_fwd_stats(x0, wp, 2, 1) if training else (E.conv_fwd(x0, wp, 2, 1), None)
+        t["x0"], t["wp"], t["c0"], tl = stem3x3_fwd(enc[0], conv1, img, bf, training)
         if training:          # bn + relu + maxpool in one pass
             x, t["s0"] = E.stem_tail_fwd(t["c0"], bn1, tiles=tl)
         else:
@@ -343,9 +366,7 @@ class ShuffleEncoderFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dann):
-        lib = L.lib()
         enc, t, recs, Wt, bf = ctx.enc, ctx.t, ctx.recs, ctx.Wt, ctx.bf
-        st = L.stream_ptr()
         grads = {}
         d = E._head_bwd(enc, t, dann, grads, Wt, bf)
         if enc.trunk_trainable:
@@ -356,14 +377,7 @@ class ShuffleEncoderFn(torch.autograd.Function):
             for r in reversed(recs):
                 d = _unit_bwd(r, d, grads, Wt)
             dc0 = _bn_g(grads, bn1, E.stem_tail_bwd(d, t["c0"], t["s0"], bn1))
-            dwp = E.conv_wgrad(dc0, t["x0"], t["wp"], 2, 1)                          # (K,cpad,3,3) view of K,3,3,{4,8} fp32 memory
-            dw3 = L.grad_buffer(conv1.weight)
-            dst = dw3 if dw3.permute(0, 2, 3, 1).is_contiguous() else torch.empty(conv1.weight.shape, dtype=torch.float32, device=d.device).contiguous(memory_format=torch.channels_last)
-            if bf:
-                L.check(lib.sat_stem_filter_grad_unpad(L.ptr(dwp), L.ptr(dst), conv1.out_channels * 9, st), "sat_stem_filter_grad_unpad")
-            else:
-                L.check(lib.sat_pad_channels_3to4(L.ptr(dwp), L.ptr(dst), conv1.out_channels * 9, 1, st), "sat_pad_channels_3to4")
-            grads[conv1.weight] = dst
+            grads[conv1.weight] = stem3x3_wgrad(dc0, t["x0"], t["wp"], conv1, bf)
         ctx.t = ctx.recs = ctx.Wt = None
         return (None, None, *[grads.get(p) if p.requires_grad else None for p in ctx.params])
 
