@@ -45,6 +45,31 @@ __global__ __launch_bounds__(256) void k_reglayout(const bf16_t* __restrict__ a,
     }
 }
 
+// pattern 2: after one cross-half exchange every lane owns 16 contiguous bytes: row = lane % 32, columns 16 * g + 8 * (lane / 32) + {0..7}
+template <int NW, int JOIN>
+__global__ __launch_bounds__(256) void k_reglayout16(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ c, long M, int N) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ncg = N / NW;
+    const long nblk = (M / 32) * ncg;
+    for (long blk = (long)blockIdx.x * 4 + wave; blk < nblk; blk += (long)gridDim.x * 4) {
+        const long mb = blk / ncg; const int cg = (int)(blk - mb * ncg);
+        const long row = mb * 32 + (lane & 31);
+        const int col0 = cg * NW + 8 * (lane >> 5);
+        uint4 va[NW / 16], vb[NW / 16];
+#pragma unroll
+        for (int g = 0; g < NW / 16; ++g) {
+            va[g] = *reinterpret_cast<const uint4*>(a + row * N + col0 + 16 * g);
+            if (JOIN) vb[g] = *reinterpret_cast<const uint4*>(b + row * N + col0 + 16 * g);
+        }
+#pragma unroll
+        for (int g = 0; g < NW / 16; ++g) {
+            uint4 o = va[g];
+            if (JOIN) { o.x ^= vb[g].x; o.y ^= vb[g].y; o.z ^= vb[g].z; o.w ^= vb[g].w; }
+            *reinterpret_cast<uint4*>(c + row * N + col0 + 16 * g) = o;
+        }
+    }
+}
+
 int main() {
     const long M = 524288; const int N = 256;
     const long bytes = M * N * 2;
@@ -66,5 +91,8 @@ int main() {
     run("register layout, NW = 128: c = a ^ b (3 streams)", [&] { hipLaunchKernelGGL((k_reglayout<128, 1>), dim3(256 * 8), dim3(256), 0, 0, a, b, c, M, N); }, 3.0 * bytes);
     run("register layout, NW = 256: c = a ^ b (3 streams)", [&] { hipLaunchKernelGGL((k_reglayout<256, 1>), dim3(256 * 8), dim3(256), 0, 0, a, b, c, M, N); }, 3.0 * bytes);
     run("register layout, NW = 64: c = a ^ b (3 streams)", [&] { hipLaunchKernelGGL((k_reglayout<64, 1>), dim3(256 * 8), dim3(256), 0, 0, a, b, c, M, N); }, 3.0 * bytes);
+    run("register layout + exchange (16 B / lane), NW = 128, 3 streams", [&] { hipLaunchKernelGGL((k_reglayout16<128, 1>), dim3(256 * 8), dim3(256), 0, 0, a, b, c, M, N); }, 3.0 * bytes);
+    run("register layout + exchange (16 B / lane), NW = 256, 3 streams", [&] { hipLaunchKernelGGL((k_reglayout16<256, 1>), dim3(256 * 8), dim3(256), 0, 0, a, b, c, M, N); }, 3.0 * bytes);
+    run("register layout + exchange, NW = 128, 3 streams, 16 blocks / CU", [&] { hipLaunchKernelGGL((k_reglayout16<128, 1>), dim3(256 * 16), dim3(256), 0, 0, a, b, c, M, N); }, 3.0 * bytes);
     return 0;
 }
