@@ -300,3 +300,46 @@ def test_replayed_step_with_the_mobilenet_encoder_is_bit_equal_to_the_eager_step
         for (k, x), (_, y) in zip(eager.state_dict().items(), graphed.state_dict().items()):
             assert torch.equal(x, y), "step %d: %s differs" % (it, k)
     assert step.stats["captured"] >= 2 and step.stats["replayed"] >= 3, dict(step.stats)
+
+
+@pytest.mark.parametrize("arch", ["shufflenet_v2_x0_5", "shufflenet_v2_x1_0", "mobilenet_v2"])
+def test_small_encoder_steps_at_the_cli_defaults_are_reproducible_bit_for_bit(arch):
+    """The reference CLI's defaults (224 px, no projection, decoder_tf None, plain output layer) with 32 images x 5 captions in bf16 mode, trainable
+    encoder: two identical models stepped twice on the same batch agree bit for bit in loss, every gradient and every updated tensor (the
+    depthwise filter gradients, like every other reduction on the path, add their partial sums in a fixed order), recycled device memory poisoned
+    in between; losses finite and near ln(V) at the start; gradients finite."""
+    import math
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    import sat_amd  # noqa: F401
+    from sat_amd import model as M
+    hp, T, B, R = bench.hparams("cli")
+    hp.update(encoder_arch=arch, decoder_tf=None, deep_output=False)
+    img, caps, lengths = bench.synthetic_batch(B, R, T, hp["vocab_size"], 1234, True, px=hp["input_size"])
+    img, caps = img.cuda(), caps.cuda()
+
+    def run():
+        torch.manual_seed(42)
+        model = M.SAT(**hp).cuda().train(); model.set_precision("bf16")
+        model.__dict__["_sat_global_step"] = 2
+        opt = model.configure_optimizers()
+        losses = []
+        for _ in range(2):
+            opt.zero_grad(set_to_none=True)
+            out = model.training_step((img.clone(), caps, lengths), 0)
+            out["loss"].backward()
+            grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+            opt.step()
+            losses.append(out["loss"].detach().clone())
+        return losses, grads, {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+    l1, g1, s1 = run()
+    junk = torch.full((1 << 26,), float("nan"), device="cuda"); del junk           # recycled blocks now hold NaN
+    l2, g2, s2 = run()
+    assert all(torch.equal(a, b) for a, b in zip(l1, l2)), (l1, l2)
+    assert [k for k in g1 if not torch.equal(g1[k], g2[k])] == []
+    assert [k for k in s1 if not torch.equal(s1[k], s2[k])] == []
+    assert all(math.isfinite(float(l)) for l in l1) and abs(float(l1[0]) - math.log(hp["vocab_size"])) < 1.0
+    assert all(bool(torch.isfinite(v).all()) for v in g1.values()) and len(g1) > 150
+    assert any(k.startswith("encoder.") for k in g1)
