@@ -168,7 +168,7 @@ class FusedOptimizer(torch.optim.Optimizer):
                     None if mv_key is None else tuple(mv_key))
         if mv_key is not None and fast_key == getattr(self, "_fast_key", None) and self._fast_ok:
             self.fast_path_steps = getattr(self, "fast_path_steps", 0) + 1
-            torch._foreach_add_(self._fast_steps, 1)
+            self._fast_steps += 1                      # every state["step"] is a view of this one tensor (see below)
             step = float(self._fast_steps[0])
             for q in self._fast_shadowed:
                 q._sat_shadow_version = q._version
@@ -204,11 +204,16 @@ class FusedOptimizer(torch.optim.Optimizer):
             if t.shadow_bf16:
                 p._sat_shadow_version = p._version
             entries[i] = (p, group, grad)              # keep a re-laid-out gradient alive until the launch
-        torch._foreach_add_(steps, 1)                  # one call instead of a tensor add + a float() per parameter (0.8 ms of host time at C2)
-        sv = torch.stack(steps)
+        # torch's state layout keeps one 0-dim "step" tensor per parameter; here they are views of ONE host tensor, so the fast path advances all
+        # of them with a single add (a foreach add over ~170 host scalars was 0.4 ms a step).  state_dict() / load_state_dict() see ordinary
+        # 0-dim tensors; after a load the addresses in the fast key change and this path re-gathers them.
+        sv = torch.stack(steps) + 1
         step = float(sv[0])
         if float(sv.min()) != float(sv.max()):
-            raise ValueError("FusedOptimizer: parameters are at different step counts %s" % sorted(set(sv.tolist())))
+            raise ValueError("FusedOptimizer: parameters are at different step counts %s" % sorted(set((sv - 1).tolist())))
+        for i, (p, _, _) in enumerate(entries):
+            self.state[p]["step"] = sv[i]
+        steps = sv
         raw = host.numpy().tobytes()
         if raw != self._uploaded:                      # pointers / lr / weight decay changed since the table on the device was written
             self._dev.copy_(host, non_blocking=True)
