@@ -357,7 +357,12 @@ static int launch_gemm_bf16_tile(const GemmArgs& g, int tile_mode, hipStream_t s
     const int KB = 64;
     int BMt = 64;
     static const long tiles128_min = getenv("SAT_TILES128_MIN") ? atol(getenv("SAT_TILES128_MIN")) : 192;
-    if ((long)cdiv(g.M, 128) * cdiv(g.N, 128) >= tiles128_min && g.M >= 128 && g.N >= 128) BMt = 128;
+    const long tiles128 = (long)cdiv(g.M, 128) * cdiv(g.N, 128);
+    if (tiles128 >= tiles128_min && g.M >= 128 && g.N >= 128) BMt = 128;
+    // short reductions over a grid of less than two 128-tile rounds of the chip (the per-time-step vocabulary projection of decoder_tf=None:
+    // 640 x 6400, K = 256 -> 250 tiles): one workgroup per CU walks load - 4 k-tiles - 64 KB store alone; 64-wide tiles put four on a CU
+    // (26.8 -> 15.1 us)
+    if (BMt == 128 && tiles128 < 512 && g.K <= 256 && !g.slab) BMt = 64;
     // long reductions (weight gradients): split-K supplies the parallelism, so keep the 64x64-per-wave tile
     if (g.slab && g.M >= 128 && g.N >= 128 && g.K >= 64 * KB) BMt = 128;
     if (tile_mode) BMt = tile_mode;

@@ -9,6 +9,8 @@ import sat_amd  # noqa
 from sat_amd import _lib, model as M
 
 hp, T, B, R = bench.hparams("c2")
+if os.environ.get("TF") == "none":
+    hp["decoder_tf"] = None
 torch.manual_seed(42)
 model = M.SAT(**hp).cuda().train(); model.set_precision("bf16")
 model.__dict__["_sat_global_step"] = 2
@@ -35,3 +37,7 @@ for e in ent:
     tot += e["total_ms"] / n
     print("%-62s %4d %8.1f %7.1f %7.0f %7.1f %7.1f" % (e["name"], e["launches"] // n, us, fl / us / 1e6, by / us / 1e3, by / 4.5e6, fl / 2.5e9))
 print("GEMM total per step: %.2f ms" % tot)
+if os.environ.get("ALL") == "1":          # every other instrumented family
+    for e in ent:
+        if e["name"].startswith("gemm"): continue
+        print("%-62s %4d %8.1f us  %7.3f ms/step" % (e["name"], e["launches"] // n, e["total_ms"] * 1e3 / e["launches"], e["total_ms"] / n))
