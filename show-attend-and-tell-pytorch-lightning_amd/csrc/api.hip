@@ -40,6 +40,8 @@ int sat_debug_option(const char* name, int32_t value) {
     if (!strcmp(name, "wide_tiles")) { dev_switch(SW_WIDE_TILES) = value; return SAT_OK; }
     if (!strcmp(name, "glds_tile")) { glds_force_tile() = value; return SAT_OK; }
     if (!strcmp(name, "glds_stages8")) { glds_stages8() = value; return SAT_OK; }
+    if (!strcmp(name, "glds_tall_k")) { glds_tall_k() = value; return SAT_OK; }
+    if (!strcmp(name, "glds_tall_conv")) { glds_tall_conv() = value; return SAT_OK; }
     if (!strcmp(name, "tile_override")) { gemm_tile_override() = value; return SAT_OK; }
     return fail(SAT_EINVAL, "debug_option: unknown option %s", name);
 }

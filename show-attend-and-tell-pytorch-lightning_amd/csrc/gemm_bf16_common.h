@@ -538,6 +538,8 @@ __device__ __forceinline__ void xcd_tile(int& bx, int& by, int& bz, int y_fastes
 int launch_gemm_glds(const BArgs& k, int amode, int bmode, int c_bf16, int BMt, hipStream_t st, int* bm_used = nullptr);
 int& glds_force_tile();      // dev switches (sat_debug_option)
 int& glds_stages8();
+int& glds_tall_k();
+int& glds_tall_conv();
 int& glds_ablate();
 int& gemm_tile_override();
 

@@ -33,6 +33,8 @@ static int rung_tiles(const BArgs& k, int tile, hipStream_t st, int* bm_used) {
 
 int& glds_force_tile() { static int v = getenv("SAT_GLDS_TILE") ? atoi(getenv("SAT_GLDS_TILE")) : -1; return v; }
 int& glds_ablate() { static int v = 0; return v; }
+int& glds_tall_k() { static int v = getenv("SAT_GLDS_TALL_K") ? atoi(getenv("SAT_GLDS_TALL_K")) : 1 << 30; return v; }
+int& glds_tall_conv() { static int v = getenv("SAT_GLDS_TALL_CONV") ? atoi(getenv("SAT_GLDS_TALL_CONV")) : 1152; return v; }
 int& glds_stages8() { static int v = getenv("SAT_GLDS_STAGES8") ? atoi(getenv("SAT_GLDS_STAGES8")) : 0; return v; }
 
 // -1: this problem does not fit the direct-to-LDS forms (caller keeps the register-staged kernel)
@@ -60,6 +62,15 @@ int launch_gemm_glds(const BArgs& k0, int amode, int bmode, int c_bf16, int BMt,
     static const int tall = getenv("SAT_GLDS_TALL") ? atoi(getenv("SAT_GLDS_TALL")) : 2;      // 0 off, 1 row-major A only, 2 also k-major A (1x1 weight gradients)
     int tile = (BMt >= 256) ? (BMt == 256 ? TILE_256 : TILE_256x128) : (BMt == 128 ? TILE_128 : TILE_64);      // BMt: 64, 128, 256 (= 256x256), 257 (= 256x128)
     if (tile == TILE_64 && tall && bmode != B_CONV_WGRAD && k.N <= 64 && (amode == A_KMAJOR ? (tall > 1 && k.M >= 128) : k.M >= 8192)) tile = TILE_128x64;
+    // 128 x 64 instead of 128 x 128 for the dense row-major products (1x1 convolutions forward / data gradient, the decoder's wide products) and for
+    // the 3x3 forward / data-gradient forms up to K = 1152 (64 and 128 input channels): twice the workgroups at half the accumulators - four to
+    // five resident per CU instead of three, which hides more of each workgroup's load / store phases than the second filter-tile read costs.
+    // Whole-step A/B (tools/ab_step.py, round 3): C2 21.93 -> 21.40 ms with the dense rule, 21.16 with both; C3 shard 14.54 -> 14.08; C4 shard
+    // 34.00 -> 33.79 (its 3x3 forms with K >= 2304 keep 128 x 128: with them on 128 x 64 the step is 34.9); C1 unchanged.  Split-K launches,
+    // k-major operands (weight gradients) and the filter-gradient forms keep 128 x 128.  (sat_debug_option "glds_tall_k" / "glds_tall_conv": the
+    // largest reduction length that takes the narrow tile, 0 = off.)
+    if (tile == TILE_128 && bmode != B_CONV_WGRAD && k.nsplit <= 1 &&
+        ((amode == A_ROW && k.K <= glds_tall_k()) || ((amode == A_CONV_FWD || amode == A_CONV_DGRAD) && k.K <= glds_tall_conv()))) tile = TILE_128x64;
     if (force_tile >= 0) tile = force_tile;
     if (tile == TILE_256 || tile == TILE_256x128) {          // one workgroup per CU: the ring may be three deep on 256x128 (144 KiB), two on 256x256
         const int maxs = (tile == TILE_256) ? 2 : 3;

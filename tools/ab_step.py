@@ -17,7 +17,7 @@ model.__dict__["_sat_global_step"] = 2
 opt = model.configure_optimizers()
 img, caps, lengths = bench.synthetic_batch(B, R, T, hp["vocab_size"], 1234, False)
 img, caps = img.cuda(), caps.cuda()
-DEFAULTS = {"bn_ticket": 0, "bn_onepass": 1, "bn_vpt": 2, "acc_prefetch": 0, "wgrad3x3": 1, "reduce_z16": 1, "wide_tiles": 0, "py:bn_bwd_epilogue": 1, "py:wgrad_stream": 1, "py:wgrad_streams": 1, "py:dgrad_join": 1, "py:fwd_res_bn": 1, "py:hi_prio": 0, "py:wgrad_side_only": 0}
+DEFAULTS = {"glds_tall_k": 1 << 30, "glds_tall_conv": 1152, "bn_onepass": 1, "bn_vpt": 2, "acc_prefetch": 0, "wgrad3x3": 1, "reduce_z16": 1, "wide_tiles": 0, "py:bn_bwd_epilogue": 1, "py:wgrad_stream": 1, "py:wgrad_streams": 1, "py:dgrad_join": 1, "py:fwd_res_bn": 1, "py:hi_prio": 0, "py:wgrad_side_only": 0}
 
 
 def apply(settings):
