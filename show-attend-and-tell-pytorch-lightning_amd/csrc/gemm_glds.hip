@@ -52,7 +52,10 @@ int launch_gemm_glds(const BArgs& k0, int amode, int bmode, int c_bf16, int BMt,
     // a single k-tile needs one stage: less LDS, a third workgroup per CU for the streaming 1x1 layers with 64 input channels
     // short reductions into a bf16 result (<= 168 VGPRs): one stage leaves room for a third workgroup per CU, which hides more of
     // the launch / load / store phases of these latency-bound tiles than the second stage does
-    static const int s1_upto = getenv("SAT_GLDS_S1_UPTO") ? atoi(getenv("SAT_GLDS_S1_UPTO")) : 1;
+    // (round 3, with the 128 x 64 tiles: EVERY bf16-result launch keeps one stage - the resident workgroups hide each other's latencies better than
+    // a second stage of the same workgroup does: C2 21.26 -> 21.00 ms, C3 shard 14.19 -> 13.87, C4 shard 33.97 -> 33.79; fp32 results keep two
+    // stages: one stage everywhere is 0.2 ms slower at C2)
+    static const int s1_upto = getenv("SAT_GLDS_S1_UPTO") ? atoi(getenv("SAT_GLDS_S1_UPTO")) : 1 << 30;
     k.nstage = force_stages ? force_stages : (ktiles >= deep_from ? 4 : ((ktiles == 1 || (c_bf16 && ktiles <= s1_upto)) ? 1 : 2));
     k.rotate = rotate;
     if (k.nstage < 1) k.nstage = 1;
@@ -69,8 +72,11 @@ int launch_gemm_glds(const BArgs& k0, int amode, int bmode, int c_bf16, int BMt,
     // 34.00 -> 33.79 (its 3x3 forms with K >= 2304 keep 128 x 128: with them on 128 x 64 the step is 34.9); C1 unchanged.  Split-K launches,
     // k-major operands (weight gradients) and the filter-gradient forms keep 128 x 128.  (sat_debug_option "glds_tall_k" / "glds_tall_conv": the
     // largest reduction length that takes the narrow tile, 0 = off.)
+    // ... and longer 3x3 reductions when 128 x 128 tiles would not give every CU two workgroups (C2's last stage: 8192 rows x 512 filters = 256
+    // tiles; C4's 16384 x 512 = 512 tiles stays on 128 x 128: narrow tiles there cost 1 ms of its 33.7)
+    static const int tall_conv_tiles = getenv("SAT_GLDS_TALL_CONV_TILES") ? atoi(getenv("SAT_GLDS_TALL_CONV_TILES")) : 512;
     if (tile == TILE_128 && bmode != B_CONV_WGRAD && k.nsplit <= 1 &&
-        ((amode == A_ROW && k.K <= glds_tall_k()) || ((amode == A_CONV_FWD || amode == A_CONV_DGRAD) && k.K <= glds_tall_conv()))) tile = TILE_128x64;
+        ((amode == A_ROW && k.K <= glds_tall_k()) || ((amode == A_CONV_FWD || amode == A_CONV_DGRAD) && (k.K <= glds_tall_conv() || (long)cdiv(k.M, 128) * cdiv(k.N, 128) < tall_conv_tiles)))) tile = TILE_128x64;
     if (force_tile >= 0) tile = force_tile;
     if (tile == TILE_256 || tile == TILE_256x128) {          // one workgroup per CU: the ring may be three deep on 256x128 (144 KiB), two on 256x256
         const int maxs = (tile == TILE_256) ? 2 : 3;
