@@ -80,10 +80,12 @@ __device__ __forceinline__ void put(const BArgs& a, int row, int col, float v) {
 // stored (the bf16-rounded, accumulated ones: exactly what the BatchNorm backward will read back), the threads of a column group are
 // combined by wave shuffles and through `sbuf` ([waves][BN][2] floats behind the staged tile) in a fixed order, and the tile's
 // (sum g, sum g * xhat) per column lands in tile_stats[tile][column] like the forward statistics do.
-template <int BM, int BN, int NTHR>
+// EN = false (the forward forms of the direct-to-LDS kernel, which never carry bn_x): nothing of this is compiled in - as a run-time "off" the
+// struct still cost those launches its ~40 VGPRs, i.e. a resident workgroup per CU.
+template <int BM, int BN, int NTHR, bool EN = true>
 struct BnAcc {
     static constexpr int VPR = BN / 8, NWV = NTHR / 64, NJ0 = BM * VPR / NTHR;
-    static constexpr bool BUILT = NJ0 <= 8;          // the 256x256 form (16 segments per thread on top of 128 accumulator registers) is not: the launcher never asks it
+    static constexpr bool BUILT = EN && NJ0 <= 8;          // the 256x256 form (16 segments per thread on top of 128 accumulator registers) is not: the launcher never asks it
     static constexpr int NJ = BUILT ? NJ0 : 1;
     static_assert(NTHR % VPR == 0 && 64 % VPR == 0, "a thread keeps one column group");
     float s1[8], s2[8], mu[8], is[8];
@@ -145,9 +147,9 @@ struct BnAcc {
 // Accumulator tile -> C.  acc[i][j] is the 32x32 MFMA block (i, j) of this wave's (BM/2 x BN/2) quadrant at (wm, wn);
 // C/D layout of v_mfma_f32_32x32x16_bf16: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
 // `smem` is the kernel's operand staging area (free once the k loop is over), `smem_elems` its size in bf16.
-template <int BM, int BN, typename TC, int SMEM_ELEMS, bool APF = false>
+template <int BM, int BN, typename TC, int SMEM_ELEMS, bool APF = false, bool BNS = true>
 __device__ __forceinline__ void store_tile(const BArgs& a, f32x16 (&acc)[BM / 64][BN / 64], __bf16* smem, int bm, int bn, int bz, int wm, int wn,
-                                           int tid, int lane, BnAcc<BM, BN, NT>& bacc, bool prefetched /* statistics operands fetched by the caller already */) {
+                                           int tid, int lane, BnAcc<BM, BN, NT, BNS>& bacc, bool prefetched /* statistics operands fetched by the caller already */) {
     constexpr int TM = BM / 64, TN = BN / 64;
     const int li = lane & 31, lh = lane >> 5;
     if (sizeof(TC) == 2 && a.wide_store) {
@@ -312,9 +314,9 @@ __device__ __forceinline__ void store_tile(const BArgs& a, f32x16 (&acc)[BM / 64
 template <int BM, int BN, int WR, int WC, typename TC> constexpr size_t store_lds_bytes() {
     return sizeof(TC) == 2 ? (size_t)BM * (BN + 8) * 2 + (size_t)WR * WC * BN * 2 * 4 : (size_t)(BM / WR) * (BN + 4) * 4;
 }
-template <int BM, int BN, int WR, int WC, typename TC>
+template <int BM, int BN, int WR, int WC, typename TC, bool BNS = true>
 __device__ __forceinline__ void store_tile_w(const BArgs& a, f32x16 (&acc)[BM / WR / 32][BN / WC / 32], __bf16* smem, int bm, int bn, int bz, int wm, int wn,
-                                             int wrow, int tid, int lane, BnAcc<BM, BN, 64 * WR * WC>& bacc, bool prefetched) {
+                                             int wrow, int tid, int lane, BnAcc<BM, BN, 64 * WR * WC, BNS>& bacc, bool prefetched) {
     constexpr int TM = BM / WR / 32, TN = BN / WC / 32, NTH = 64 * WR * WC;
     const int li = lane & 31, lh = lane >> 5;
     if (sizeof(TC) == 2 && a.wide_store) {

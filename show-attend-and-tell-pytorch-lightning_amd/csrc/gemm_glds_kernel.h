@@ -289,7 +289,8 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_glds_kernel(BArgs a) {
     // BatchNorm-backward statistics (data-gradient launches, bf16 result): the tile's slice of the BatchNorm input and its sign bits are
     // fetched NOW, so that the loads fly under the whole k loop instead of in front of the write phase (they were 3 us of exposed
     // latency per tile there).  In-order completion keeps the counted waits below valid: these loads are older than every LDS-DMA.
-    BnAcc<BM, BN, 64 * NW> bnacc(a, bn, tid);
+    constexpr bool BNS = (AM == A_CONV_DGRAD) || (AM == A_ROW && BMo == B_KMAJOR);          // the data-gradient forms: the only ones that carry bn_x
+    BnAcc<BM, BN, 64 * NW, BNS> bnacc(a, bn, tid);
     if constexpr (sizeof(TC) == 2) { bnacc.prefetch(a, bm, bn, tid); __builtin_amdgcn_sched_barrier(0); }      // issued here, not sunk to their use
 
     // ---- per-lane fragment read offsets (elements)
@@ -401,8 +402,8 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_glds_kernel(BArgs a) {
             for (int j = 0; j < TN; ++j) keep_alive(acc[i][j]);
         return;
     }
-    if constexpr (WR == 2 && WC == 2) store_tile<BM, BN, TC, 2 * STAGE, APF>(a, acc, smem, bm, bn, bz, wm, wn, tid, lane, bnacc, sizeof(TC) == 2);
-    else store_tile_w<BM, BN, WR, WC, TC>(a, acc, smem, bm, bn, bz, wm, wn, wrow, tid, lane, bnacc, sizeof(TC) == 2);      // the launch allocates at least the epilogue's staging size
+    if constexpr (WR == 2 && WC == 2) store_tile<BM, BN, TC, 2 * STAGE, APF, BNS>(a, acc, smem, bm, bn, bz, wm, wn, tid, lane, bnacc, sizeof(TC) == 2);
+    else store_tile_w<BM, BN, WR, WC, TC, BNS>(a, acc, smem, bm, bn, bz, wm, wn, wrow, tid, lane, bnacc, sizeof(TC) == 2);      // the launch allocates at least the epilogue's staging size
 }
 
 static const char* gname(int am, int bm) {
