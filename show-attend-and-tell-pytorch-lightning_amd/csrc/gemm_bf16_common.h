@@ -82,15 +82,19 @@ __device__ __forceinline__ void put(const BArgs& a, int row, int col, float v) {
 // (sum g, sum g * xhat) per column lands in tile_stats[tile][column] like the forward statistics do.
 // EN = false (the forward forms of the direct-to-LDS kernel, which never carry bn_x): nothing of this is compiled in - as a run-time "off" the
 // struct still cost those launches its ~40 VGPRs, i.e. a resident workgroup per CU.
-template <int BM, int BN, int NTHR, bool EN = true>
+// PF = false (-DSAT_GLDS_BN_PREFETCH=0): the BatchNorm input and its sign bits are read inside the write loop instead of ahead of the k loop -
+// 94 instead of 110 VGPRs, a fourth resident workgroup per CU for the 128 x 64 data-gradient launches.  Measured on one box, both builds: C2
+// 20.30 (prefetch) vs 20.41 ms, C4 shard 33.30 vs 33.08: a wash, the prefetch stays.
+template <int BM, int BN, int NTHR, bool EN = true, bool PF = true>
 struct BnAcc {
     static constexpr int VPR = BN / 8, NWV = NTHR / 64, NJ0 = BM * VPR / NTHR;
     static constexpr bool BUILT = EN && NJ0 <= 8;          // the 256x256 form (16 segments per thread on top of 128 accumulator registers) is not: the launcher never asks it
     static constexpr int NJ = BUILT ? NJ0 : 1;
     static_assert(NTHR % VPR == 0 && 64 % VPR == 0, "a thread keeps one column group");
     float s1[8], s2[8], mu[8], is[8];
-    bf16x8 xv[NJ]; unsigned mb[NJ];          // the thread's segments of the BatchNorm input and their sign bits, fetched before the write phase
+    bf16x8 xv[PF ? NJ : 1]; unsigned mb[PF ? NJ : 1];          // the thread's segments of the BatchNorm input and their sign bits, fetched before the write phase
     bool on;
+    const BArgs* ap; int bm0, bn0, tid0;          // PF = false: where to read them from in add()
     __device__ __forceinline__ BnAcc(const BArgs& a, int bn, int tid) {
         on = BUILT && a.bn_x != nullptr && a.tile_stats != nullptr;
         const int col = bn + (tid % VPR) * 8;
@@ -104,8 +108,9 @@ struct BnAcc {
     // issue the loads of every row segment this thread will write (rows past M: nothing to add, sign bits 0)
     __device__ __forceinline__ void prefetch(const BArgs& a, int bm, int bn, int tid) {
         if (!on) return;
+        if constexpr (!PF) { ap = &a; bm0 = bm; bn0 = bn; tid0 = tid; return; }
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
+        for (int j = 0; j < (PF ? NJ : 0); ++j) {
             const int v = tid + j * NTHR, row = bm + v / VPR, col = bn + (v % VPR) * 8;
             const bool ok = row < a.M && col < a.N;
             const long elem = ok ? (long)row * a.ldc + col : 0;
@@ -115,10 +120,20 @@ struct BnAcc {
     }
     __device__ __forceinline__ void add(int j, const bf16x8& o) {
         if (!on || j >= NJ) return;
+        bf16x8 x; unsigned m;
+        if constexpr (PF) { x = xv[j]; m = mb[j]; }
+        else {
+            const BArgs& a = *ap;
+            const int v = tid0 + j * NTHR, row = bm0 + v / VPR, col = bn0 + (v % VPR) * 8;
+            const bool ok = row < a.M && col < a.N;
+            const long elem = ok ? (long)row * a.ldc + col : 0;
+            x = *reinterpret_cast<const bf16x8*>(a.bn_x + elem);
+            m = ok ? (a.bn_mask ? (unsigned)a.bn_mask[elem >> 3] : 0xFFu) : 0u;
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float g = ((mb[j] >> e) & 1u) ? (float)o[e] : 0.f;
-            s1[e] += g; s2[e] = fmaf(g, ((float)xv[j][e] - mu[e]) * is[e], s2[e]);
+            const float g = ((m >> e) & 1u) ? (float)o[e] : 0.f;
+            s1[e] += g; s2[e] = fmaf(g, ((float)x[e] - mu[e]) * is[e], s2[e]);
         }
     }
     __device__ __forceinline__ void finish(const BArgs& a, float* sbuf, int tile, int bn, int tid) {
@@ -147,9 +162,9 @@ struct BnAcc {
 // Accumulator tile -> C.  acc[i][j] is the 32x32 MFMA block (i, j) of this wave's (BM/2 x BN/2) quadrant at (wm, wn);
 // C/D layout of v_mfma_f32_32x32x16_bf16: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
 // `smem` is the kernel's operand staging area (free once the k loop is over), `smem_elems` its size in bf16.
-template <int BM, int BN, typename TC, int SMEM_ELEMS, bool APF = false, bool BNS = true>
+template <int BM, int BN, typename TC, int SMEM_ELEMS, bool APF = false, bool BNS = true, bool BPF = true>
 __device__ __forceinline__ void store_tile(const BArgs& a, f32x16 (&acc)[BM / 64][BN / 64], __bf16* smem, int bm, int bn, int bz, int wm, int wn,
-                                           int tid, int lane, BnAcc<BM, BN, NT, BNS>& bacc, bool prefetched /* statistics operands fetched by the caller already */) {
+                                           int tid, int lane, BnAcc<BM, BN, NT, BNS, BPF>& bacc, bool prefetched /* statistics operands fetched by the caller already */) {
     constexpr int TM = BM / 64, TN = BN / 64;
     const int li = lane & 31, lh = lane >> 5;
     if (sizeof(TC) == 2 && a.wide_store) {
@@ -314,9 +329,9 @@ __device__ __forceinline__ void store_tile(const BArgs& a, f32x16 (&acc)[BM / 64
 template <int BM, int BN, int WR, int WC, typename TC> constexpr size_t store_lds_bytes() {
     return sizeof(TC) == 2 ? (size_t)BM * (BN + 8) * 2 + (size_t)WR * WC * BN * 2 * 4 : (size_t)(BM / WR) * (BN + 4) * 4;
 }
-template <int BM, int BN, int WR, int WC, typename TC, bool BNS = true>
+template <int BM, int BN, int WR, int WC, typename TC, bool BNS = true, bool BPF = true>
 __device__ __forceinline__ void store_tile_w(const BArgs& a, f32x16 (&acc)[BM / WR / 32][BN / WC / 32], __bf16* smem, int bm, int bn, int bz, int wm, int wn,
-                                             int wrow, int tid, int lane, BnAcc<BM, BN, 64 * WR * WC, BNS>& bacc, bool prefetched) {
+                                             int wrow, int tid, int lane, BnAcc<BM, BN, 64 * WR * WC, BNS, BPF>& bacc, bool prefetched) {
     constexpr int TM = BM / WR / 32, TN = BN / WC / 32, NTH = 64 * WR * WC;
     const int li = lane & 31, lh = lane >> 5;
     if (sizeof(TC) == 2 && a.wide_store) {

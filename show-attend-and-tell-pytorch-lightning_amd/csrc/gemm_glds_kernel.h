@@ -89,6 +89,9 @@ struct PixEnt { int off; unsigned mask; };   // wgrad: byte offset of the input 
 // WR x WC waves per workgroup; wave (wr, wc) owns the (BM / WR) x (BN / WC) block of the tile.  2 x 2 waves on 128x128 (and 128x64,
 // 64x64) is the original form; 4 x 2 waves on 256x128 and 256x256 tiles (one workgroup per CU) halve the L2 -> LDS traffic per
 // product and, on 256x256, read 6 LDS fragments per 8 MFMAs instead of 4 per 4.
+#ifndef SAT_GLDS_BN_PREFETCH
+#define SAT_GLDS_BN_PREFETCH 1
+#endif
 template <int BM, int BN, int WR, int WC, int AM, int BMo, typename TC, bool APF = false>
 __global__ __launch_bounds__(64 * WR * WC) void gemm_glds_kernel(BArgs a) {
     constexpr int KB = 64;
@@ -290,7 +293,8 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_glds_kernel(BArgs a) {
     // fetched NOW, so that the loads fly under the whole k loop instead of in front of the write phase (they were 3 us of exposed
     // latency per tile there).  In-order completion keeps the counted waits below valid: these loads are older than every LDS-DMA.
     constexpr bool BNS = (AM == A_CONV_DGRAD) || (AM == A_ROW && BMo == B_KMAJOR);          // the data-gradient forms: the only ones that carry bn_x
-    BnAcc<BM, BN, 64 * NW, BNS> bnacc(a, bn, tid);
+    constexpr bool BPF = SAT_GLDS_BN_PREFETCH;
+    BnAcc<BM, BN, 64 * NW, BNS, BPF> bnacc(a, bn, tid);
     if constexpr (sizeof(TC) == 2) { bnacc.prefetch(a, bm, bn, tid); __builtin_amdgcn_sched_barrier(0); }      // issued here, not sunk to their use
 
     // ---- per-lane fragment read offsets (elements)
@@ -402,8 +406,8 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_glds_kernel(BArgs a) {
             for (int j = 0; j < TN; ++j) keep_alive(acc[i][j]);
         return;
     }
-    if constexpr (WR == 2 && WC == 2) store_tile<BM, BN, TC, 2 * STAGE, APF, BNS>(a, acc, smem, bm, bn, bz, wm, wn, tid, lane, bnacc, sizeof(TC) == 2);
-    else store_tile_w<BM, BN, WR, WC, TC, BNS>(a, acc, smem, bm, bn, bz, wm, wn, wrow, tid, lane, bnacc, sizeof(TC) == 2);      // the launch allocates at least the epilogue's staging size
+    if constexpr (WR == 2 && WC == 2) store_tile<BM, BN, TC, 2 * STAGE, APF, BNS, BPF>(a, acc, smem, bm, bn, bz, wm, wn, tid, lane, bnacc, sizeof(TC) == 2);
+    else store_tile_w<BM, BN, WR, WC, TC, BNS, BPF>(a, acc, smem, bm, bn, bz, wm, wn, wrow, tid, lane, bnacc, sizeof(TC) == 2);      // the launch allocates at least the epilogue's staging size
 }
 
 static const char* gname(int am, int bm) {
