@@ -91,19 +91,17 @@ struct BnAcc {
     static constexpr bool BUILT = EN && NJ0 <= 8;          // the 256x256 form (16 segments per thread on top of 128 accumulator registers) is not: the launcher never asks it
     static constexpr int NJ = BUILT ? NJ0 : 1;
     static_assert(NTHR % VPR == 0 && 64 % VPR == 0, "a thread keeps one column group");
-    float s1[8], s2[8], mu[8], is[8];
+    float s1[8], s2[8], mu[8];          // sum g, sum g * (x - mean): the scale 1 / std is applied once per column in finish() (8 registers less in the write loop)
     bf16x8 xv[PF ? NJ : 1]; unsigned mb[PF ? NJ : 1];          // the thread's segments of the BatchNorm input and their sign bits, fetched before the write phase
     bool on;
     const BArgs* ap; int bm0, bn0, tid0;          // PF = false: where to read them from in add()
-    __device__ __forceinline__ BnAcc(const BArgs& a, int bn, int tid) {
-        on = BUILT && a.bn_x != nullptr && a.tile_stats != nullptr;
+    __device__ __forceinline__ BnAcc(const BArgs& a, int bn, int tid) { on = BUILT && a.bn_x != nullptr && a.tile_stats != nullptr; }
+    // the per-column constants and the accumulators come to life in front of the write loop, not in front of the k loop (32 registers that the
+    // main loop does not have to carry)
+    __device__ __forceinline__ void begin(const BArgs& a, int bn, int tid) {
         const int col = bn + (tid % VPR) * 8;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            s1[e] = 0.f; s2[e] = 0.f;
-            const bool ok = on && col + e < a.N;
-            mu[e] = ok ? a.bn_mean[col + e] : 0.f; is[e] = ok ? a.bn_invstd[col + e] : 0.f;
-        }
+        for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; mu[e] = (on && col + e < a.N) ? a.bn_mean[col + e] : 0.f; }
     }
     // issue the loads of every row segment this thread will write (rows past M: nothing to add, sign bits 0)
     __device__ __forceinline__ void prefetch(const BArgs& a, int bm, int bn, int tid) {
@@ -133,7 +131,7 @@ struct BnAcc {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float g = ((m >> e) & 1u) ? (float)o[e] : 0.f;
-            s1[e] += g; s2[e] = fmaf(g, ((float)x[e] - mu[e]) * is[e], s2[e]);
+            s1[e] += g; s2[e] = fmaf(g, (float)x[e] - mu[e], s2[e]);
         }
     }
     __device__ __forceinline__ void finish(const BArgs& a, float* sbuf, int tile, int bn, int tid) {
@@ -154,7 +152,7 @@ struct BnAcc {
 #pragma unroll
             for (int w = 0; w < NWV; ++w) { t1 += sbuf[((long)w * BN + tid) * 2]; t2 += sbuf[((long)w * BN + tid) * 2 + 1]; }
             float* o = a.tile_stats + ((long)tile * a.N + bn + tid) * 2;
-            o[0] = t1; o[1] = t2;
+            o[0] = t1; o[1] = t2 * a.bn_invstd[bn + tid];          // sum g * xhat = invstd * sum g * (x - mean)
         }
     }
 };
@@ -174,6 +172,7 @@ __device__ __forceinline__ void store_tile(const BArgs& a, f32x16 (&acc)[BM / 64
         static_assert(BM * LDC <= SMEM_ELEMS, "C tile must fit the staging buffers");
         __bf16* cs = smem;
         if (!prefetched) bacc.prefetch(a, bm, bn, tid);           // in flight while the tile is staged
+        bacc.begin(a, bn, tid);
         __syncthreads();
         if (a.tile_stats && !a.bn_x) {
             // BatchNorm statistics of the tile while it is still in registers (one HBM pass less for the layer that follows):
@@ -338,6 +337,7 @@ __device__ __forceinline__ void store_tile_w(const BArgs& a, f32x16 (&acc)[BM / 
         constexpr int LDC = BN + 8;
         __bf16* cs = smem;
         if (!prefetched) bacc.prefetch(a, bm, bn, tid);           // in flight while the tile is staged
+        bacc.begin(a, bn, tid);
         __syncthreads();
         if (a.tile_stats && !a.bn_x) {
             float* sbuf = reinterpret_cast<float*>(smem + BM * LDC);           // [WR wave rows][BN][2], behind the staged tile
