@@ -93,7 +93,7 @@ struct PixEnt { int off; unsigned mask; };   // wgrad: byte offset of the input 
 #define SAT_GLDS_BN_PREFETCH 1
 #endif
 template <int BM, int BN, int WR, int WC, int AM, int BMo, typename TC, bool APF = false>
-__global__ __launch_bounds__(64 * WR * WC, (BM == 128 && BN == 64 && sizeof(TC) == 2) ? 4 : ((BM == 128 && BN == 128 && sizeof(TC) == 4) ? 3 : 1)) void gemm_glds_kernel(BArgs a) {          // 128 x 64, bf16 result: four resident workgroups per CU (the 3x3 data-gradient form sat at 97 VGPRs, one over)
+__global__ __launch_bounds__(64 * WR * WC, (BM == 128 && BN == 64 && sizeof(TC) == 2) ? ((AM == A_ROW && BMo == B_ROW) ? 6 : 4) : ((BM == 128 && BN == 128 && sizeof(TC) == 4) ? 3 : 1)) void gemm_glds_kernel(BArgs a) {          // 128 x 64, bf16 result: four resident workgroups per CU (the 3x3 data-gradient form sat at 97 VGPRs, one over)
     constexpr int KB = 64;
     constexpr int NW = WR * WC;
     constexpr bool AK = (AM == A_KMAJOR);
